@@ -1,0 +1,130 @@
+"""Pin the oracle's kernel formulas against independent symbolic differentiation.
+
+Mirrors `tests/linpde_gp/randprocs/kernels/linfuncops/diffops/test_diffops.py:30-42`
+of the reference (closed form vs autodiff of the base kernel), with SymPy + 50-digit
+mpmath in place of JAX (not installed here).
+"""
+from fractions import Fraction
+
+import mpmath
+import numpy as np
+import pytest
+import sympy as sp
+
+from oracle import covfuncs, polynomials
+
+mpmath.mp.dps = 50
+
+
+def test_matern_base_coefficients():
+    # SURVEY.md §8(a) A1 / probnum Matern.half_integer_coefficients
+    assert polynomials.matern_half_integer_coefficients(0) == (1,)
+    assert polynomials.matern_half_integer_coefficients(1) == (1, 1)
+    assert polynomials.matern_half_integer_coefficients(2) == (1, 1, Fraction(1, 3))
+    assert polynomials.matern_half_integer_coefficients(3) == (
+        1, 1, Fraction(2, 5), Fraction(1, 15))
+
+
+def test_matern_derivative_polynomials_known_values():
+    P = polynomials.matern_derivative_polynomial
+    F = Fraction
+    # p = 1
+    assert [P(1, n) for n in range(5)] == [(1, 1), (0, -1), (-1, 1), (2, -1), (-3, 1)]
+    # p = 2 (nu = 5/2), the table behind the Poisson configs
+    assert P(2, 1) == (0, F(-1, 3), F(-1, 3))
+    assert P(2, 2) == (F(-1, 3), F(-1, 3), F(1, 3))
+    assert P(2, 3) == (0, 1, F(-1, 3))
+    assert P(2, 4) == (1, F(-5, 3), F(1, 3))
+    # p = 3
+    assert P(3, 2) == (F(-1, 5), F(-1, 5), 0, F(1, 15))
+    assert P(3, 4) == (F(1, 5), F(1, 5), F(-2, 5), F(1, 15))
+
+
+def test_hermite():
+    H = polynomials.hermite_polynomial
+    assert H(0) == (1,)
+    assert H(1) == (0, 1)
+    assert H(2) == (-1, 0, 1)
+    assert H(3) == (0, -3, 0, 1)
+    assert H(4) == (3, 0, -6, 0, 1)
+
+
+def _sympy_matern(p, a):
+    """(expr for x>y, expr for x<y) of kappa_p(a|x-y|)."""
+    x, y = sp.symbols("x y", real=True)
+    c = polynomials.matern_half_integer_coefficients(p)
+    out = []
+    for s in (a * (x - y), a * (y - x)):
+        out.append(sum(sp.Rational(ck.numerator, ck.denominator) * s**k
+                       for k, ck in enumerate(c)) * sp.exp(-s))
+    return x, y, out
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_matern_factor_vs_sympy(p):
+    nu = p + 0.5
+    ell = 0.7
+    a_exact = sp.sqrt(2 * sp.Rational(2 * p + 1, 2)) / sp.Rational(7, 10)
+    x, y, (e_gt, e_lt) = _sympy_matern(p, a_exact)
+    rng = np.random.default_rng(390852098 + p)
+    x0 = rng.uniform(-3, 3, size=24)
+    x1 = rng.uniform(-3, 3, size=24)
+    # mean-square differentiability: total order <= 2p
+    orders = [(n0, n1) for n0 in range(0, 3) for n1 in range(0, 3) if n0 + n1 <= 2 * p]
+    for n0, n1 in orders:
+        got = covfuncs.matern_factor(nu, ell, n0, n1, x0, x1)
+        f_gt = sp.lambdify((x, y), sp.diff(e_gt, x, n0, y, n1), "mpmath")
+        f_lt = sp.lambdify((x, y), sp.diff(e_lt, x, n0, y, n1), "mpmath")
+        ref = np.array([
+            float((f_gt if xi > yi else f_lt)(mpmath.mpf(float(xi)), mpmath.mpf(float(yi))))
+            for xi, yi in zip(x0, x1)
+        ])
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14,
+                                   err_msg=f"p={p} orders=({n0},{n1})")
+
+
+def test_expquad_factor_vs_sympy():
+    ell = 0.25
+    x, y = sp.symbols("x y", real=True)
+    e = sp.exp(-(x - y) ** 2 / (2 * sp.Rational(1, 4) ** 2))
+    rng = np.random.default_rng(4158)
+    x0 = rng.uniform(-1, 1, size=24)
+    x1 = rng.uniform(-1, 1, size=24)
+    for n0 in range(3):
+        for n1 in range(3):
+            f = sp.lambdify((x, y), sp.diff(e, x, n0, y, n1), "mpmath")
+            ref = np.array([float(f(mpmath.mpf(float(a)), mpmath.mpf(float(b))))
+                            for a, b in zip(x0, x1)])
+            got = covfuncs.expquad_factor(ell, n0, n1, x0, x1)
+            np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12 * max(1, np.abs(ref).max()))
+
+
+def test_poisson2d_LkL_closed_form():
+    """sigma^2 alpha^2 e^{-(s1+s2)}[a^4 P4 P0 + 2 a^4 P2 P2 + a^4 P0 P4]."""
+    rng = np.random.default_rng(24)
+    X0 = rng.uniform(-1, 1, size=(17, 2))
+    X1 = rng.uniform(-1, 1, size=(13, 2))
+    kernel = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
+    lap = {(2, 0): -1.0, (0, 2): -1.0}
+    got = covfuncs.LkL(kernel, lap, lap, X0, X1)
+    a = np.sqrt(5.0)
+    s1 = a * np.abs(X0[:, None, 0] - X1[None, :, 0])
+    s2 = a * np.abs(X0[:, None, 1] - X1[None, :, 1])
+    P = lambda n, s: polynomials.horner(polynomials.matern_derivative_polynomial(2, n), s)
+    ref = 4.0 * np.exp(-(s1 + s2)) * (
+        a**4 * P(4, s1) * P(0, s2) + 2 * a**4 * P(2, s1) * P(2, s2) + a**4 * P(0, s1) * P(4, s2))
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-13)
+    cross = covfuncs.LkL(kernel, covfuncs.identity(2), lap, X0, X1)
+    ref_c = -4.0 * np.exp(-(s1 + s2)) * (a**2 * P(2, s1) * P(0, s2) + a**2 * P(0, s1) * P(2, s2))
+    np.testing.assert_allclose(cross, ref_c, rtol=1e-13, atol=1e-13)
+
+
+def test_tensor_product_expquad_equals_multivariate():
+    # tests/linpde_gp/randprocs/kernels/test_tensor_product.py:39-47
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(20, 3))
+    ls = np.array([0.4, 1.3, 0.9])
+    kernel = [(1.0, [("expquad", l) for l in ls])]
+    got = covfuncs.LkL(kernel, covfuncs.identity(3), covfuncs.identity(3), X)
+    D = (X[:, None, :] - X[None, :, :]) / ls
+    np.testing.assert_allclose(got, np.exp(-0.5 * np.sum(D * D, axis=-1)), rtol=1e-13)
