@@ -1,0 +1,168 @@
+/*
+ * lpgp.h -- C ABI of the MI355X-native GP-posterior hot path of linpde-gp.
+ *
+ * Every entry point replaces a call site of the reference's two Python plug-in
+ * protocols, cited as /root/reference/src/linpde_gp/<file>:<line>.
+ * Plain pointers and sizes only; no torch types.  Host pointers are BORROWED for
+ * the duration of a call; device state lives behind opaque handles that the caller
+ * frees explicitly.  All calls are synchronous from the caller's point of view
+ * unless stated otherwise.  Return value: 0 = ok, <0 = error (text in
+ * lpgp_last_error()).  fp64 everywhere, C-order host arrays.
+ */
+#ifndef LPGP_H
+#define LPGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPGP_MAXD 4      /* input dimension of a tensor-product kernel            */
+#define LPGP_MAXT 64     /* terms of the expansion  sum_t c_t prod_d d^{n0} d'^{n1} k_d */
+#define LPGP_MAXG 4      /* summands of a sum kernel                              */
+
+enum lpgp_family { LPGP_MATERN_HALFINT = 1, LPGP_EXPQUAD = 2 };
+
+typedef struct lpgp_ctx lpgp_ctx;   /* one per process / per GPU                          */
+typedef struct lpgp_pts lpgp_pts;   /* device-resident point set (n x d)                  */
+typedef struct lpgp_mat lpgp_mat;   /* device-resident SPD matrix -> Cholesky factor      */
+typedef struct lpgp_rhs lpgp_rhs;   /* device-resident n x m block of right-hand sides    */
+
+/* One term  coef * prod_d  d^{n0[d]}/dx_d^{n0[d]}  d^{n1[d]}/dx'_d^{n1[d]}  k_d(x_d, x'_d)
+ * of `TensorProduct_LinDiffOp_LinDiffOp.__init__`
+ * (randprocs/covfuncs/linfuncops/diffops/_tensor_product.py:38-67).                     */
+typedef struct {
+  double  coef;
+  int32_t n0[LPGP_MAXD];
+  int32_t n1[LPGP_MAXD];
+} lpgp_term;
+
+/* One scaled tensor-product kernel with both operators applied:
+ *   scale * sum_t terms[t]      ( = L0 (scale * k_1 (x) ... (x) k_d) L1'^* ).
+ * family/p/lengthscale per dimension: Matern nu = p + 1/2 (probnum Matern, scale factor
+ * sqrt(2 nu)/lengthscale; diffops/_matern.py:17-639) or ExpQuad
+ * exp(-(x-x')^2/(2 l^2)) (diffops/_expquad.py:12-433).                                   */
+typedef struct {
+  int32_t   d;
+  int32_t   family[LPGP_MAXD];
+  int32_t   p[LPGP_MAXD];
+  double    lengthscale[LPGP_MAXD];
+  double    scale;
+  int32_t   nterms;
+  lpgp_term terms[LPGP_MAXT];
+} lpgp_kdesc;
+
+/* ---- context ------------------------------------------------------------------------ */
+int  lpgp_init(int device, lpgp_ctx** ctx);
+int  lpgp_finalize(lpgp_ctx* ctx);
+const char* lpgp_last_error(void);
+/* name (<= len bytes), compute units, HBM bytes of the device behind ctx */
+int  lpgp_device_info(lpgp_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_bytes);
+int  lpgp_sync(lpgp_ctx* ctx);                       /* hipDeviceSynchronize */
+/* tuning knobs (env LPGP_NB / LPGP_LOOKAHEAD give the defaults): panel width of the
+ * blocked Cholesky (multiple of 128) and look-ahead on/off                              */
+int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
+
+/* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) ----- */
+int  lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out);
+int  lpgp_pts_destroy(lpgp_pts* pts);
+
+/* ---- Gram matrix: replaces `(L_i k L_j'^*).linop(X_i, X_j)` + todense()
+ *      (crosscov/linfunctls/_evaluation.py:163-173, randvars/_covariance.py:197-224),
+ *      the noise add (_conditional.py:392-394) and the BlockMatrix2x2 assembly
+ *      (_conditional.py:275-281).
+ *      The matrix is a sequence of observation blocks (one per conditioning step), in
+ *      conditioning order.  Storage: lower triangle, column-major; every block is padded
+ *      to a multiple of 128 rows with an identity tail (internal; all sizes and vectors in
+ *      this API are LOGICAL, i.e. without padding).                                      */
+int  lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out);
+int  lpgp_mat_destroy(lpgp_mat* mat);
+/* declare the next observation block of n rows; returns its index (>= 0) or < 0       */
+int  lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n);
+int64_t lpgp_mat_size(const lpgp_mat* mat);           /* logical size = sum of block sizes */
+int64_t lpgp_mat_padded_size(const lpgp_mat* mat);    /* internal padded size              */
+/* block (bi, bj), bi >= bj  <-  sum_g (kd[g])(X0, X1) with X0 the points of block bi
+ * (operator on argument 0) and X1 those of block bj (operator on argument 1).  For
+ * bi == bj pass X1 == NULL: only the lower triangle is evaluated and stored.           */
+int  lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
+                        const lpgp_pts* X0, const lpgp_pts* X1,
+                        lpgp_mat* mat, int32_t bi, int32_t bj);
+/* diagonal of block bi += v_host[i] (v_host may be NULL) + scalar                       */
+int  lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar);
+/* diagonal block bi += B_host (n_bi x n_bi, C-order, symmetric)                          */
+int  lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B_host);
+/* dense copy-out (n x n, C-order, n = lpgp_mat_size).  what = 0: symmetric Gram as
+ * assembled (only valid while nothing is factored), 1: lower Cholesky factor.           */
+int  lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host);
+
+/* ---- factor + solve: replaces `gram.solve`, `LinearOperator.cholesky`
+ *      (_conditional.py:44,108) and the Schur-complement append
+ *      `BlockMatrix2x2.schur_update/_cholesky` (linops/_block.py:192-242).
+ *      Factors every block that is not factored yet; blocks factored by an earlier call
+ *      are kept (block append).  info: 0 ok, k > 0 => leading minor of (padded) order k
+ *      is not positive definite.                                                         */
+int  lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info);
+/* x = G^{-1} b for nrhs right-hand sides, b_host (n x nrhs, column-major, in/out)      */
+int  lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs);
+/* representer weights w = G^{-1} r; keeps w resident for lpgp_predict; w_host may be
+ * NULL (_conditional.py:96-110)                                                         */
+int  lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host);
+
+/* ---- prediction: replaces `PriorPredictiveCrossCovariance._evaluate`
+ *      (_conditional.py:140-153), `Mean._evaluate` (:193-197) and
+ *      `CovarianceFunction._evaluate` (:223-231).                                       */
+int  lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out);
+int  lpgp_rhs_destroy(lpgp_rhs* rhs);
+/* rows of block bi of K_Xx <- sum_g (kd[g])(X_obs, X_test)   (n_bi x m)                 */
+int  lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
+                         const lpgp_pts* X_obs, const lpgp_pts* X_test,
+                         lpgp_rhs* rhs, const lpgp_mat* mat, int32_t bi);
+/* mean_host[j] = prior_mean_host[j] + K_Xx[:, j] . w     (prior_mean_host may be NULL)
+ * var_host[j]  = kxx_host[j] - || L^{-1} K_Xx[:, j] ||^2  (skipped if var_host == NULL)
+ * K_Xx is overwritten by V = L^{-1} K_Xx when the variance is requested.               */
+int  lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K,
+                  const double* prior_mean_host, const double* kxx_host,
+                  double* mean_host, double* var_host);
+/* V <- L^{-1} V  (forward substitution on all m columns)                                */
+int  lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V);
+/* out_host (ma x mb, C-order) = A^T B   (covariance update V0^T V1)                     */
+int  lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host);
+/* logical rows, n x m C-order                                                           */
+int  lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* out_host);
+/* diag of sum_g (kd[g])(x, x): a constant for the stationary kernels supported here     */
+int  lpgp_kernel_diag(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, double* out_value);
+
+/* dense block (n0 x n1, C-order) of sum_g (kd[g])(X0, X1): replaces
+ * `CovarianceFunction.__call__/matrix` (probnum protocol; call sites
+ * crosscov/linfunctls/_evaluation.py:79,160,170)                                        */
+int  lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
+                        const lpgp_pts* X0, const lpgp_pts* X1, double* out_host);
+
+/* ---- measurement: HIP-event timing of the hot kernels on their own streams ---------- */
+enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1, LPGP_K_GEMM = 2,
+                      LPGP_K_POTRF_TILE = 3, LPGP_K_TRSM = 4, LPGP_K_COUNT = 5 };
+int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t on);
+int  lpgp_profile_reset(lpgp_ctx* ctx);
+/* accumulated over all launches since reset: device milliseconds (HIP events on the
+ * launching stream), launch count, algorithmic flops, algorithmic bytes                */
+int  lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* launches,
+                      double* flops, double* bytes);
+
+/* ---- raw kernels for unit tests / microbenchmarks (device work on host buffers) ----- */
+/* C(m x n, col-major ldc) = beta*C + alpha * op(A) op(B); ta/tb: 0 => operand stored with
+ * its non-contracted index fastest, 1 => contracted index (k) fastest.                  */
+int  lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only,
+                    int64_t m, int64_t n, int64_t k, double alpha,
+                    const double* A, int64_t lda, const double* B, int64_t ldb,
+                    double beta, double* C, int64_t ldc, int32_t reps, double* ms_per_rep);
+/* in-place 128x128 tile Cholesky + inverse: T (col-major 128x128) -> L, Linv            */
+int  lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info);
+/* peak probes: fp64 MFMA issue loop and streaming write; returns TFLOP/s resp. GB/s     */
+int  lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops);
+int  lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPGP_H */

@@ -1,0 +1,763 @@
+// C-ABI entry points of liblpgp.so (declared in include/lpgp.h).
+
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+#include "lpgp_internal.h"
+
+namespace lpgp {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------
+// profiling with HIP events on the launching stream
+// ---------------------------------------------------------------------------------------
+static hipEvent_t get_event(lpgp_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(lpgp_ctx* ctx, hipStream_t stream, int kernel, double flops, double bytes) {
+  if (!ctx->prof_on) return;
+  PendingEvent p;
+  p.e0 = get_event(ctx);
+  p.e1 = get_event(ctx);
+  p.kernel = kernel;
+  (void)hipEventRecord(p.e0, stream);
+  ctx->pending.push_back(p);
+  ctx->prof[kernel].launches += 1;
+  ctx->prof[kernel].flops += flops;
+  ctx->prof[kernel].bytes += bytes;
+}
+
+void prof_end(lpgp_ctx* ctx, hipStream_t stream) {
+  if (!ctx->prof_on) return;
+  (void)hipEventRecord(ctx->pending.back().e1, stream);
+}
+
+int prof_collect(lpgp_ctx* ctx) {
+  if (ctx->pending.empty()) return 0;
+  LPGP_HIP(hipDeviceSynchronize());
+  for (auto& p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) ctx->prof[p.kernel].ms += ms;
+    ctx->event_pool.push_back(p.e0);
+    ctx->event_pool.push_back(p.e1);
+  }
+  ctx->pending.clear();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------
+__global__ void set_identity_kernel(double* a, int64_t ld, int64_t from, int64_t to) {
+  int64_t i = from + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < to) a[i * (ld + 1)] = 1.0;
+}
+
+// out[j] = sum_i K[i + j*ld] * (w ? w[i] : K[i + j*ld])   over i < rows; one block per column
+__global__ __launch_bounds__(256) void col_reduce_kernel(const double* __restrict__ K, int64_t ld, int64_t rows,
+                                                          const double* __restrict__ w, double* __restrict__ out) {
+  __shared__ double red[4];
+  const double* col = K + (int64_t)blockIdx.x * ld;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x * 2; i < rows; i += 512) {
+    double2 v = *reinterpret_cast<const double2*>(col + i);
+    if (w) {
+      double2 ww = *reinterpret_cast<const double2*>(w + i);
+      acc = fma(v.x, ww.x, acc);
+      acc = fma(v.y, ww.y, acc);
+    } else {
+      acc = fma(v.x, v.x, acc);
+      acc = fma(v.y, v.y, acc);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters) {
+  v4f64 acc[8];
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * (int64_t)blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void write_probe_kernel(double* out, int64_t n2) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride)
+    reinterpret_cast<double2*>(out)[i] = make_double2((double)i, 1.0);
+}
+
+static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
+  if (n <= ctx->tmp_cap) return 0;
+  if (ctx->d_tmp) LPGP_HIP(hipFree(ctx->d_tmp));
+  ctx->d_tmp = nullptr;
+  ctx->tmp_cap = 0;
+  LPGP_HIP(hipMalloc(&ctx->d_tmp, (size_t)n * sizeof(double)));
+  ctx->tmp_cap = n;
+  return 0;
+}
+
+static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
+  // (re)allocate to `cap` (multiple of TILE) keeping the content of the first mat->pn rows/cols
+  double *na = nullptr, *nl = nullptr, *nw = nullptr;
+  LPGP_HIP(hipMalloc(&na, (size_t)cap * cap * sizeof(double)));
+  LPGP_HIP(hipMalloc(&nl, (size_t)cap * TILE * sizeof(double)));
+  LPGP_HIP(hipMalloc(&nw, (size_t)cap * sizeof(double)));
+  LPGP_HIP(hipMemsetAsync(na, 0, (size_t)cap * cap * sizeof(double), ctx->s_main));
+  LPGP_HIP(hipMemsetAsync(nl, 0, (size_t)cap * TILE * sizeof(double), ctx->s_main));
+  LPGP_HIP(hipMemsetAsync(nw, 0, (size_t)cap * sizeof(double), ctx->s_main));
+  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->s_main, na, cap,
+                     (int64_t)0, cap);
+  if (mat->a && mat->pn > 0) {
+    LPGP_HIP(hipMemcpy2DAsync(na, (size_t)cap * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
+                              (size_t)mat->pn * sizeof(double), (size_t)mat->pn, hipMemcpyDeviceToDevice,
+                              ctx->s_main));
+    LPGP_HIP(hipMemcpyAsync(nl, mat->linv, (size_t)mat->pn * TILE * sizeof(double), hipMemcpyDeviceToDevice,
+                            ctx->s_main));
+    LPGP_HIP(hipMemcpyAsync(nw, mat->w, (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+  }
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  if (mat->a) (void)hipFree(mat->a);
+  if (mat->linv) (void)hipFree(mat->linv);
+  if (mat->w) (void)hipFree(mat->w);
+  mat->a = na;
+  mat->linv = nl;
+  mat->w = nw;
+  mat->cap = cap;
+  return 0;
+}
+
+// logical (length mat->n) <-> padded (length mat->pn) host vectors
+static void scatter_padded(const lpgp_mat* mat, const double* logical, double* padded) {
+  std::memset(padded, 0, (size_t)mat->pn * sizeof(double));
+  for (const auto& b : mat->blocks) std::memcpy(padded + b.poff, logical + b.off, (size_t)b.n * sizeof(double));
+}
+static void gather_padded(const lpgp_mat* mat, const double* padded, double* logical) {
+  for (const auto& b : mat->blocks) std::memcpy(logical + b.off, padded + b.poff, (size_t)b.n * sizeof(double));
+}
+
+}  // namespace lpgp
+
+using namespace lpgp;
+
+extern "C" {
+
+const char* lpgp_last_error(void) { return lpgp::g_err; }
+
+int lpgp_init(int device, lpgp_ctx** out) {
+  LPGP_CHECK(out != nullptr, "lpgp_init: null out");
+  int ndev = 0;
+  LPGP_HIP(hipGetDeviceCount(&ndev));
+  LPGP_CHECK(ndev > 0, "lpgp_init: no HIP device visible (this library has no CPU fallback)");
+  LPGP_CHECK(device >= 0 && device < ndev, "lpgp_init: device %d out of range (%d visible)", device, ndev);
+  LPGP_HIP(hipSetDevice(device));
+  lpgp_ctx* ctx = new lpgp_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  LPGP_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->cus = prop.multiProcessorCount;
+  int lo = 0, hi = 0;
+  LPGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, hi));
+  LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd, hipStreamNonBlocking, lo));
+  for (int i = 0; i < 2; ++i) {
+    LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
+    LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
+  }
+  LPGP_HIP(hipMalloc(&ctx->d_desc, sizeof(DevDesc)));
+  LPGP_HIP(hipMalloc(&ctx->d_info, sizeof(int)));
+  if (const char* e = std::getenv("LPGP_NB")) {
+    long v = std::atol(e);
+    if (v >= TILE && v % TILE == 0) ctx->nb = v;
+  }
+  if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
+  *out = ctx;
+  return 0;
+}
+
+int lpgp_finalize(lpgp_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& p : ctx->pending) {
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipEventDestroy(ctx->ev_panel[i]);
+    (void)hipEventDestroy(ctx->ev_upd[i]);
+  }
+  (void)hipFree(ctx->d_desc);
+  (void)hipFree(ctx->d_info);
+  if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  (void)hipStreamDestroy(ctx->s_main);
+  (void)hipStreamDestroy(ctx->s_upd);
+  delete ctx;
+  return 0;
+}
+
+int lpgp_device_info(lpgp_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_bytes) {
+  hipDeviceProp_t prop;
+  LPGP_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && len > 0) {
+    std::snprintf(name, (size_t)len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cus) *cus = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return 0;
+}
+
+int lpgp_sync(lpgp_ctx* ctx) {
+  LPGP_HIP(hipSetDevice(ctx->device));
+  LPGP_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
+  if (std::strcmp(key, "nb") == 0) {
+    LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
+    ctx->nb = value;
+  } else if (std::strcmp(key, "lookahead") == 0) {
+    ctx->lookahead = value != 0;
+  } else {
+    LPGP_CHECK(false, "unknown option %s", key);
+  }
+  return 0;
+}
+
+// ---- points ----------------------------------------------------------------------------
+int lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out) {
+  LPGP_CHECK(ctx && X_host && out, "lpgp_pts_create: null argument");
+  LPGP_CHECK(n >= 0 && d >= 1 && d <= LPGP_MAXD, "lpgp_pts_create: n=%lld d=%d", (long long)n, d);
+  lpgp_pts* p = new lpgp_pts();
+  p->ctx = ctx;
+  p->n = n;
+  p->d = d;
+  p->n_pad = round_up(n > 0 ? n : 1, 64);
+  std::vector<double> soa((size_t)p->n_pad * d, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int j = 0; j < d; ++j) soa[(size_t)j * p->n_pad + i] = X_host[i * d + j];
+  LPGP_HIP(hipMalloc(&p->x, soa.size() * sizeof(double)));
+  LPGP_HIP(hipMemcpy(p->x, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+
+int lpgp_pts_destroy(lpgp_pts* p) {
+  if (!p) return 0;
+  (void)hipFree(p->x);
+  delete p;
+  return 0;
+}
+
+// ---- matrix ----------------------------------------------------------------------------
+int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
+  LPGP_CHECK(ctx && out, "lpgp_mat_create: null argument");
+  lpgp_mat* m = new lpgp_mat();
+  m->ctx = ctx;
+  m->cap = 0;
+  m->a = m->linv = m->w = nullptr;
+  m->n = m->pn = m->pn_fact = 0;
+  m->has_w = 0;
+  int64_t cap = round_up(capacity_hint > 0 ? capacity_hint : TILE, TILE);
+  int rc = mat_alloc(ctx, m, cap);
+  if (rc != 0) {
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+int lpgp_mat_destroy(lpgp_mat* m) {
+  if (!m) return 0;
+  (void)hipFree(m->a);
+  (void)hipFree(m->linv);
+  (void)hipFree(m->w);
+  delete m;
+  return 0;
+}
+
+int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
+  LPGP_CHECK(ctx && mat && n > 0, "lpgp_mat_add_block: bad argument");
+  lpgp_block b;
+  b.n = n;
+  b.off = mat->n;
+  b.poff = mat->pn;
+  b.pn = round_up(n, TILE);
+  if (b.poff + b.pn > mat->cap) {
+    int rc = mat_alloc(ctx, mat, b.poff + b.pn);
+    if (rc != 0) return rc;
+  }
+  mat->blocks.push_back(b);
+  mat->n += n;
+  mat->pn += b.pn;
+  mat->has_w = 0;
+  return (int)mat->blocks.size() - 1;
+}
+
+int64_t lpgp_mat_size(const lpgp_mat* mat) { return mat ? mat->n : -1; }
+int64_t lpgp_mat_padded_size(const lpgp_mat* mat) { return mat ? mat->pn : -1; }
+
+int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
+                       const lpgp_pts* X1, lpgp_mat* mat, int32_t bi, int32_t bj) {
+  LPGP_CHECK(ctx && kd && X0 && mat, "lpgp_gram_assemble: null argument");
+  LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size() && bj >= 0 && bj <= bi, "lpgp_gram_assemble: bad block (%d,%d)", bi, bj);
+  const lpgp_block& Bi = mat->blocks[bi];
+  const lpgp_block& Bj = mat->blocks[bj];
+  LPGP_CHECK(Bi.poff >= mat->pn_fact, "lpgp_gram_assemble: block %d is already factored", bi);
+  LPGP_CHECK(X0->n == Bi.n, "lpgp_gram_assemble: X0 has %lld points, block %d has %lld rows", (long long)X0->n, bi, (long long)Bi.n);
+  const bool sym = (X1 == nullptr);
+  LPGP_CHECK(sym == (bi == bj), "lpgp_gram_assemble: X1 must be NULL exactly for diagonal blocks");
+  const lpgp_pts* Xc = sym ? X0 : X1;
+  LPGP_CHECK(Xc->n == Bj.n && Xc->d == X0->d && kd[0].d == X0->d, "lpgp_gram_assemble: shape mismatch");
+  DevDesc desc;
+  int rc = lower_kdesc(kd, ngroups, &desc);
+  if (rc != 0) return rc;
+  rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->cap,
+                       Bi.poff, Bj.poff, sym ? 1 : 0);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));   // desc is a stack object
+  return 0;
+}
+
+int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar) {
+  LPGP_CHECK(ctx && mat && bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_mat_add_diag: bad argument");
+  const lpgp_block& B = mat->blocks[bi];
+  LPGP_CHECK(B.poff >= mat->pn_fact, "lpgp_mat_add_diag: block %d is already factored", bi);
+  double* dv = nullptr;
+  if (v_host) {
+    int rc = ensure_tmp(ctx, B.n);
+    if (rc != 0) return rc;
+    LPGP_HIP(hipMemcpyAsync(ctx->d_tmp, v_host, (size_t)B.n * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+    dv = ctx->d_tmp;
+  }
+  int rc = launch_add_diag(ctx->s_main, mat->a, mat->cap, B.poff, B.n, dv, scalar);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  return 0;
+}
+
+int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B_host) {
+  LPGP_CHECK(ctx && mat && B_host && bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_mat_add_dense: bad argument");
+  const lpgp_block& B = mat->blocks[bi];
+  LPGP_CHECK(B.poff >= mat->pn_fact, "lpgp_mat_add_dense: block %d is already factored", bi);
+  int rc = ensure_tmp(ctx, B.n * B.n);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipMemcpyAsync(ctx->d_tmp, B_host, (size_t)(B.n * B.n) * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+  rc = launch_add_dense(ctx->s_main, mat->a, mat->cap, B.poff, B.n, ctx->d_tmp);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  return 0;
+}
+
+int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host) {
+  LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_to_host: null argument");
+  LPGP_CHECK(what == 0 || what == 1, "lpgp_mat_to_host: what must be 0 or 1");
+  if (what == 0) LPGP_CHECK(mat->pn_fact == 0, "lpgp_mat_to_host: Gram no longer available after potrf");
+  if (what == 1) LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_to_host: matrix is not (fully) factored");
+  const int64_t pn = mat->pn, n = mat->n;
+  std::vector<double> tmp((size_t)pn * pn);
+  LPGP_HIP(hipMemcpy2D(tmp.data(), (size_t)pn * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
+                       (size_t)pn * sizeof(double), (size_t)pn, hipMemcpyDeviceToHost));
+  // tmp is column-major pn x pn: element (r,c) at tmp[r + c*pn]
+  for (const auto& bi : mat->blocks)
+    for (const auto& bj : mat->blocks)
+      for (int64_t i = 0; i < bi.n; ++i)
+        for (int64_t j = 0; j < bj.n; ++j) {
+          const int64_t r = bi.poff + i, c = bj.poff + j;
+          double v;
+          if (r >= c) v = tmp[(size_t)(r + c * pn)];
+          else v = (what == 0) ? tmp[(size_t)(c + r * pn)] : 0.0;
+          out_host[(bi.off + i) * n + (bj.off + j)] = v;
+        }
+  return 0;
+}
+
+// ---- factor + solve -----------------------------------------------------------------------
+int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
+  LPGP_CHECK(ctx && mat, "lpgp_potrf: null argument");
+  if (info) *info = 0;
+  if (mat->pn_fact == mat->pn) return 0;
+  int32_t h = 0;
+  int rc = potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
+  if (rc != 0) return rc;
+  if (info) *info = h;
+  if (h == 0) mat->pn_fact = mat->pn;
+  mat->has_w = 0;
+  return 0;
+}
+
+int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
+  LPGP_CHECK(ctx && mat && b_host && nrhs >= 1, "lpgp_potrs: bad argument");
+  LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_potrs: matrix is not factored");
+  const int64_t pn = mat->pn, n = mat->n, m_pad = round_up(nrhs, TILE);
+  double* dv = nullptr;
+  LPGP_HIP(hipMalloc(&dv, (size_t)pn * m_pad * sizeof(double)));
+  std::vector<double> hp((size_t)pn * m_pad, 0.0);
+  for (int64_t j = 0; j < nrhs; ++j) scatter_padded(mat, b_host + j * n, hp.data() + j * pn);
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(dv, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
+    rc = trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    if (rc) break;
+    rc = trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    if (rc) break;
+    if (hipMemcpyAsync(hp.data(), dv, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
+    if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
+  } while (0);
+  (void)hipFree(dv);
+  if (rc != 0) {
+    if (rc == -1) set_error("lpgp_potrs: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
+  for (int64_t j = 0; j < nrhs; ++j) gather_padded(mat, hp.data() + j * pn, b_host + j * n);
+  return 0;
+}
+
+int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host) {
+  LPGP_CHECK(ctx && mat && r_host, "lpgp_solve_weights: null argument");
+  LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_solve_weights: matrix is not factored");
+  const int64_t pn = mat->pn;
+  double* dv = nullptr;
+  LPGP_HIP(hipMalloc(&dv, (size_t)pn * TILE * sizeof(double)));
+  std::vector<double> hp((size_t)pn);
+  scatter_padded(mat, r_host, hp.data());
+  int rc = 0;
+  do {
+    if (hipMemsetAsync(dv, 0, (size_t)pn * TILE * sizeof(double), ctx->s_main) != hipSuccess) { rc = -1; break; }
+    if (hipMemcpyAsync(dv, hp.data(), (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
+    rc = trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, TILE);
+    if (rc) break;
+    rc = trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, TILE);
+    if (rc) break;
+    if (hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
+    if (hipMemcpyAsync(hp.data(), dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
+    if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
+  } while (0);
+  (void)hipFree(dv);
+  if (rc != 0) {
+    if (rc == -1) set_error("lpgp_solve_weights: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
+  mat->has_w = 1;
+  if (w_host) gather_padded(mat, hp.data(), w_host);
+  return 0;
+}
+
+// ---- prediction -----------------------------------------------------------------------------
+int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out) {
+  LPGP_CHECK(ctx && mat && out && m >= 1, "lpgp_rhs_create: bad argument");
+  lpgp_rhs* r = new lpgp_rhs();
+  r->ctx = ctx;
+  r->ld = mat->pn;
+  r->m = m;
+  r->m_pad = round_up(m, TILE);
+  r->v = nullptr;
+  if (hipMalloc(&r->v, (size_t)r->ld * r->m_pad * sizeof(double)) != hipSuccess) {
+    delete r;
+    set_error("lpgp_rhs_create: hipMalloc of %lld x %lld failed", (long long)mat->pn, (long long)r->m_pad);
+    return -1;
+  }
+  LPGP_HIP(hipMemsetAsync(r->v, 0, (size_t)r->ld * r->m_pad * sizeof(double), ctx->s_main));
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  *out = r;
+  return 0;
+}
+
+int lpgp_rhs_destroy(lpgp_rhs* r) {
+  if (!r) return 0;
+  (void)hipFree(r->v);
+  delete r;
+  return 0;
+}
+
+int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X_obs,
+                        const lpgp_pts* X_test, lpgp_rhs* rhs, const lpgp_mat* mat, int32_t bi) {
+  LPGP_CHECK(ctx && kd && X_obs && X_test && rhs && mat, "lpgp_cross_assemble: null argument");
+  LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_cross_assemble: bad block %d", bi);
+  const lpgp_block& B = mat->blocks[bi];
+  LPGP_CHECK(X_obs->n == B.n && X_test->n == rhs->m && X_obs->d == X_test->d && kd[0].d == X_obs->d,
+             "lpgp_cross_assemble: shape mismatch");
+  LPGP_CHECK(rhs->ld == mat->pn, "lpgp_cross_assemble: rhs was created for a different matrix size");
+  DevDesc desc;
+  int rc = lower_kdesc(kd, ngroups, &desc);
+  if (rc != 0) return rc;
+  rc = launch_assemble(ctx, ctx->s_main, desc, X_obs->x, X_obs->n, X_obs->n_pad, X_test->x, X_test->n,
+                       X_test->n_pad, rhs->v, rhs->ld, B.poff, 0, 0);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  return 0;
+}
+
+int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
+  LPGP_CHECK(ctx && mat && V, "lpgp_trsm_lower: null argument");
+  LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
+  int rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  return 0;
+}
+
+int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_mean_host,
+                 const double* kxx_host, double* mean_host, double* var_host) {
+  LPGP_CHECK(ctx && mat && K, "lpgp_predict: null argument");
+  LPGP_CHECK(mat->pn_fact == mat->pn && K->ld == mat->pn, "lpgp_predict: matrix not factored or size mismatch");
+  const int64_t m = K->m;
+  int rc = ensure_tmp(ctx, 2 * K->m_pad);
+  if (rc != 0) return rc;
+  std::vector<double> h((size_t)m);
+  if (mean_host) {
+    LPGP_CHECK(mat->has_w, "lpgp_predict: representer weights not computed (call lpgp_solve_weights)");
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
+                       (const double*)mat->w, ctx->d_tmp);
+    LPGP_HIP(hipGetLastError());
+    LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h[j];
+  }
+  if (var_host) {
+    LPGP_CHECK(kxx_host != nullptr, "lpgp_predict: kxx_host required for the variance");
+    rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
+                       (const double*)nullptr, ctx->d_tmp);
+    LPGP_HIP(hipGetLastError());
+    LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - h[j];
+  }
+  return 0;
+}
+
+int lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host) {
+  LPGP_CHECK(ctx && A && B && out_host, "lpgp_rhs_inner: null argument");
+  LPGP_CHECK(A->ld == B->ld, "lpgp_rhs_inner: row mismatch");
+  const int64_t ma = A->m_pad, mb = B->m_pad;
+  double* dc = nullptr;
+  LPGP_HIP(hipMalloc(&dc, (size_t)ma * mb * sizeof(double)));
+  GemmArgs g;
+  g.A = A->v; g.B = B->v; g.C = dc; g.lda = A->ld; g.ldb = B->ld; g.ldc = ma;
+  g.mt = (int)(ma / TILE); g.nt = (int)(mb / TILE); g.k = (int)A->ld; g.alpha = 1.0; g.beta = 0.0;
+  g.tri = 0; g.row_tile0 = g.col_tile0 = 0; g.ktrim = 0;
+  int rc = launch_gemm(ctx, ctx->s_main, 1, 1, g, LPGP_K_GEMM);
+  std::vector<double> h((size_t)ma * mb);
+  if (rc == 0 && hipMemcpyAsync(h.data(), dc, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) rc = -1;
+  if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
+  (void)hipFree(dc);
+  if (rc != 0) return rc;
+  for (int64_t i = 0; i < A->m; ++i)
+    for (int64_t j = 0; j < B->m; ++j) out_host[i * B->m + j] = h[(size_t)(i + j * ma)];
+  return 0;
+}
+
+int lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* out_host) {
+  LPGP_CHECK(ctx && mat && rhs && out_host, "lpgp_rhs_to_host: null argument");
+  LPGP_CHECK(rhs->ld == mat->pn, "lpgp_rhs_to_host: size mismatch");
+  std::vector<double> h((size_t)rhs->ld * rhs->m);
+  LPGP_HIP(hipMemcpy(h.data(), rhs->v, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (const auto& b : mat->blocks)
+    for (int64_t i = 0; i < b.n; ++i)
+      for (int64_t j = 0; j < rhs->m; ++j) out_host[(b.off + i) * rhs->m + j] = h[(size_t)(b.poff + i + j * rhs->ld)];
+  return 0;
+}
+
+int lpgp_kernel_diag(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, double* out_value) {
+  LPGP_CHECK(kd && out_value, "lpgp_kernel_diag: null argument");
+  (void)ctx;
+  DevDesc desc;
+  int rc = lower_kdesc(kd, ngroups, &desc);
+  if (rc != 0) return rc;
+  // at x == x' every r_d = 0: only the constant coefficient of the all-even parity class survives
+  double v = 0.0;
+  for (int g = 0; g < desc.ngroups; ++g)
+    for (int c = 0; c < desc.g[g].ncls; ++c)
+      if (desc.g[g].parity[c] == 0) v += desc.g[g].scale * desc.coef[desc.g[g].coef_off[c]];
+  *out_value = v;
+  return 0;
+}
+
+int lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
+                       const lpgp_pts* X1, double* out_host) {
+  LPGP_CHECK(ctx && kd && X0 && X1 && out_host, "lpgp_kernel_matrix: null argument");
+  LPGP_CHECK(X0->d == X1->d && kd[0].d == X0->d, "lpgp_kernel_matrix: dimension mismatch");
+  if (X0->n == 0 || X1->n == 0) return 0;
+  DevDesc desc;
+  int rc = lower_kdesc(kd, ngroups, &desc);
+  if (rc != 0) return rc;
+  const int64_t ld = round_up(X0->n, 2);
+  double* d = nullptr;
+  LPGP_HIP(hipMalloc(&d, (size_t)ld * X1->n * sizeof(double)));
+  rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, X1->x, X1->n, X1->n_pad, d, ld, 0, 0, 0);
+  std::vector<double> h((size_t)ld * X1->n);
+  if (rc == 0 && hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) rc = -1;
+  if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
+  (void)hipFree(d);
+  if (rc != 0) return rc;
+  for (int64_t i = 0; i < X0->n; ++i)
+    for (int64_t j = 0; j < X1->n; ++j) out_host[i * X1->n + j] = h[(size_t)(i + j * ld)];
+  return 0;
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+int lpgp_profile_enable(lpgp_ctx* ctx, int32_t on) {
+  int rc = prof_collect(ctx);
+  ctx->prof_on = on != 0;
+  return rc;
+}
+
+int lpgp_profile_reset(lpgp_ctx* ctx) {
+  int rc = prof_collect(ctx);
+  for (auto& s : ctx->prof) s = ProfSlot();
+  return rc;
+}
+
+int lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* launches, double* flops, double* bytes) {
+  LPGP_CHECK(kernel_id >= 0 && kernel_id < LPGP_K_COUNT, "lpgp_profile_get: bad kernel id");
+  int rc = prof_collect(ctx);
+  if (rc != 0) return rc;
+  const ProfSlot& s = ctx->prof[kernel_id];
+  if (ms) *ms = s.ms;
+  if (launches) *launches = s.launches;
+  if (flops) *flops = s.flops;
+  if (bytes) *bytes = s.bytes;
+  return 0;
+}
+
+// ---- raw kernels for unit tests / microbenchmarks ---------------------------------------------
+int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, int64_t m, int64_t n, int64_t k,
+                   double alpha, const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+                   double* C, int64_t ldc, int32_t reps, double* ms_per_rep) {
+  LPGP_CHECK(m % TILE == 0 && n % TILE == 0 && k % 16 == 0, "lpgp_test_gemm: m,n multiples of 128 and k of 16 required");
+  const int64_t a_elems = ta ? lda * m : lda * k;
+  const int64_t b_elems = tb ? ldb * n : ldb * k;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  LPGP_HIP(hipMalloc(&dA, (size_t)a_elems * sizeof(double)));
+  LPGP_HIP(hipMalloc(&dB, (size_t)b_elems * sizeof(double)));
+  LPGP_HIP(hipMalloc(&dC, (size_t)ldc * n * sizeof(double)));
+  LPGP_HIP(hipMemcpy(dA, A, (size_t)a_elems * sizeof(double), hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dB, B, (size_t)b_elems * sizeof(double), hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dC, C, (size_t)ldc * n * sizeof(double), hipMemcpyHostToDevice));
+  GemmArgs g;
+  g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.mt = (int)(m / TILE); g.nt = (int)(n / TILE); g.k = (int)k; g.alpha = alpha; g.beta = beta;
+  g.tri = lower_only; g.row_tile0 = g.col_tile0 = 0; g.ktrim = 0;
+  int rc = launch_gemm(ctx, ctx->s_main, ta, tb, g, -1);
+  if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
+  if (rc == 0) LPGP_HIP(hipMemcpy(C, dC, (size_t)ldc * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (rc == 0 && reps > 0 && ms_per_rep) {
+    hipEvent_t e0, e1;
+    LPGP_HIP(hipEventCreate(&e0));
+    LPGP_HIP(hipEventCreate(&e1));
+    LPGP_HIP(hipEventRecord(e0, ctx->s_main));
+    for (int r = 0; r < reps && rc == 0; ++r) rc = launch_gemm(ctx, ctx->s_main, ta, tb, g, -1);
+    LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+    LPGP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_rep = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  return rc;
+}
+
+int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) {
+  double *dT = nullptr, *dL = nullptr;
+  LPGP_HIP(hipMalloc(&dT, (size_t)TILE * TILE * sizeof(double)));
+  LPGP_HIP(hipMalloc(&dL, (size_t)TILE * TILE * sizeof(double)));
+  LPGP_HIP(hipMemcpy(dT, T, (size_t)TILE * TILE * sizeof(double), hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->s_main));
+  int rc = launch_potrf_tile(ctx, ctx->s_main, dT, TILE, dL, ctx->d_info, 0);
+  int h = 0;
+  if (rc == 0) {
+    LPGP_HIP(hipMemcpyAsync(&h, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
+    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    LPGP_HIP(hipMemcpy(T, dT, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToHost));
+    LPGP_HIP(hipMemcpy(Linv, dL, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (info) *info = h;
+  (void)hipFree(dT);
+  (void)hipFree(dL);
+  return rc;
+}
+
+int lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops) {
+  const int blocks = ctx->cus * 4, iters = 4000;
+  double* d = nullptr;
+  LPGP_HIP(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  LPGP_HIP(hipEventCreate(&e0));
+  LPGP_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->s_main, d, 100);   // warm-up
+  LPGP_HIP(hipEventRecord(e0, ctx->s_main));
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->s_main, d, iters);
+  LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+  LPGP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4.0 * iters * 8.0 * (2.0 * 16 * 16 * 4);
+  if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  return 0;
+}
+
+int lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps) {
+  double* d = nullptr;
+  bytes = round_up(bytes, 16);
+  LPGP_HIP(hipMalloc(&d, (size_t)bytes));
+  hipEvent_t e0, e1;
+  LPGP_HIP(hipEventCreate(&e0));
+  LPGP_HIP(hipEventCreate(&e1));
+  const int grid = ctx->cus * 8;
+  hipLaunchKernelGGL(write_probe_kernel, dim3(grid), dim3(256), 0, ctx->s_main, d, bytes / 16);
+  LPGP_HIP(hipEventRecord(e0, ctx->s_main));
+  for (int r = 0; r < 5; ++r)
+    hipLaunchKernelGGL(write_probe_kernel, dim3(grid), dim3(256), 0, ctx->s_main, d, bytes / 16);
+  LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+  LPGP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (gbps) *gbps = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// Pairwise evaluation of differentiated covariance blocks (L0 k L1'^*)(X0, X1).
+//
+// Replaces the NumPy evaluation chain of the reference
+//   covfuncs/linfuncops/diffops/_tensor_product.py:84-119  (_compute_res / _evaluate)
+//   covfuncs/linfuncops/diffops/_matern.py:64-86,300-318,403-410,476-483,558-571
+//   covfuncs/linfuncops/diffops/_expquad.py:45-57,106-122,187-201,280-312,390-410
+//   functions/_polynomial.py:61-68 (Horner)
+// (~40-60 full-matrix temporaries per block) by ONE fused kernel: point coordinates of
+// the column tile staged in LDS, one exp per entry, one coalesced fp64 store per entry.
+//
+// Host part: lower_kdesc() turns the term list  sum_t c_t prod_d d^{n0} d'^{n1} k_d  into a
+// per-parity-class dense polynomial in r_d = |a_d (x_d - x'_d)| (exact integer tables for
+// the Matern derivative polynomials, _matern.py:613-639, and Hermite polynomials).
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "lpgp_internal.h"
+
+namespace lpgp {
+
+// ---------------------------------------------------------------------------------------
+// host: polynomial tables
+// ---------------------------------------------------------------------------------------
+static long double ifact(int n) {
+  long double r = 1;
+  for (int i = 2; i <= n; ++i) r *= i;
+  return r;
+}
+
+// Integer numerators of P_n for Matern nu = p + 1/2 over the common denominator
+// D_p = (2p)!/p!  (c_k D_p = (2p-k)!/((p-k)! k!) 2^k are integers; P_n = P'_{n-1} - P_{n-1}).
+static void matern_poly(int p, int n, long double* out /* p+1 */) {
+  long double cur[16], nxt[16];
+  for (int k = 0; k <= p; ++k)
+    cur[k] = ifact(2 * p - k) / (ifact(p - k) * ifact(k)) * std::pow(2.0L, k);
+  for (int it = 0; it < n; ++it) {
+    for (int k = 0; k <= p; ++k) {
+      long double d = (k + 1 <= p) ? (k + 1) * cur[k + 1] : 0.0L;
+      nxt[k] = d - cur[k];
+    }
+    for (int k = 0; k <= p; ++k) cur[k] = nxt[k];
+  }
+  long double D = ifact(2 * p) / ifact(p);
+  // round to double exactly like float(Fraction(num, D)) and continue in long double
+  for (int k = 0; k <= p; ++k) out[k] = (long double)(double)(cur[k] / D);
+}
+
+// Probabilists' Hermite He_n, ascending coefficients, degree n.
+static void hermite_poly(int n, long double* out /* n+1 */) {
+  long double a[16] = {1}, b[16];
+  int deg = 0;
+  for (int it = 0; it < n; ++it) {
+    for (int k = 0; k <= deg + 1; ++k) b[k] = 0;
+    for (int k = 0; k <= deg; ++k) b[k + 1] += a[k];            // u * He
+    for (int k = 1; k <= deg; ++k) b[k - 1] -= k * a[k];        // - He'
+    ++deg;
+    for (int k = 0; k <= deg; ++k) a[k] = b[k];
+  }
+  for (int k = 0; k <= n; ++k) out[k] = a[k];
+}
+
+int lower_kdesc(const lpgp_kdesc* kd, int ngroups, DevDesc* out) {
+  LPGP_CHECK(kd != nullptr && ngroups >= 1 && ngroups <= LPGP_MAXG, "lower_kdesc: bad ngroups %d", ngroups);
+  std::memset(out, 0, sizeof(*out));
+  const int d = kd[0].d;
+  LPGP_CHECK(d >= 1 && d <= LPGP_MAXD, "lower_kdesc: d=%d out of range", d);
+  out->d = d;
+  out->ngroups = ngroups;
+  int coef_used = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const lpgp_kdesc& K = kd[g];
+    LPGP_CHECK(K.d == d, "lower_kdesc: group %d has d=%d != %d", g, K.d, d);
+    LPGP_CHECK(K.nterms >= 1 && K.nterms <= LPGP_MAXT, "lower_kdesc: nterms=%d", K.nterms);
+    DevGroup& G = out->g[g];
+    G.scale = K.scale;
+    long double a[LPGP_MAXD];
+    for (int j = 0; j < d; ++j) {
+      LPGP_CHECK(K.lengthscale[j] > 0, "lower_kdesc: lengthscale must be positive");
+      if (K.family[j] == LPGP_MATERN_HALFINT) {
+        LPGP_CHECK(K.p[j] >= 0 && K.p[j] <= 6, "lower_kdesc: Matern p=%d unsupported", K.p[j]);
+        // probnum Matern._scale_factors = sqrt(2 nu) / lengthscale, in fp64 like the reference
+        double as = std::sqrt(2.0 * (K.p[j] + 0.5)) / K.lengthscale[j];
+        a[j] = as;
+        G.expkind[j] = 1;
+      } else if (K.family[j] == LPGP_EXPQUAD) {
+        a[j] = 1.0 / K.lengthscale[j];
+        G.expkind[j] = 2;
+      } else {
+        LPGP_CHECK(false, "lower_kdesc: unknown family %d", K.family[j]);
+      }
+      G.a[j] = (double)a[j];
+    }
+    // degrees
+    for (int j = 0; j < d; ++j) {
+      int deg = 0;
+      for (int t = 0; t < K.nterms; ++t) {
+        int n = K.terms[t].n0[j] + K.terms[t].n1[j];
+        LPGP_CHECK(K.terms[t].n0[j] >= 0 && K.terms[t].n1[j] >= 0 && n <= 12,
+                   "lower_kdesc: derivative order out of range");
+        int dg = (K.family[j] == LPGP_MATERN_HALFINT) ? K.p[j] : n;
+        if (dg > deg) deg = dg;
+      }
+      G.deg[j] = deg;
+    }
+    int tsize = 1;
+    for (int j = 0; j < d; ++j) tsize *= (G.deg[j] + 1);
+    // accumulate per parity class
+    std::vector<std::vector<long double>> cls(1 << d);
+    for (int t = 0; t < K.nterms; ++t) {
+      const lpgp_term& T = K.terms[t];
+      int parity = 0;
+      long double pref = T.coef;
+      long double q[LPGP_MAXD][16];
+      int qdeg[LPGP_MAXD];
+      for (int j = 0; j < d; ++j) {
+        int n = T.n0[j] + T.n1[j];
+        if (n & 1) parity |= (1 << j);
+        pref *= std::pow(a[j], n);
+        if (K.family[j] == LPGP_MATERN_HALFINT) {
+          if (T.n1[j] & 1) pref = -pref;
+          matern_poly(K.p[j], n, q[j]);
+          qdeg[j] = K.p[j];
+        } else {
+          if (T.n0[j] & 1) pref = -pref;
+          hermite_poly(n, q[j]);
+          qdeg[j] = n;
+        }
+      }
+      auto& C = cls[parity];
+      if (C.empty()) C.assign(tsize, 0.0L);
+      // tensor product of the per-dim polynomials
+      int idx[LPGP_MAXD] = {0, 0, 0, 0};
+      for (;;) {
+        long double v = pref;
+        int lin = 0;
+        for (int j = 0; j < d; ++j) {
+          v *= q[j][idx[j]];
+          lin = lin * (G.deg[j] + 1) + idx[j];
+        }
+        C[lin] += v;
+        int j = d - 1;
+        while (j >= 0) {
+          if (++idx[j] <= qdeg[j]) break;
+          idx[j] = 0;
+          --j;
+        }
+        if (j < 0) break;
+      }
+    }
+    G.ncls = 0;
+    for (int c = 0; c < (1 << d); ++c) {
+      if (cls[c].empty()) continue;
+      bool nz = false;
+      for (long double v : cls[c]) nz |= (v != 0.0L);
+      if (!nz) continue;
+      LPGP_CHECK(coef_used + tsize <= MAXCOEF, "lower_kdesc: coefficient table overflow");
+      G.parity[G.ncls] = c;
+      G.coef_off[G.ncls] = coef_used;
+      for (int i = 0; i < tsize; ++i) out->coef[coef_used + i] = (double)cls[c][i];
+      coef_used += tsize;
+      ++G.ncls;
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// device kernel
+// ---------------------------------------------------------------------------------------
+constexpr int AT = 64;          // tile: 64 rows x 64 cols per workgroup (256 threads)
+constexpr int AE = 8;           // entries per thread per pass (1 row x 8 cols)
+
+struct AsmArgs {
+  const double* x0;             // SoA rows
+  const double* x1;             // SoA cols
+  int64_t n0, n1;               // valid rows / cols
+  int64_t n0_pad, n1_pad;       // SoA strides
+  double* out;                  // column-major
+  int64_t ld;
+  int64_t row_off, col_off;
+  int32_t lower_only;           // symmetric diagonal block: skip tiles strictly above diagonal
+  int32_t tiles_r, tiles_c;
+};
+
+template <int D>
+__device__ __forceinline__ void eval_entries(const DevDesc* __restrict__ desc,
+                                             const double (&dx)[D][AE], double (&res)[AE]) {
+#pragma unroll
+  for (int e = 0; e < AE; ++e) res[e] = 0.0;
+  for (int g = 0; g < desc->ngroups; ++g) {
+    const DevGroup& G = desc->g[g];
+    double r[D][AE];
+    unsigned sg[D][AE];
+    double expo[AE];
+#pragma unroll
+    for (int e = 0; e < AE; ++e) expo[e] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double a = G.a[j];
+      const int kind = G.expkind[j];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        double v = a * dx[j][e];
+        sg[j][e] = ((unsigned)__double2hiint(v)) & 0x80000000u;
+        r[j][e] = fabs(v);
+        expo[e] += (kind == 1) ? r[j][e] : 0.5 * r[j][e] * r[j][e];
+      }
+    }
+    double tot[AE];
+#pragma unroll
+    for (int e = 0; e < AE; ++e) tot[e] = 0.0;
+    const int n1 = (D > 1) ? G.deg[D > 1 ? 1 : 0] + 1 : 1;
+    const int n2 = (D > 2) ? G.deg[D > 2 ? 2 : 0] + 1 : 1;
+    const int n3 = (D > 3) ? G.deg[D > 3 ? 3 : 0] + 1 : 1;
+    for (int c = 0; c < G.ncls; ++c) {
+      const double* __restrict__ cf = desc->coef + G.coef_off[c];
+      const int par = G.parity[c];
+      double acc0[AE];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) acc0[e] = 0.0;
+      for (int i0 = G.deg[0]; i0 >= 0; --i0) {
+        if constexpr (D == 1) {
+          const double cv = cf[i0];
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], cv);
+        } else {
+          double acc1[AE];
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc1[e] = 0.0;
+          for (int i1 = n1 - 1; i1 >= 0; --i1) {
+            if constexpr (D == 2) {
+              const double cv = cf[i0 * n1 + i1];
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], cv);
+            } else {
+              double acc2[AE];
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc2[e] = 0.0;
+              for (int i2 = n2 - 1; i2 >= 0; --i2) {
+                if constexpr (D == 3) {
+                  const double cv = cf[(i0 * n1 + i1) * n2 + i2];
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], cv);
+                } else {
+                  double acc3[AE];
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc3[e] = 0.0;
+                  for (int i3 = n3 - 1; i3 >= 0; --i3) {
+                    const double cv = cf[((i0 * n1 + i1) * n2 + i2) * n3 + i3];
+#pragma unroll
+                    for (int e = 0; e < AE; ++e) acc3[e] = fma(acc3[e], r[D - 1][e], cv);
+                  }
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], acc3[e]);
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], acc2[e]);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
+        }
+      }
+      // sign of the parity class: prod_{d in class} sign(x_d - x'_d)
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        unsigned s = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s ^= ((par >> j) & 1) ? sg[j][e] : 0u;
+        double v = __hiloint2double((int)(((unsigned)__double2hiint(acc0[e])) ^ s), __double2loint(acc0[e]));
+        tot[e] += v;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * exp(-expo[e]), tot[e], res[e]);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
+  __shared__ double sx1[D][AT];
+  const int tr = blockIdx.x % a.tiles_r;   // row tile fastest: consecutive blocks write neighbouring rows
+  const int tc = blockIdx.x / a.tiles_r;
+  const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
+  if (a.lower_only && c0 > r0 + AT - 1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // stage column coordinates
+  if (threadIdx.x < AT) {
+    int64_t c = c0 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+  }
+  const int64_t row = r0 + lane;
+  double xr[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < 16 / AE; ++pass) {
+    const int cb = w * 16 + pass * AE;
+    double dx[D][AE], res[AE];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int e = 0; e < AE; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
+    eval_entries<D>(desc, dx, res);
+    if (row < a.n0) {
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        int64_t c = c0 + cb + e;
+        if (c < a.n1) a.out[(a.row_off + row) + (a.col_off + c) * a.ld] = res[e];
+      }
+    }
+  }
+}
+
+__global__ void add_diag_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) a[(off + i) * (ld + 1)] += (v ? v[i] : 0.0) + scalar;
+}
+
+__global__ void add_dense_lower_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* b /* n x n C-order */) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;   // row
+  int64_t j = blockIdx.y;                                       // col
+  if (i < n && j <= i) a[(off + i) + (off + j) * ld] += b[i * n + j];
+}
+
+int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
+                    int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
+                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only) {
+  LPGP_HIP(hipMemcpyAsync(ctx->d_desc, &host_desc, sizeof(DevDesc), hipMemcpyHostToDevice, stream));
+  AsmArgs a;
+  a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
+  a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
+  a.tiles_r = (int)((n0 + AT - 1) / AT);
+  a.tiles_c = (int)((n1 + AT - 1) / AT);
+  if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
+  dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
+  double entries = lower_only ? 0.5 * (double)n0 * ((double)n0 + 1.0) : (double)n0 * (double)n1;
+  prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+  switch (host_desc.d) {
+    case 1: hipLaunchKernelGGL(assemble_kernel<1>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
+    case 2: hipLaunchKernelGGL(assemble_kernel<2>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
+    case 3: hipLaunchKernelGGL(assemble_kernel<3>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
+    case 4: hipLaunchKernelGGL(assemble_kernel<4>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
+    default: LPGP_CHECK(false, "assemble: d=%d", host_desc.d);
+  }
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ld, off, n, v, scalar);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_dense_lower_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, a, ld, off, n, b);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace lpgp

@@ -1,0 +1,178 @@
+// Internal declarations shared by the HIP translation units of liblpgp.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "lpgp.h"
+
+namespace lpgp {
+
+constexpr int TILE = 128;          // base tile: potrf_tile block, GEMM block tile, padding unit
+
+void set_error(const char* fmt, ...);
+
+#define LPGP_HIP(expr)                                                              \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      ::lpgp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,                \
+                        hipGetErrorString(_e));                                     \
+      return -1;                                                                    \
+    }                                                                               \
+  } while (0)
+
+#define LPGP_CHECK(cond, ...)                                                       \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      ::lpgp::set_error(__VA_ARGS__);                                               \
+      return -2;                                                                    \
+    }                                                                               \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- lowered kernel descriptor (device form) ------------------------------------------
+// entry = sum_g scale_g * exp(-sum_d E_d(r_d)) * sum_c sgn^{parity_c} Poly_c(r_1..r_d),
+// r_d = |a_d (x_d - x'_d)|, E = r (Matern) or r^2/2 (ExpQuad); Poly_c dense nested-Horner
+// coefficient tensor.  Built on the host by lower_kdesc (assemble.hip).
+constexpr int MAXCLS = 16;         // parity classes (2^d, d <= 4)
+constexpr int MAXCOEF = 2048;      // coefficient doubles over all groups
+
+struct DevGroup {
+  double scale;
+  double a[LPGP_MAXD];
+  int32_t expkind[LPGP_MAXD];      // 1: exp(-r), 2: exp(-r^2/2)
+  int32_t deg[LPGP_MAXD];          // polynomial degree per dim
+  int32_t ncls;
+  int32_t parity[MAXCLS];          // bit d set => factor sign(x_d - x'_d)
+  int32_t coef_off[MAXCLS];        // offset into coef[]
+};
+
+struct DevDesc {
+  int32_t d;
+  int32_t ngroups;
+  DevGroup g[LPGP_MAXG];
+  double coef[MAXCOEF];
+};
+
+int lower_kdesc(const lpgp_kdesc* kd, int ngroups, DevDesc* out);
+
+// ---- profiling -------------------------------------------------------------------------
+struct ProfSlot {
+  double ms = 0.0;
+  int64_t launches = 0;
+  double flops = 0.0;
+  double bytes = 0.0;
+};
+
+struct PendingEvent {
+  hipEvent_t e0, e1;
+  int kernel;
+};
+
+}  // namespace lpgp
+
+struct lpgp_ctx {
+  int device = 0;
+  int cus = 0;
+  hipStream_t s_main = nullptr;    // panel / critical-path stream (high priority)
+  hipStream_t s_upd = nullptr;     // trailing-update stream
+  hipEvent_t ev_panel[2] = {nullptr, nullptr};
+  hipEvent_t ev_upd[2] = {nullptr, nullptr};
+  int64_t nb = 512;                // panel width of the blocked Cholesky
+  int lookahead = 1;
+  // workspace
+  lpgp::DevDesc* d_desc = nullptr; // device copy of the current descriptor
+  int* d_info = nullptr;           // potrf info word
+  double* d_tmp = nullptr;         // small scratch (vectors)
+  int64_t tmp_cap = 0;
+  // profiling
+  int prof_on = 0;
+  lpgp::ProfSlot prof[LPGP_K_COUNT];
+  std::vector<lpgp::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+struct lpgp_pts {
+  lpgp_ctx* ctx;
+  int64_t n;
+  int32_t d;
+  double* x;                       // device, SoA: x[dim * n_pad + i]
+  int64_t n_pad;
+};
+
+struct lpgp_block {
+  int64_t n;                       // logical rows
+  int64_t off;                     // logical offset
+  int64_t poff;                    // padded offset (multiple of TILE)
+  int64_t pn;                      // padded rows
+};
+
+struct lpgp_mat {
+  lpgp_ctx* ctx;
+  int64_t cap;                     // padded capacity (multiple of TILE) == leading dimension
+  double* a;                       // device cap x cap column-major (lower part meaningful)
+  double* linv;                    // device (cap/TILE) tiles of TILE x TILE: inverse of each diagonal tile of L
+  double* w;                       // device cap: representer weights (padded layout)
+  std::vector<lpgp_block> blocks;
+  int64_t n;                       // logical size
+  int64_t pn;                      // padded size in use
+  int64_t pn_fact;                 // padded columns factored so far
+  int has_w;
+};
+
+struct lpgp_rhs {
+  lpgp_ctx* ctx;
+  int64_t ld;                      // padded row capacity (multiple of TILE)
+  int64_t m;                       // columns
+  int64_t m_pad;                   // multiple of TILE
+  double* v;                       // device ld x m_pad column-major
+};
+
+namespace lpgp {
+
+// profiling helpers: bracket launches of `kernel` on `stream`
+void prof_begin(lpgp_ctx* ctx, hipStream_t stream, int kernel, double flops, double bytes);
+void prof_end(lpgp_ctx* ctx, hipStream_t stream);
+int prof_collect(lpgp_ctx* ctx);
+
+// gemm.hip --------------------------------------------------------------------------------
+// C(m x n) = beta*C + alpha*A*B.  All of m, n multiples of TILE, k multiple of 16.
+// ta: A element (i,kk) at A[i + kk*lda] (0) or A[kk + i*lda] (1);
+// tb: B element (kk,j) at B[j + kk*ldb] (0) or B[kk + j*ldb] (1).
+// tri: 0 full; 1 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
+//      with global row tile < global col tile are skipped.
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int32_t mt, nt;                  // tiles in m and n
+  int32_t k;
+  double alpha, beta;
+  int32_t tri;
+  int32_t row_tile0, col_tile0;    // global tile index of C(0,0) (for tri)
+  int32_t ktrim;                   // 1: B (or A) lower-triangular in (n,k): skip k > n-range (invL products)
+};
+int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
+
+// potrf.hip -------------------------------------------------------------------------------
+int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
+                      int* d_info, int info_base);
+int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
+int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
+int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
+
+// assemble.hip ----------------------------------------------------------------------------
+int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
+                    int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
+                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only);
+int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar);
+int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b);
+
+}  // namespace lpgp

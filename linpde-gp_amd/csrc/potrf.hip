@@ -1,0 +1,382 @@
+// Blocked right-looking Cholesky, block append (Schur complement), multi-RHS triangular
+// solves.  Replaces probnum `LinearOperator.cholesky/solve` -> LAPACK dpotrf/dpotrs/dtrtrs
+// (_conditional.py:44,108,228) and `BlockMatrix2x2.schur/_cholesky/schur_update`
+// (linops/_block.py:192-242): appending an observation block continues the factorisation
+// of the padded in-place matrix instead of building a nested block operator.
+//
+// Structure per panel of `nb` columns (nb = 4 tiles of 128 by default):
+//   for each 128-wide tile column:  potrf_tile (one workgroup, LDS resident; also emits
+//   the explicit inverse of the diagonal tile)  ->  panel rows below: X = A * Linv^T as an
+//   in-place MFMA GEMM  ->  rank-128 update of the rest of the panel;
+//   then the rank-nb SYRK trailing update (gemm.hip), split into the next panel's columns
+//   (high-priority stream, followed immediately by the next panel factorisation) and the
+//   remainder (second stream): look-ahead of one panel.
+
+#include <climits>
+
+#include "lpgp_internal.h"
+
+namespace lpgp {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+constexpr int TL = 136;                       // LDS leading dimension of the 128x128 tile (col-major)
+constexpr int TILE_LDS_DOUBLES = TILE * TL + 8 * 256;
+
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// In-place Cholesky of one 128x128 SPD tile (lower, column-major, leading dim lda) and the
+// explicit inverse of its factor (dense 128x128 column-major, zeros above the diagonal).
+__global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
+                                                          double* __restrict__ linv, int* __restrict__ info,
+                                                          int info_base) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* s = sm;                       // s[c*TL + r]
+  double* sD = sm + TILE * TL;          // 8 diagonal-block inverses, column-major 16x16: Linv[r][c] at [c*16 + r]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // ---- load tile ----
+  for (int c = wid; c < TILE; c += 4) {
+    v2f64 v = *reinterpret_cast<const v2f64*>(a + (int64_t)c * lda + 2 * lane);
+    *reinterpret_cast<v2f64*>(s + c * TL + 2 * lane) = v;
+  }
+  __syncthreads();
+
+  for (int jb = 0; jb < 8; ++jb) {
+    const int j0 = jb * 16;
+    // ---- (a) diagonal 16x16 block: factor + invert, wave 0, one matrix row per lane ----
+    if (wid == 0) {
+      double row[16];
+      const int i = r16;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) row[k] = s[(j0 + k) * TL + j0 + i];
+      double invd[16];
+      int bad = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double piv = bcast_lane(row[j], j);
+        if (!(piv > 0.0)) {
+          if (!bad) bad = j0 + j + 1;
+          piv = 1.0;
+        }
+        const double l = sqrt(piv);
+        const double inv = 1.0 / l;
+        invd[j] = inv;
+        row[j] = (i == j) ? l : row[j] * inv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = bcast_lane(row[j], k);
+          row[k] = fma(-row[j], lkj, row[k]);
+        }
+      }
+      if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
+      // inverse: lane c computes column c of X = L^{-1}
+      double x[16];
+      const int c = r16;
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        double acc = (ii == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < ii; ++k) acc = fma(-bcast_lane(row[k], ii), x[k], acc);
+        x[ii] = (ii >= c) ? acc * invd[ii] : 0.0;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          s[(j0 + k) * TL + j0 + i] = (k <= i) ? row[k] : 0.0;
+          sD[jb * 256 + c * 16 + k] = x[k];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (b) panel below: X_ib = A_ib * Linv^T  (in place) ----
+    for (int ib = jb + 1 + wid; ib < 8; ib += 4) {
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double aop = sD[jb * 256 + (4 * ks + g) * 16 + r16];            // Linv[c=r16][k]
+        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];         // A[r=r16][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[(j0 + g + 4 * q) * TL + ib * 16 + r16] = acc[q];
+    }
+    __syncthreads();
+    // ---- (c) trailing update inside the tile: A_ib,kb -= X_ib X_kb^T, jb < kb <= ib ----
+    const int cnt = 7 - jb;
+    const int npairs = cnt * (cnt + 1) / 2;
+    for (int pidx = wid; pidx < npairs; pidx += 4) {
+      int u = 0;
+      while ((u + 1) * (u + 2) / 2 <= pidx) ++u;
+      const int v = pidx - u * (u + 1) / 2;
+      const int ib = jb + 1 + u, kb = jb + 1 + v;
+      v4f64 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = s[(kb * 16 + g + 4 * q) * TL + ib * 16 + r16];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double aop = -s[(j0 + 4 * ks + g) * TL + kb * 16 + r16];        // -X_kb[c=r16][k]
+        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];         //  X_ib[r=r16][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[(kb * 16 + g + 4 * q) * TL + ib * 16 + r16] = acc[q];
+    }
+    __syncthreads();
+  }
+
+  // ---- inverse of the whole tile by block forward substitution; X_ij (i>j) is kept
+  //      transposed in the strict upper triangle: X_ij[r][c] at s[(i16+r)*TL + j16+c] ----
+  for (int dlt = 1; dlt < 8; ++dlt) {
+    for (int j = wid; j + dlt < 8; j += 4) {
+      const int i = j + dlt;
+      v4f64 S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double aop = s[(j * 16 + 4 * ks + g) * TL + i * 16 + r16];      // L_ij[m=r16][t]
+        const double bop = sD[j * 256 + r16 * 16 + 4 * ks + g];               // Linv_j[t][c=r16]
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, S, 0, 0, 0);
+      }
+      for (int k = j + 1; k < i; ++k) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double aop = s[(k * 16 + 4 * ks + g) * TL + i * 16 + r16];    // L_ik[m=r16][t]
+          const double bop = s[(k * 16 + 4 * ks + g) * TL + j * 16 + r16];    // X_kj[t][c=r16]
+          S = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, S, 0, 0, 0);
+        }
+      }
+      v4f64 X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double aop = -sD[i * 256 + (g + 4 * q) * 16 + r16];             // -Linv_i[r=r16][m=g+4q]
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, S[q], X, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[(i * 16 + g + 4 * q) * TL + j * 16 + r16] = X[q];
+    }
+    __syncthreads();
+  }
+
+  // ---- write back L (zeros above the diagonal) and Linv ----
+  for (int c = wid; c < TILE; c += 4) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + 64 * h;
+      a[(int64_t)c * lda + r] = (r >= c) ? s[c * TL + r] : 0.0;
+      double xv;
+      if (r < c) xv = 0.0;
+      else if ((r >> 4) == (c >> 4)) xv = sD[(c >> 4) * 256 + (c & 15) * 16 + (r & 15)];
+      else xv = s[r * TL + c];
+      linv[c * TILE + r] = xv;
+    }
+  }
+}
+
+int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
+                      int* d_info, int info_base) {
+  static bool attr_set = false;
+  const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
+  if (!attr_set) {
+    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
+  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), shmem, stream, a, lda, linv, d_info, info_base);
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                          int64_t ldc, int mt, int nt, int k, double alpha, double beta, int tri) {
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.mt = mt; g.nt = nt; g.k = k; g.alpha = alpha; g.beta = beta;
+  g.tri = tri; g.row_tile0 = 0; g.col_tile0 = 0; g.ktrim = 0;
+  return g;
+}
+
+#define LPGP_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != 0) return _rc;     \
+  } while (0)
+
+// Factor tile columns [t_done, T) of the padded matrix; columns [0, t_done) already hold L.
+int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
+  const int T = (int)T64, t_done = (int)t_done64;
+  const int64_t ld = mat->cap;
+  double* a = mat->a;
+  const int nbt = (int)(ctx->nb / TILE);
+  const int64_t tb = TILE;
+  hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
+  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
+
+  // ---- phase A (append): push the new rows through the already factored columns ----
+  if (t_done > 0 && T > t_done) {
+    const int mnew = T - t_done;
+    double* rows = a + (int64_t)t_done * tb;          // row offset of the new rows
+    for (int p0 = 0; p0 < t_done; p0 += nbt) {
+      const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
+      for (int jt = p0; jt < p1; ++jt) {
+        double* X = rows + (int64_t)jt * tb * ld;
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(X, ld, mat->linv + (int64_t)jt * tb * tb, tb, X, ld, mnew, 1, TILE, 1.0, 0.0, 0),
+                             LPGP_K_TRSM));
+        if (jt + 1 < p1)
+          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                               mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
+                                  rows + (int64_t)(jt + 1) * tb * ld, ld, mnew, p1 - jt - 1, TILE, -1.0, 1.0, 0),
+                               LPGP_K_GEMM));
+      }
+      const int K = (p1 - p0) * TILE;
+      double* Xp = rows + (int64_t)p0 * tb * ld;
+      if (p1 < t_done)
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(Xp, ld, a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld,
+                                rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                           mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, mnew, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+    }
+  }
+
+  // ---- phase B: right-looking with look-ahead ----
+  const bool la = ctx->lookahead != 0;
+  int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
+  int it = 0;
+  for (int p0 = t_done; p0 < T; p0 += nbt, ++it) {
+    const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
+    // panel factorisation on sP
+    for (int jt = p0; jt < p1; ++jt) {
+      double* dj = a + (int64_t)jt * tb * (ld + 1);
+      double* linv = mat->linv + (int64_t)jt * tb * tb;
+      LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
+      if (jt + 1 < T) {
+        double* X = dj + tb;     // rows below, same tile column
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0, mk(X, ld, linv, tb, X, ld, T - jt - 1, 1, TILE, 1.0, 0.0, 0),
+                             LPGP_K_TRSM));
+        if (jt + 1 < p1)
+          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                               mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
+                                  p1 - jt - 1, TILE, -1.0, 1.0, 1),
+                               LPGP_K_GEMM));
+      }
+    }
+    if (p1 >= T) break;
+    const int K = (p1 - p0) * TILE;
+    const double* P = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;      // panel rows below
+    if (!la) {
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, T - p1, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+      continue;
+    }
+    const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
+    // panel done -> the remainder update may start
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
+    // (a) next panel's columns on sP; they were last written by the previous remainder update
+    if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
+    LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
+                         LPGP_K_SYRK));
+    // (b) remainder on sU
+    if (p2 < T) {
+      const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
+      LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+      LPGP_TRY(launch_gemm(ctx, sU, 0, 0,
+                           mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+      have_upd_event = 1;
+    } else {
+      have_upd_event = 0;
+    }
+  }
+  if (la) {
+    // join: sP must not run ahead of outstanding sU work
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
+  }
+  int h_info = 0;
+  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
+  LPGP_HIP(hipStreamSynchronize(sP));
+  if (info) *info = h_info;
+  return 0;
+}
+
+// V <- L^{-1} V for a padded (T*128) x m_pad block, column-major with leading dim ldv.
+int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
+  const int T = (int)T64;
+  const int64_t ld = mat->cap, tb = TILE;
+  const int mtl = (int)(m_pad / TILE);
+  const int nbt = (int)(ctx->nb / TILE);
+  const double* a = mat->a;
+  hipStream_t st = ctx->s_main;
+  for (int p0 = 0; p0 < T; p0 += nbt) {
+    const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
+    for (int jt = p0; jt < p1; ++jt) {
+      double* Vj = v + (int64_t)jt * tb;
+      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+                           mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
+                           LPGP_K_TRSM));
+      if (jt + 1 < p1)
+        LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+                             mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, ldv,
+                                v + (int64_t)(jt + 1) * tb, ldv, p1 - jt - 1, mtl, TILE, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+    }
+    if (p1 < T)
+      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+                           mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, v + (int64_t)p0 * tb, ldv,
+                              v + (int64_t)p1 * tb, ldv, T - p1, mtl, (p1 - p0) * TILE, -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+  }
+  return 0;
+}
+
+// V <- L^{-T} V (backward substitution), same layout.
+int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
+  const int T = (int)T64;
+  const int64_t ld = mat->cap, tb = TILE;
+  const int mtl = (int)(m_pad / TILE);
+  const int nbt = (int)(ctx->nb / TILE);
+  const double* a = mat->a;
+  hipStream_t st = ctx->s_main;
+  for (int p1 = T; p1 > 0;) {
+    const int p0 = (p1 - nbt > 0) ? p1 - nbt : 0;
+    for (int jt = p1 - 1; jt >= p0; --jt) {
+      double* Vj = v + (int64_t)jt * tb;
+      // x_jt = Linv_jt^T y_jt
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1,
+                           mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
+                           LPGP_K_TRSM));
+      if (jt > p0)
+        LPGP_TRY(launch_gemm(ctx, st, 1, 1,
+                             mk(a + (int64_t)jt * tb + (int64_t)p0 * tb * ld, ld, Vj, ldv,
+                                v + (int64_t)p0 * tb, ldv, jt - p0, mtl, TILE, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+    }
+    if (p0 > 0)
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1,
+                           mk(a + (int64_t)p0 * tb, ld, v + (int64_t)p0 * tb, ldv, v, ldv, p0, mtl,
+                              (p1 - p0) * TILE, -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+    p1 = p0;
+  }
+  return 0;
+}
+
+}  // namespace lpgp

@@ -1,0 +1,273 @@
+"""Object layer over the C ABI: device context, point sets, the block Gram matrix /
+Cholesky factor and right-hand-side blocks.  Pure plumbing (ctypes + NumPy); all
+arithmetic of the hot path happens in liblpgp.so on the GPU."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, as_pd, lib
+
+
+class Context:
+    """One per process / per GPU (`lpgp_init`)."""
+
+    def __init__(self, device: int | None = None):
+        if device is None:
+            device = int(os.environ.get("LPGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = C.c_void_p()
+        check(lib.lpgp_init(int(device), C.byref(h)), "lpgp_init")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib.lpgp_finalize(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib.lpgp_sync(self._h), "lpgp_sync")
+
+    def set_option(self, key: str, value: int):
+        check(lib.lpgp_set_option(self._h, key.encode(), int(value)), "lpgp_set_option")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        hbm = C.c_int64()
+        check(lib.lpgp_device_info(self._h, name, 256, C.byref(cus), C.byref(hbm)), "lpgp_device_info")
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+    # ---- measurement ----
+    def profile_enable(self, on: bool = True):
+        check(lib.lpgp_profile_enable(self._h, int(on)), "lpgp_profile_enable")
+
+    def profile_reset(self):
+        check(lib.lpgp_profile_reset(self._h), "lpgp_profile_reset")
+
+    def profile_get(self) -> dict:
+        out = {}
+        for kid, name in enumerate(_lib.KERNEL_NAMES):
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            n = C.c_int64()
+            check(lib.lpgp_profile_get(self._h, kid, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
+                  "lpgp_profile_get")
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    def probe_mfma_f64(self) -> float:
+        v = C.c_double()
+        check(lib.lpgp_probe_mfma_f64(self._h, C.byref(v)), "lpgp_probe_mfma_f64")
+        return v.value
+
+    def probe_hbm_write(self, nbytes: int = 1 << 30) -> float:
+        v = C.c_double()
+        check(lib.lpgp_probe_hbm_write(self._h, int(nbytes), C.byref(v)), "lpgp_probe_hbm_write")
+        return v.value
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context() -> Context:
+    """Process-wide context on device $LPGP_DEVICE / $LOCAL_RANK / 0."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context()
+        return _default_ctx
+
+
+class Points:
+    """Device-resident point set (`lpgp_pts_create`)."""
+
+    def __init__(self, ctx: Context, X: np.ndarray):
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.double))
+        if X.ndim != 2:
+            raise ValueError(f"points must have shape (n, d), got {X.shape}")
+        self.ctx = ctx
+        self.n, self.d = X.shape
+        h = C.c_void_p()
+        check(lib.lpgp_pts_create(ctx._h, as_pd(X), self.n, self.d, C.byref(h)), "lpgp_pts_create")
+        self._h = h
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.lpgp_pts_destroy(self._h)
+            self._h = None
+
+
+class GramMatrix:
+    """Block Gram matrix that becomes its own Cholesky factor (`lpgp_mat_*`, `lpgp_potrf`)."""
+
+    def __init__(self, ctx: Context, capacity_hint: int = 0):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib.lpgp_mat_create(ctx._h, int(capacity_hint), C.byref(h)), "lpgp_mat_create")
+        self._h = h
+        self.block_sizes: list[int] = []
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.lpgp_mat_destroy(self._h)
+            self._h = None
+
+    @property
+    def n(self) -> int:
+        return int(lib.lpgp_mat_size(self._h))
+
+    @property
+    def padded_n(self) -> int:
+        return int(lib.lpgp_mat_padded_size(self._h))
+
+    def add_block(self, n: int) -> int:
+        bi = lib.lpgp_mat_add_block(self.ctx._h, self._h, int(n))
+        if bi < 0:
+            check(bi, "lpgp_mat_add_block")
+        self.block_sizes.append(int(n))
+        return bi
+
+    def assemble(self, kdesc, X0: Points, X1: Points | None, bi: int, bj: int):
+        arr = _lib.make_kdesc_array(kdesc)
+        check(lib.lpgp_gram_assemble(self.ctx._h, arr, len(arr), X0._h, X1._h if X1 is not None else None,
+                                     self._h, bi, bj), "lpgp_gram_assemble")
+
+    def add_diag(self, bi: int, v: np.ndarray | None = None, scalar: float = 0.0):
+        if v is not None:
+            v = np.ascontiguousarray(v, dtype=np.double)
+            if v.shape != (self.block_sizes[bi],):
+                raise ValueError("diagonal has the wrong length")
+        check(lib.lpgp_mat_add_diag(self.ctx._h, self._h, bi, as_pd(v) if v is not None else None, float(scalar)),
+              "lpgp_mat_add_diag")
+
+    def add_dense(self, bi: int, B: np.ndarray):
+        B = np.ascontiguousarray(B, dtype=np.double)
+        n = self.block_sizes[bi]
+        if B.shape != (n, n):
+            raise ValueError("dense noise block has the wrong shape")
+        check(lib.lpgp_mat_add_dense(self.ctx._h, self._h, bi, as_pd(B)), "lpgp_mat_add_dense")
+
+    def todense(self, what: str = "gram") -> np.ndarray:
+        n = self.n
+        out = np.empty((n, n))
+        check(lib.lpgp_mat_to_host(self.ctx._h, self._h, 0 if what == "gram" else 1, as_pd(out)), "lpgp_mat_to_host")
+        return out
+
+    def potrf(self) -> int:
+        info = C.c_int32()
+        check(lib.lpgp_potrf(self.ctx._h, self._h, C.byref(info)), "lpgp_potrf")
+        return info.value
+
+    def potrs(self, B: np.ndarray) -> np.ndarray:
+        """Solve G X = B for B of shape (n,) or (n, nrhs)."""
+        B = np.asarray(B, dtype=np.double)
+        vec = B.ndim == 1
+        Bc = np.asfortranarray(B.reshape(self.n, -1)).copy(order="F")
+        buf = np.ascontiguousarray(Bc.T)          # (nrhs, n) C-order == (n, nrhs) column-major
+        check(lib.lpgp_potrs(self.ctx._h, self._h, as_pd(buf), buf.shape[0]), "lpgp_potrs")
+        X = buf.T
+        return X[:, 0].copy() if vec else np.ascontiguousarray(X)
+
+    def solve_weights(self, r: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(r, dtype=np.double)
+        if r.shape != (self.n,):
+            raise ValueError(f"residual must have shape ({self.n},), got {r.shape}")
+        w = np.empty_like(r)
+        check(lib.lpgp_solve_weights(self.ctx._h, self._h, as_pd(r), as_pd(w)), "lpgp_solve_weights")
+        return w
+
+
+class Rhs:
+    """Device-resident n x m block sharing the row layout of a GramMatrix (`lpgp_rhs_*`)."""
+
+    def __init__(self, ctx: Context, mat: GramMatrix, m: int):
+        self.ctx, self.mat, self.m = ctx, mat, int(m)
+        h = C.c_void_p()
+        check(lib.lpgp_rhs_create(ctx._h, mat._h, self.m, C.byref(h)), "lpgp_rhs_create")
+        self._h = h
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.lpgp_rhs_destroy(self._h)
+            self._h = None
+
+    def cross_assemble(self, kdesc, X_obs: Points, X_test: Points, bi: int):
+        arr = _lib.make_kdesc_array(kdesc)
+        check(lib.lpgp_cross_assemble(self.ctx._h, arr, len(arr), X_obs._h, X_test._h, self._h, self.mat._h, bi),
+              "lpgp_cross_assemble")
+
+    def trsm_lower(self):
+        check(lib.lpgp_trsm_lower(self.ctx._h, self.mat._h, self._h), "lpgp_trsm_lower")
+
+    def predict(self, prior_mean: np.ndarray | None, kxx: np.ndarray | None, want_mean=True, want_var=True):
+        mean = np.empty(self.m) if want_mean else None
+        var = np.empty(self.m) if want_var else None
+        pm = np.ascontiguousarray(prior_mean, dtype=np.double) if prior_mean is not None else None
+        kx = np.ascontiguousarray(kxx, dtype=np.double) if kxx is not None else None
+        check(lib.lpgp_predict(self.ctx._h, self.mat._h, self._h,
+                               as_pd(pm) if pm is not None else None,
+                               as_pd(kx) if kx is not None else None,
+                               as_pd(mean) if mean is not None else None,
+                               as_pd(var) if var is not None else None), "lpgp_predict")
+        return mean, var
+
+    def inner(self, other: "Rhs") -> np.ndarray:
+        out = np.empty((self.m, other.m))
+        check(lib.lpgp_rhs_inner(self.ctx._h, self._h, other._h, as_pd(out)), "lpgp_rhs_inner")
+        return out
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.mat.n, self.m))
+        check(lib.lpgp_rhs_to_host(self.ctx._h, self.mat._h, self._h, as_pd(out)), "lpgp_rhs_to_host")
+        return out
+
+
+def kernel_diag(ctx: Context, kdesc) -> float:
+    arr = _lib.make_kdesc_array(kdesc)
+    v = C.c_double()
+    check(lib.lpgp_kernel_diag(ctx._h, arr, len(arr), C.byref(v)), "lpgp_kernel_diag")
+    return v.value
+
+
+def kernel_matrix(ctx: Context, kdesc, X0: Points, X1: Points) -> np.ndarray:
+    arr = _lib.make_kdesc_array(kdesc)
+    out = np.empty((X0.n, X1.n))
+    check(lib.lpgp_kernel_matrix(ctx._h, arr, len(arr), X0._h, X1._h, as_pd(out)), "lpgp_kernel_matrix")
+    return out
+
+
+def test_gemm(ctx: Context, ta: int, tb: int, lower_only: int, alpha: float, A: np.ndarray, B: np.ndarray,
+              beta: float, Cm: np.ndarray, k: int, reps: int = 0):
+    """Raw GEMM on column-major (Fortran-ordered) arrays; returns (C, ms_per_rep)."""
+    A = np.asfortranarray(A, dtype=np.double)
+    B = np.asfortranarray(B, dtype=np.double)
+    Cm = np.asfortranarray(Cm, dtype=np.double).copy(order="F")
+    m, n = Cm.shape
+    ms = C.c_double(0.0)
+    pd = C.POINTER(C.c_double)
+    check(lib.lpgp_test_gemm(ctx._h, ta, tb, lower_only, m, n, k, alpha,
+                             A.ctypes.data_as(pd), A.shape[0], B.ctypes.data_as(pd), B.shape[0], beta,
+                             Cm.ctypes.data_as(pd), Cm.shape[0], reps, C.byref(ms)), "lpgp_test_gemm")
+    return Cm, ms.value
+
+
+def test_potrf_tile(ctx: Context, T: np.ndarray):
+    T = np.asfortranarray(T, dtype=np.double).copy(order="F")
+    Linv = np.zeros((128, 128), order="F")
+    info = C.c_int32()
+    pd = C.POINTER(C.c_double)
+    check(lib.lpgp_test_potrf_tile(ctx._h, T.ctypes.data_as(pd), Linv.ctypes.data_as(pd), C.byref(info)),
+          "lpgp_test_potrf_tile")
+    return T, Linv, info.value

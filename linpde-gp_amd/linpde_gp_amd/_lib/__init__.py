@@ -1,0 +1,148 @@
+"""ctypes binding of liblpgp.so (C ABI: include/lpgp.h).
+
+There is NO CPU fallback: importing this module without the built library, or creating
+a `Context` without a visible MI355X, raises.  Build with
+`linpde-gp_amd/csrc/build.sh` (or `__graft_entry__.build()`).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpgp.so")
+
+MAXD, MAXT, MAXG = 4, 64, 4
+MATERN_HALFINT, EXPQUAD = 1, 2
+K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm")
+
+
+class Term(C.Structure):
+    _fields_ = [("coef", C.c_double), ("n0", C.c_int32 * MAXD), ("n1", C.c_int32 * MAXD)]
+
+
+class KDesc(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32),
+        ("family", C.c_int32 * MAXD),
+        ("p", C.c_int32 * MAXD),
+        ("lengthscale", C.c_double * MAXD),
+        ("scale", C.c_double),
+        ("nterms", C.c_int32),
+        ("terms", Term * MAXT),
+    ]
+
+
+class LpgpError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run linpde-gp_amd/csrc/build.sh); there is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd = C.POINTER(C.c_double)
+    pk = C.POINTER(KDesc)
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("lpgp_init", C.c_int, C.c_int, C.POINTER(vp))
+    sig("lpgp_finalize", C.c_int, vp)
+    sig("lpgp_last_error", C.c_char_p)
+    sig("lpgp_device_info", C.c_int, vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64))
+    sig("lpgp_sync", C.c_int, vp)
+    sig("lpgp_set_option", C.c_int, vp, C.c_char_p, i64)
+    sig("lpgp_pts_create", C.c_int, vp, pd, i64, i32, C.POINTER(vp))
+    sig("lpgp_pts_destroy", C.c_int, vp)
+    sig("lpgp_mat_create", C.c_int, vp, i64, C.POINTER(vp))
+    sig("lpgp_mat_destroy", C.c_int, vp)
+    sig("lpgp_mat_add_block", C.c_int, vp, vp, i64)
+    sig("lpgp_mat_size", i64, vp)
+    sig("lpgp_mat_padded_size", i64, vp)
+    sig("lpgp_gram_assemble", C.c_int, vp, pk, i32, vp, vp, vp, i32, i32)
+    sig("lpgp_mat_add_diag", C.c_int, vp, vp, i32, pd, dbl)
+    sig("lpgp_mat_add_dense", C.c_int, vp, vp, i32, pd)
+    sig("lpgp_mat_to_host", C.c_int, vp, vp, i32, pd)
+    sig("lpgp_potrf", C.c_int, vp, vp, C.POINTER(i32))
+    sig("lpgp_potrs", C.c_int, vp, vp, pd, i64)
+    sig("lpgp_solve_weights", C.c_int, vp, vp, pd, pd)
+    sig("lpgp_rhs_create", C.c_int, vp, vp, i64, C.POINTER(vp))
+    sig("lpgp_rhs_destroy", C.c_int, vp)
+    sig("lpgp_cross_assemble", C.c_int, vp, pk, i32, vp, vp, vp, vp, i32)
+    sig("lpgp_predict", C.c_int, vp, vp, vp, pd, pd, pd, pd)
+    sig("lpgp_trsm_lower", C.c_int, vp, vp, vp)
+    sig("lpgp_rhs_inner", C.c_int, vp, vp, vp, pd)
+    sig("lpgp_rhs_to_host", C.c_int, vp, vp, vp, pd)
+    sig("lpgp_kernel_diag", C.c_int, vp, pk, i32, pd)
+    sig("lpgp_kernel_matrix", C.c_int, vp, pk, i32, vp, vp, pd)
+    sig("lpgp_profile_enable", C.c_int, vp, i32)
+    sig("lpgp_profile_reset", C.c_int, vp)
+    sig("lpgp_profile_get", C.c_int, vp, i32, pd, C.POINTER(i64), pd, pd)
+    sig("lpgp_test_gemm", C.c_int, vp, i32, i32, i32, i64, i64, i64, dbl, pd, i64, pd, i64, dbl, pd, i64, i32, pd)
+    sig("lpgp_test_potrf_tile", C.c_int, vp, pd, pd, C.POINTER(i32))
+    sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
+    sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
+    return lib
+
+
+lib = _load()
+
+EXPORTED = [
+    "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
+    "lpgp_set_option", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
+    "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_size", "lpgp_mat_padded_size",
+    "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
+    "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_rhs_create", "lpgp_rhs_destroy",
+    "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
+    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_profile_enable", "lpgp_profile_reset",
+    "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_probe_mfma_f64",
+    "lpgp_probe_hbm_write",
+]
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.lpgp_last_error().decode(errors="replace")
+        raise LpgpError(f"{what} failed (rc={rc}): {msg}")
+
+
+def as_pd(a: np.ndarray):
+    assert a.dtype == np.double and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_kdesc_array(groups) -> "C.Array[KDesc]":
+    """groups: list of dicts {d, family[], p[], lengthscale[], scale, terms[(coef, n0[], n1[])]}."""
+    if not 1 <= len(groups) <= MAXG:
+        raise ValueError(f"between 1 and {MAXG} summands supported, got {len(groups)}")
+    arr = (KDesc * len(groups))()
+    for kd, g in zip(arr, groups):
+        d = int(g["d"])
+        if not 1 <= d <= MAXD:
+            raise ValueError(f"input dimension {d} not supported (max {MAXD})")
+        if not 1 <= len(g["terms"]) <= MAXT:
+            raise ValueError(f"{len(g['terms'])} terms not supported (max {MAXT})")
+        kd.d = d
+        for j in range(d):
+            kd.family[j] = int(g["family"][j])
+            kd.p[j] = int(g["p"][j])
+            kd.lengthscale[j] = float(g["lengthscale"][j])
+        kd.scale = float(g["scale"])
+        kd.nterms = len(g["terms"])
+        for t, (coef, n0, n1) in enumerate(g["terms"]):
+            kd.terms[t].coef = float(coef)
+            for j in range(d):
+                kd.terms[t].n0[j] = int(n0[j])
+                kd.terms[t].n1[j] = int(n1[j])
+    return arr

@@ -1,0 +1,155 @@
+"""Linear functionals on the hot path: point evaluation, optionally composed with a
+differential operator.
+
+Host mirror of
+  `linfunctls/_linfunctl.py:14-129`   LinearFunctional (+ `@` with a function operator)
+  `linfunctls/_evaluation.py:10-64`   _EvaluationFunctional (output = codomain shape, then
+                                      batch shape; scalar-valued priors only here)
+  `linfunctls/_arithmetic.py:92-174`  CompositeLinearFunctional
+Integrals, L2 projections and weak forms are out of scope.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ..linfuncops import LinearFunctionOperator
+
+
+def _as_shape(shape):
+    if isinstance(shape, (int, np.integer)):
+        return (int(shape),)
+    return tuple(int(s) for s in shape)
+
+
+class LinearFunctional:
+    def __init__(self, input_shapes, output_shape):
+        self._input_domain_shape = _as_shape(input_shapes[0])
+        self._input_codomain_shape = _as_shape(input_shapes[1])
+        self._output_shape = _as_shape(output_shape)
+
+    @property
+    def input_shapes(self):
+        return (self._input_domain_shape, self._input_codomain_shape)
+
+    @property
+    def input_domain_shape(self):
+        return self._input_domain_shape
+
+    @property
+    def input_codomain_shape(self):
+        return self._input_codomain_shape
+
+    @property
+    def output_shape(self):
+        return self._output_shape
+
+    @property
+    def output_size(self):
+        return int(np.prod(self._output_shape, dtype=int))
+
+    # canonical form used by the GPU path: evaluation points + operator coefficient map
+    def points(self) -> np.ndarray:
+        raise NotImplementedError
+
+    def coefficients_dict(self) -> dict:
+        raise NotImplementedError
+
+    def __call__(self, f, /, *, argnum: int = 0):
+        from ..functions import Function
+        from ..randprocs import _gaussian_process as gps
+        from ..randprocs import covfuncs
+
+        if isinstance(f, gps.ConditionalGaussianProcess):
+            return gps.apply_linfunctl_to_conditional_gp(self, f)
+        if isinstance(f, gps.GaussianProcess):
+            return gps.apply_linfunctl_to_gp(self, f)
+        if isinstance(f, covfuncs.CovarianceFunction):
+            return covfuncs.ProcessVectorCrossCovariance(f, self, argnum=argnum)
+        if isinstance(f, Function):
+            return self._apply_to_function(f)
+        raise NotImplementedError(f"cannot apply {type(self).__name__} to {type(f).__name__}")
+
+    def _apply_to_function(self, f):
+        raise NotImplementedError
+
+    def __matmul__(self, other):
+        if isinstance(other, LinearFunctionOperator):
+            return CompositeLinearFunctional(linfunctl=self, linfuncop=other)
+        return NotImplemented
+
+
+class _EvaluationFunctional(LinearFunctional):
+    def __init__(self, input_domain_shape, input_codomain_shape, X):
+        input_domain_shape = _as_shape(input_domain_shape)
+        input_codomain_shape = _as_shape(input_codomain_shape)
+        self._X = np.asanyarray(X)
+        nd = len(input_domain_shape)
+        self._X_batch_shape = self._X.shape[: self._X.ndim - nd]
+        if self._X.shape != self._X_batch_shape + input_domain_shape:
+            raise ValueError(
+                f"X has shape {self._X.shape}, expected batch shape + {input_domain_shape}")
+        super().__init__(
+            input_shapes=(input_domain_shape, input_codomain_shape),
+            output_shape=input_codomain_shape + self._X_batch_shape,
+        )
+
+    @property
+    def X(self):
+        return self._X
+
+    @property
+    def X_batch_shape(self):
+        return self._X_batch_shape
+
+    def points(self) -> np.ndarray:
+        d = self._input_domain_shape[0] if self._input_domain_shape else 1
+        return np.ascontiguousarray(np.asarray(self._X, dtype=np.double).reshape(-1, d))
+
+    def coefficients_dict(self):
+        d = self._input_domain_shape[0] if self._input_domain_shape else 1
+        return {(0,) * d: 1.0}
+
+    def _apply_to_function(self, f):
+        res = np.asarray(f(self._X))
+        if f.output_ndim > 0:
+            res = np.moveaxis(res, res.ndim - f.output_ndim + np.arange(f.output_ndim), np.arange(f.output_ndim))
+        return res
+
+
+class CompositeLinearFunctional(LinearFunctional):
+    """`linfunctl @ linfuncop` -- here: point evaluation of `linfuncop[f]`."""
+
+    def __init__(self, *, linfunctl: LinearFunctional, linfuncop: LinearFunctionOperator, linop=None):
+        if linop is not None:
+            raise NotImplementedError("a leading matrix factor is not supported on the MI355X path")
+        if linfunctl.input_shapes != linfuncop.output_shapes:
+            raise ValueError("shapes of the functional and the operator do not match")
+        self._linfunctl = linfunctl
+        self._linfuncop = linfuncop
+        super().__init__(input_shapes=linfuncop.input_shapes, output_shape=linfunctl.output_shape)
+
+    @property
+    def linfunctl(self):
+        return self._linfunctl
+
+    @property
+    def linfuncop(self):
+        return self._linfuncop
+
+    def points(self):
+        return self._linfunctl.points()
+
+    def coefficients_dict(self):
+        inner = self._linfunctl.coefficients_dict()
+        d = len(next(iter(inner)))
+        if set(inner) != {(0,) * d}:
+            raise NotImplementedError("only point evaluation may be composed with an operator")
+        c0 = inner[(0,) * d]
+        return {mi: c0 * c for mi, c in self._linfuncop.coefficients_dict().items()}
+
+    def _apply_to_function(self, f):
+        return self._linfunctl(self._linfuncop(f))
+
+
+__all__ = ["LinearFunctional", "_EvaluationFunctional", "CompositeLinearFunctional"]

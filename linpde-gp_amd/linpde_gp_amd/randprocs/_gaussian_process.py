@@ -1,0 +1,398 @@
+"""`GaussianProcess` and `ConditionalGaussianProcess` -- orchestration of the hot path.
+
+Host mirror of `randprocs/_gaussian_process/_conditional.py` of the reference:
+  `from_observations`            :27-54    first conditioning
+  `representer_weights`          :96-110
+  `PriorPredictiveCrossCovariance` :112-175  kLas(x) = [(k L_j'^*)(x, X_j)]_j
+  `Mean._evaluate`               :193-197  m(x) + kLas(x) @ w
+  `CovarianceFunction._evaluate` :223-231  k(x,x') - kLas(x) G^{-1} kLas(x')^T
+  `condition_on_observations`    :253-294  re-conditioning (Schur / block Cholesky)
+  `_preprocess_observations`     :296-399  build L, validate X/Y/b, flatten C-order
+  functional / operator read-outs :432-467
+Same call signature, argument meaning and error behaviour; the arithmetic (Gram and
+cross-covariance assembly, Cholesky, triangular solves, mean/variance reductions) runs in
+liblpgp.so on the GPU and the factor stays resident in HBM: re-conditioning appends a
+block row to the factor instead of nesting `BlockMatrix2x2` operators.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _engine, functions, linfunctls, randvars
+from ..linfuncops import LinearFunctionOperator
+from ..linfunctls import LinearFunctional
+from . import covfuncs
+
+
+class GaussianProcess:
+    """Prior GP (probnum `randprocs.GaussianProcess` surface used by linpde-gp)."""
+
+    def __init__(self, mean, cov):
+        if not isinstance(mean, functions.Function):
+            raise TypeError("`mean` must be a `functions.Function`")
+        if not isinstance(cov, covfuncs.CovarianceFunction):
+            raise TypeError("`cov` must be a `CovarianceFunction`")
+        if mean.input_shape != cov.input_shape:
+            raise ValueError(
+                f"mean and covariance function disagree on the input shape: "
+                f"{mean.input_shape} != {cov.input_shape}")
+        if mean.output_shape != ():
+            raise NotImplementedError("multi-output GPs are out of scope of the MI355X path")
+        self._mean = mean
+        self._cov = cov
+
+    @property
+    def mean(self):
+        return self._mean
+
+    @property
+    def cov(self):
+        return self._cov
+
+    @property
+    def input_shape(self):
+        return self._mean.input_shape
+
+    @property
+    def input_ndim(self):
+        return len(self._mean.input_shape)
+
+    @property
+    def output_shape(self):
+        return ()
+
+    def _flat(self, x):
+        x = np.asarray(x, dtype=np.double)
+        batch = x.shape[: x.ndim - self.input_ndim]
+        d = max(int(np.prod(self.input_shape, dtype=int)), 1)
+        return np.ascontiguousarray(x.reshape(-1, d)), batch
+
+    def __call__(self, x) -> randvars.Normal:
+        X, batch = self._flat(x)
+        if len(batch) != 1:
+            raise ValueError("`GaussianProcess.__call__` needs inputs of shape (N,) + input_shape")
+        return randvars.Normal(self.mean(x), self.cov.matrix(x))
+
+    def var(self, x):
+        return self.cov(x, None)
+
+    def std(self, x):
+        return np.sqrt(np.maximum(self.var(x), 0.0))
+
+    def condition_on_observations(self, Y, X=None, *, L=None, b=None):
+        return ConditionalGaussianProcess.from_observations(self, Y, X, L=L, b=b)
+
+
+class _ObservationBlock:
+    __slots__ = ("Y", "L", "b", "X", "coeffs", "points", "pred_mean")
+
+    def __init__(self, Y, L, b, X, coeffs, points, pred_mean):
+        self.Y, self.L, self.b, self.X = Y, L, b, X
+        self.coeffs = coeffs          # coefficient map of the functional's operator part
+        self.points = points          # device point set
+        self.pred_mean = pred_mean    # L[m] + b.mean, flattened
+
+
+class _GramOperator:
+    """What `ConditionalGaussianProcess.gram` returns: the resident factorisation with the
+    `solve` / `cholesky` / `todense` subset of probnum's `LinearOperator` protocol."""
+
+    def __init__(self, cgp: "ConditionalGaussianProcess"):
+        self._cgp = cgp
+
+    @property
+    def shape(self):
+        n = self._cgp._state.mat.n
+        return (n, n)
+
+    def solve(self, B):
+        self._cgp._check_current()
+        return self._cgp._state.mat.potrs(B)
+
+    def cholesky(self, lower: bool = True):
+        self._cgp._check_current()
+        Lf = self._cgp._state.mat.todense("factor")
+        return Lf if lower else Lf.T
+
+    def todense(self):
+        Lf = self.cholesky(True)
+        return Lf @ Lf.T
+
+
+class _DeviceState:
+    """Device-resident state shared along a chain of conditionings."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.mat = _engine.GramMatrix(ctx)
+        self.generation = 0
+
+
+class ConditionalGaussianProcess(GaussianProcess):
+    @classmethod
+    def from_observations(cls, prior: GaussianProcess, Y, X=None, *, L=None, b=None):
+        Yf, Lf, bf, Xpts, coeffs, pred_mean = cls._preprocess_observations(prior=prior, Y=Y, X=X, L=L, b=b)
+        state = _DeviceState(_engine.default_context())
+        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, _engine.Points(state.ctx, Xpts), pred_mean)
+        return cls._extend(prior, state, (), block)
+
+    @classmethod
+    def _extend(cls, prior, state, old_blocks, new_block):
+        mat = state.mat
+        base = prior.cov
+        bi = mat.add_block(new_block.points.n)
+        assert bi == len(old_blocks)
+        # lower-left blocks  (L_new k L_j'^*)(X_new, X_j)   (`_conditional.py:270`)
+        for bj, ob in enumerate(old_blocks):
+            k = covfuncs.DifferentiatedCovarianceFunction(
+                covfuncs._base(base), *_combine(base, new_block.coeffs, ob.coeffs))
+            mat.assemble(k.lower(), new_block.points, ob.points, bi, bj)
+        k = covfuncs.DifferentiatedCovarianceFunction(
+            covfuncs._base(base), *_combine(base, new_block.coeffs, new_block.coeffs))
+        mat.assemble(k.lower(), new_block.points, None, bi, bi)
+        # measurement noise  gram + b.cov   (`_conditional.py:392-394`)
+        if new_block.b is not None and isinstance(new_block.b, randvars.Normal):
+            cov = np.asarray(new_block.b.cov)
+            n = new_block.points.n
+            cov = cov.reshape(n, n)
+            off = cov - np.diag(np.diag(cov))
+            if np.any(off != 0.0):
+                mat.add_dense(bi, cov)
+            else:
+                mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
+        info = mat.potrf()
+        if info != 0:
+            raise np.linalg.LinAlgError(
+                f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
+        blocks = tuple(old_blocks) + (new_block,)
+        r = np.concatenate([ob.Y - ob.pred_mean for ob in blocks])
+        w = mat.solve_weights(r)
+        state.generation += 1
+        return cls(prior=prior, blocks=blocks, state=state, representer_weights=w)
+
+    def __init__(self, *, prior, blocks, state, representer_weights, test_coeffs=None):
+        self._prior = prior
+        self._blocks = tuple(blocks)
+        self._state = state
+        self._generation = state.generation
+        self._representer_weights = representer_weights
+        d = max(int(np.prod(prior.input_shape, dtype=int)), 1)
+        self._test_coeffs = dict(test_coeffs) if test_coeffs is not None else {(0,) * d: 1.0}
+        GaussianProcess.__init__(
+            self,
+            mean=_PosteriorMean(self),
+            cov=_PosteriorCovarianceFunction(self),
+        )
+
+    # -- reference attribute surface --
+    @property
+    def gram(self):
+        return _GramOperator(self)
+
+    @property
+    def representer_weights(self) -> np.ndarray:
+        return self._representer_weights
+
+    @property
+    def prior(self):
+        return self._prior
+
+    def _check_current(self):
+        if self._generation != self._state.generation:
+            raise RuntimeError(
+                "this ConditionalGaussianProcess has been extended by a later "
+                "`condition_on_observations`; its device-resident factor now belongs to the "
+                "newer object (the factor is updated in place in HBM)")
+
+    def condition_on_observations(self, Y, X=None, *, L=None, b=None):
+        self._check_current()
+        if any(v != 1.0 or any(mi) for mi, v in self._test_coeffs.items()):
+            raise NotImplementedError("conditioning a transformed posterior is not supported")
+        Yf, Lf, bf, Xpts, coeffs, pred_mean = self._preprocess_observations(
+            prior=self._prior, Y=Y, X=X, L=L, b=b)
+        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, _engine.Points(self._state.ctx, Xpts), pred_mean)
+        return ConditionalGaussianProcess._extend(self._prior, self._state, self._blocks, block)
+
+    @classmethod
+    def _preprocess_observations(cls, *, prior, Y, X, L, b):
+        # build measurement functional `L`
+        if isinstance(L, LinearFunctional):
+            if X is not None:
+                raise TypeError("If `L` is a `LinearFunctional`, `X` must be `None`.")
+        elif isinstance(L, LinearFunctionOperator):
+            if X is None:
+                raise ValueError("`X` must not be omitted if `L` is a `LinearFunctionOperator`.")
+            L = L.to_linfunctl(X)
+        elif L is None:
+            if X is None:
+                raise ValueError("`X` and `L` can not be omitted at the same time.")
+            L = linfunctls._EvaluationFunctional(
+                input_domain_shape=prior.input_shape, input_codomain_shape=prior.output_shape, X=X)
+        else:
+            raise TypeError("`L` must be a `LinearFunctional`, a `LinearFunctionOperator` or None")
+        if L.input_domain_shape != tuple(prior.input_shape):
+            raise ValueError(
+                f"`L` acts on functions with input shape {L.input_domain_shape}, the prior has "
+                f"input shape {prior.input_shape}")
+        # measurement noise model
+        if b is not None:
+            b = randvars.asrandvar(b)
+            if not isinstance(b, (randvars.Constant, randvars.Normal)):
+                raise TypeError(f"`b` must be a `Normal` or a `Constant` `RandomVariable` ({type(b)=})")
+            if tuple(b.shape) != tuple(L.output_shape):
+                raise ValueError(f"{b.shape=} must be equal to {L.output_shape}")
+        coeffs = L.coefficients_dict()
+        Xpts = L.points()
+        # predictive mean  L[m] (+ b.mean)
+        pred_mean = np.asarray(L(prior.mean), dtype=np.double).reshape(-1, order="C")
+        Y = np.asarray(Y, dtype=np.double)
+        if Y.shape != tuple(L.output_shape):
+            raise ValueError(f"Expected Y to have shape {L.output_shape}, got shape {Y.shape}.")
+        Y = Y.reshape(-1, order="C")
+        if b is not None:
+            pred_mean = pred_mean + np.asarray(b.mean, dtype=np.double).reshape(-1, order="C")
+        return Y, L, b, Xpts, coeffs, pred_mean
+
+    # -- prediction -----------------------------------------------------------------------
+    def _cross(self, Xtest_pts):
+        """K_Xx on the device: rows = all observation blocks, columns = test points."""
+        st = self._state
+        rhs = _engine.Rhs(st.ctx, st.mat, Xtest_pts.n)
+        base = self._prior.cov
+        for bi, ob in enumerate(self._blocks):
+            # (L_obs k Ltest'^*)(X_obs, x)  == (Ltest k L_obs'^*)(x, X_obs) for the symmetric priors here
+            k = covfuncs.DifferentiatedCovarianceFunction(
+                covfuncs._base(base), *_combine(base, ob.coeffs, self._test_coeffs))
+            rhs.cross_assemble(k.lower(), ob.points, Xtest_pts, bi)
+        return rhs
+
+    def _prior_diag(self) -> float:
+        base = self._prior.cov
+        k = covfuncs.DifferentiatedCovarianceFunction(
+            covfuncs._base(base), *_combine(base, self._test_coeffs, self._test_coeffs))
+        return _engine.kernel_diag(self._state.ctx, k.lower())
+
+    def _prior_mean_at(self, x, n):
+        m = self._prior.mean
+        d = len(next(iter(self._test_coeffs)))
+        c0 = self._test_coeffs.get((0,) * d, 0.0)
+        if isinstance(m, functions.Constant):
+            return np.full(n, c0 * float(m.value))
+        if any(any(mi) for mi in self._test_coeffs):
+            raise NotImplementedError("differentiating a general prior mean needs autodiff (out of scope)")
+        return c0 * np.asarray(m(x), dtype=np.double).reshape(-1)
+
+    def predict(self, x, *, return_var: bool = True):
+        """Posterior mean and marginal variance at `x` in one pass over the factor."""
+        self._check_current()
+        X, batch = self._flat(x)
+        pts = _engine.Points(self._state.ctx, X)
+        rhs = self._cross(pts)
+        pm = self._prior_mean_at(x, X.shape[0])
+        kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None
+        mean, var = rhs.predict(pm, kxx, want_mean=True, want_var=return_var)
+        mean = mean.reshape(batch)
+        return (mean, var.reshape(batch)) if return_var else mean
+
+    def var(self, x):
+        return self.predict(x, return_var=True)[1]
+
+    def __call__(self, x) -> randvars.Normal:
+        X, batch = self._flat(x)
+        if len(batch) != 1:
+            raise ValueError("`__call__` needs inputs of shape (N,) + input_shape")
+        return randvars.Normal(self.mean(x), self.cov.matrix(x))
+
+
+def _combine(base_cov, c0: dict, c1: dict):
+    """Operator maps (arg 0, arg 1) of  L0 (base_cov) L1'^*  given the maps already on base_cov."""
+    k0, k1 = base_cov._operator_coeffs()
+    return covfuncs._compose(c0, k0), covfuncs._compose(c1, k1)
+
+
+class _PosteriorMean(functions.Function):
+    """`ConditionalGaussianProcess.Mean` (`_conditional.py:177-204`)."""
+
+    def __init__(self, cgp: ConditionalGaussianProcess):
+        super().__init__(input_shape=cgp._prior.input_shape, output_shape=())
+        self._cgp = cgp
+
+    def _evaluate(self, x):
+        return self._cgp.predict(x, return_var=False)
+
+
+class _PosteriorCovarianceFunction(covfuncs.CovarianceFunction):
+    """`ConditionalGaussianProcess.CovarianceFunction` (`_conditional.py:206-251`)."""
+
+    def __init__(self, cgp: ConditionalGaussianProcess):
+        super().__init__(cgp._prior.input_shape)
+        self._cgp = cgp
+
+    def _base_groups(self):
+        raise NotImplementedError("a posterior covariance function has no closed-form descriptor")
+
+    def matrix(self, x0, x1=None) -> np.ndarray:
+        cgp = self._cgp
+        cgp._check_current()
+        X0, b0 = cgp._flat(x0)
+        if len(b0) != 1:
+            raise ValueError("`matrix` needs inputs of shape (N,) + input_shape")
+        ctx = cgp._state.ctx
+        base = cgp._prior.cov
+        kxx_f = covfuncs.DifferentiatedCovarianceFunction(
+            covfuncs._base(base), *_combine(base, cgp._test_coeffs, cgp._test_coeffs))
+        P0 = _engine.Points(ctx, X0)
+        V0 = cgp._cross(P0)
+        V0.trsm_lower()
+        if x1 is None:
+            P1, V1 = P0, V0
+        else:
+            X1, b1 = cgp._flat(x1)
+            if len(b1) != 1:
+                raise ValueError("`matrix` needs inputs of shape (N,) + input_shape")
+            P1 = _engine.Points(ctx, X1)
+            V1 = cgp._cross(P1)
+            V1.trsm_lower()
+        k_xx = _engine.kernel_matrix(ctx, kxx_f.lower(), P0, P1)
+        return k_xx - V0.inner(V1)
+
+    def __call__(self, x0, x1=None):
+        if x1 is None:
+            return self._cgp.var(x0)
+        X0, b0 = self._cgp._flat(x0)
+        X1, b1 = self._cgp._flat(x1)
+        out_shape = np.broadcast_shapes(b0, b1)
+        K = self.matrix(X0 if self.input_ndim else X0[:, 0], X1 if self.input_ndim else X1[:, 0])
+        i0 = np.broadcast_to(np.arange(X0.shape[0]).reshape(b0), out_shape)
+        i1 = np.broadcast_to(np.arange(X1.shape[0]).reshape(b1), out_shape)
+        return K[i0, i1]
+
+
+# ---- L(posterior) read-outs (`_conditional.py:432-467`) -------------------------------------
+def apply_linfuncop_to_conditional_gp(L, cgp: ConditionalGaussianProcess) -> ConditionalGaussianProcess:
+    cgp._check_current()
+    coeffs = covfuncs._compose(L.coefficients_dict(), cgp._test_coeffs)
+    return ConditionalGaussianProcess(
+        prior=cgp._prior, blocks=cgp._blocks, state=cgp._state,
+        representer_weights=cgp._representer_weights, test_coeffs=coeffs)
+
+
+def apply_linfunctl_to_conditional_gp(L, cgp: ConditionalGaussianProcess) -> randvars.Normal:
+    view = ConditionalGaussianProcess(
+        prior=cgp._prior, blocks=cgp._blocks, state=cgp._state,
+        representer_weights=cgp._representer_weights,
+        test_coeffs=covfuncs._compose(L.coefficients_dict(), cgp._test_coeffs))
+    X = L.points()
+    x = X if cgp.input_ndim else X[:, 0]
+    return randvars.Normal(view.mean(x), view.cov.matrix(x))
+
+
+def apply_linfunctl_to_gp(L, gp: GaussianProcess) -> randvars.Normal:
+    """`L(prior)`: joint law of L[f]  (`_lintransforms.py:9-22`)."""
+    c = L.coefficients_dict()
+    k = covfuncs.DifferentiatedCovarianceFunction(covfuncs._base(gp.cov), *_combine(gp.cov, c, c))
+    X = L.points()
+    x = X if gp.input_ndim else X[:, 0]
+    mean = np.asarray(L(gp.mean), dtype=np.double).reshape(-1)
+    return randvars.Normal(mean, k.matrix(x))

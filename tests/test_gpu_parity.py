@@ -1,0 +1,262 @@
+"""HIP path vs CPU oracle on the same seeded inputs, through the C ABI / host mirror.
+
+Tolerances (fp64):
+  * Gram / cross-covariance entries:  rtol 1e-12 relative to max|block| (the reference's own
+    kernel tests use atol 1e-14 + rtol 1e-7, test_diffops.py:42)
+  * posterior mean / marginal variance: 1e-8 relative to max|.| (north_star)
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from oracle import covfuncs as ocf
+from oracle import gp as ogp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lp():
+    import linpde_gp_amd
+    return linpde_gp_amd
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _sobol_like(rng, n, d, lo=-3.0, hi=3.0):
+    return rng.uniform(lo, hi, size=(n, d))
+
+
+# ---- (1) kernel blocks -------------------------------------------------------------------
+MATERN_CASES = [(nu, a, b) for nu in (1.5, 2.5, 3.5, 4.5) for a in range(3) for b in range(3)
+                if a + b <= 2 * int(nu - 0.5)]
+
+
+@pytest.mark.parametrize("nu,a,b", MATERN_CASES)
+def test_matern_1d_blocks(lp, nu, a, b):
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(390852098 + int(10 * nu) + 3 * a + b)
+    X0 = _sobol_like(rng, 150, 1)
+    X1 = _sobol_like(rng, 77, 1)
+    ell = 0.9
+    k = cf.Matern((), nu=nu, lengthscales=ell)
+    kk = diffops.Derivative(a)(diffops.Derivative(b)(k, argnum=1), argnum=0)
+    got = kk.matrix(X0[:, 0], X1[:, 0])
+    ref = ocf.LkL([(1.0, [("matern", nu, ell)])], {(a,): 1.0}, {(b,): 1.0}, X0, X1)
+    assert _rel(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize("a,b", [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2), (2, 2), (1, 2), (2, 1)])
+def test_expquad_1d_blocks(lp, a, b):
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(4158 + 3 * a + b)
+    X0 = _sobol_like(rng, 130, 1, -1, 1)
+    X1 = _sobol_like(rng, 64, 1, -1, 1)
+    k = 4.0 * cf.ExpQuad((), lengthscales=0.25)
+    kk = diffops.Derivative(a)(diffops.Derivative(b)(k, argnum=1), argnum=0)
+    got = kk.matrix(X0[:, 0], X1[:, 0])
+    ref = ocf.LkL([(4.0, [("expquad", 0.25)])], {(a,): 1.0}, {(b,): 1.0}, X0, X1)
+    assert _rel(got, ref) < 1e-12
+
+
+def test_poisson2d_blocks(lp):
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(24)
+    X0 = _sobol_like(rng, 200, 2, -1, 1)
+    X1 = _sobol_like(rng, 131, 2, -1, 1)
+    k = 2.0**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=0.7))
+    okern = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 0.7)])]
+    D = -1.0 * diffops.Laplacian((2,))
+    lap = {(2, 0): -1.0, (0, 2): -1.0}
+    ident = ocf.identity(2)
+    assert _rel(k.matrix(X0, X1), ocf.LkL(okern, ident, ident, X0, X1)) < 1e-13
+    assert _rel(D(k, argnum=1).matrix(X0, X1), ocf.LkL(okern, ident, lap, X0, X1)) < 1e-12
+    assert _rel(D(k, argnum=0).matrix(X0, X1), ocf.LkL(okern, lap, ident, X0, X1)) < 1e-12
+    assert _rel(D(D(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, lap, lap, X0, X1)) < 1e-12
+    # symmetric (lower-only) assembly path
+    G = D(D(k, argnum=1), argnum=0).matrix(X0)
+    assert _rel(G, ocf.LkL(okern, lap, lap, X0, X0)) < 1e-12
+
+
+def test_heat_blocks(lp):
+    # cases_tensor_product.py:167-186 (heat x heat) of the reference
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(128)
+    X0 = np.column_stack([rng.uniform(0, 5, 90), rng.uniform(-1, 1, 90)])
+    X1 = np.column_stack([rng.uniform(0, 5, 70), rng.uniform(-1, 1, 70)])
+    k = cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
+    okern = [(1.0, [("matern", 1.5, 2.5), ("matern", 2.5, 2.0)])]
+    H = diffops.HeatOperator((2,), alpha=0.1)
+    heat = {(1, 0): 1.0, (0, 2): -0.1}
+    ident = ocf.identity(2)
+    assert _rel(H(H(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, heat, heat, X0, X1)) < 1e-12
+    assert _rel(H(k, argnum=0).matrix(X0, X1), ocf.LkL(okern, heat, ident, X0, X1)) < 1e-12
+    dd = diffops.DirectionalDerivative([0.3, -1.2])
+    ddc = {(1, 0): 0.3, (0, 1): -1.2}
+    assert _rel(dd(H(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, ddc, heat, X0, X1)) < 1e-12
+
+
+def test_sum_kernel_and_3d(lp):
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(5)
+    X0 = rng.normal(size=(70, 3))
+    X1 = rng.normal(size=(65, 3))
+    k1 = 1.5 * cf.ExpQuad((3,), lengthscales=[0.4, 1.3, 0.9])
+    k2 = 0.5 * cf.TensorProduct(*(cf.Matern((), nu=2.5, lengthscales=l) for l in (1.0, 2.0, 0.5)))
+    k = k1 + k2
+    okern = [(1.5, [("expquad", 0.4), ("expquad", 1.3), ("expquad", 0.9)]),
+             (0.5, [("matern", 2.5, 1.0), ("matern", 2.5, 2.0), ("matern", 2.5, 0.5)])]
+    L = diffops.Laplacian((3,))
+    lap = {(2, 0, 0): 1.0, (0, 2, 0): 1.0, (0, 0, 2): 1.0}
+    assert _rel(L(L(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, lap, lap, X0, X1)) < 1e-12
+
+
+# ---- (2) factor + solve --------------------------------------------------------------------
+def _poisson_blocks(nb, npde, rhs=2.0, noise=1e-8):
+    """Small version of BASELINE config c3."""
+    g = np.linspace(-1, 1, npde)
+    Xp = np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)
+    e = np.linspace(-1 + 1e-6, 1 - 1e-6, nb)
+    edges = [np.column_stack([np.full(nb, -1.0), e]), np.column_stack([np.full(nb, 1.0), e]),
+             np.column_stack([e, np.full(nb, -1.0)]), np.column_stack([e, np.full(nb, 1.0)])]
+    ident = ocf.identity(2)
+    lap = {(2, 0): -1.0, (0, 2): -1.0}
+    blocks = [ogp.ObsBlock(X, ident, np.zeros(nb), 0.0, noise) for X in edges]
+    blocks.append(ogp.ObsBlock(Xp, lap, np.full(Xp.shape[0], rhs)))
+    return blocks
+
+
+def _condition_host(lp, prior, blocks):
+    from linpde_gp_amd.linfuncops import diffops
+    u = prior
+    for b in blocks:
+        n = b.n
+        noise = None if b.noise_cov is None else lp.randvars.Normal(np.zeros(n), b.noise_cov * np.eye(n))
+        if set(b.L) == {(0, 0)}:
+            u = u.condition_on_observations(b.Y, X=b.X, b=noise)
+        else:
+            u = u.condition_on_observations(b.Y, X=b.X, L=-1.0 * diffops.Laplacian((2,)), b=noise)
+    return u
+
+
+def test_poisson2d_posterior_small(lp):
+    cf = lp.randprocs.covfuncs
+    blocks = _poisson_blocks(nb=24, npde=20)       # 4*24 + 400 = 496 observations, ragged vs 128
+    okern = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
+    prior = lp.GaussianProcess(
+        lp.functions.Zero((2,)),
+        2.0**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=1.0)))
+    u = _condition_host(lp, prior, blocks)
+    post = ogp.condition(okern, blocks)
+    t = np.linspace(-1 + 1 / 16, 1 - 1 / 16, 16)
+    Xt = np.stack(np.meshgrid(t, t, indexing="ij"), axis=-1).reshape(-1, 2)
+    mean, var = u.predict(Xt)
+    assert _rel(mean, post.mean(Xt)) < 1e-8
+    ref_var = post.var(Xt)
+    assert np.max(np.abs(var - ref_var)) / np.max(np.abs(ref_var)) < 1e-8
+    # factor against LAPACK: two backward-stable factorisations of a Gram matrix with
+    # cond ~ 1e10 (boundary nugget 1e-8) agree to cond*eps in the factor, and exactly
+    # (to rounding) in the product L L^T
+    Lf = u.gram.cholesky(True)
+    assert _rel(Lf, post.chol) < 1e-5
+    np.testing.assert_allclose(u.gram.todense(), post.G, rtol=0, atol=1e-12 * np.max(np.abs(post.G)))
+    # analytic solution of -Lap u = 2 with zero boundary is not polynomial; sanity only: u > 0 inside
+    assert mean.min() > 0.0
+
+
+def test_iterative_equals_oneshot_and_linop_readout(lp):
+    """Reference `tests/linpde_gp/randprocs/test_posterior_gp.py:152-178`: 4 batches (2,3,2,4),
+    two with Normal noise, prior 4*ExpQuad(l=0.25); also the Laplacian read-out."""
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), 2.0**2 * cf.ExpQuad((1,), lengthscales=0.25))
+    okern = [(4.0, [("expquad", 0.25)])]
+    sizes = (2, 3, 2, 4)
+    Xs = np.linspace(-1.0, 1.0, sum(sizes))[:, None]
+    Ys = 2.0 * np.sin(np.pi * Xs[:, 0])
+    Xb = np.array_split(Xs, np.cumsum(sizes)[:-1])
+    Yb = np.array_split(Ys, np.cumsum(sizes)[:-1])
+    noise = [(np.ones(2), 0.6**2), None, None, (np.zeros(4), 0.3**2)]
+    u = prior
+    oblocks = []
+    for X, Y, nz in zip(Xb, Yb, noise):
+        b = None if nz is None else lp.randvars.Normal(nz[0], nz[1] * np.eye(len(Y)))
+        u = u.condition_on_observations(Y, X, b=b)
+        oblocks.append(ogp.ObsBlock(X, ocf.identity(1), Y, None if nz is None else nz[0],
+                                    None if nz is None else nz[1]))
+    post = ogp.condition(okern, oblocks)
+    post_it = ogp.condition_iteratively(okern, oblocks)
+    Xt = np.linspace(-1.0, 1.0, 50)[:, None]
+    rv = u(Xt)
+    np.testing.assert_allclose(rv.mean, post.mean(Xt), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(rv.cov, post.cov(Xt), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(rv.var, post.var(Xt), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(post_it.mean(Xt), post.mean(Xt), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(u.representer_weights, post.weights, rtol=1e-7, atol=1e-9)
+    # Laplacian of the posterior (`test_posterior_gp_linop`)
+    Lu = diffops.Laplacian((1,))(u)
+    lap = {(2,): 1.0}
+    rvL = Lu(Xt)
+    np.testing.assert_allclose(rvL.mean, post.mean(Xt, lap), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(rvL.cov, post.cov(Xt, Ltest=lap), rtol=1e-7, atol=1e-6)
+
+
+def test_potrs_multiple_rhs_and_dense_noise(lp):
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(0)
+    X = np.sort(rng.uniform(-1, 1, 300))[:, None]
+    Y = np.sin(3 * X[:, 0])
+    A = rng.normal(size=(300, 300))
+    noise_cov = 0.05 * (A @ A.T) / 300 + 0.01 * np.eye(300)
+    prior = lp.GaussianProcess(lp.functions.Constant((1,), 0.5), 1.3 * cf.Matern((1,), nu=1.5, lengthscales=0.5))
+    u = prior.condition_on_observations(Y, X, b=lp.randvars.Normal(np.zeros(300), noise_cov))
+    okern = [(1.3, [("matern", 1.5, 0.5)])]
+    post = ogp.condition(okern, [ogp.ObsBlock(X, ocf.identity(1), Y, None, noise_cov)], mean_const=0.5)
+    B = rng.normal(size=(300, 5))
+    np.testing.assert_allclose(u.gram.solve(B), np.linalg.solve(post.G, B), rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(u.gram.solve(B[:, 0]), np.linalg.solve(post.G, B[:, 0]), rtol=1e-8, atol=1e-8)
+    Xt = np.linspace(-1, 1, 33)[:, None]
+    m, v = u.predict(Xt)
+    assert _rel(m, post.mean(Xt)) < 1e-9 and _rel(v, post.var(Xt)) < 1e-9
+
+
+def test_not_positive_definite_raises(lp):
+    cf = lp.randprocs.covfuncs
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    X = np.array([[0.0], [0.0], [0.5]])             # duplicated point, no noise => singular Gram
+    with pytest.raises(np.linalg.LinAlgError):
+        prior.condition_on_observations(np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+
+
+def test_superseded_object_raises(lp):
+    cf = lp.randprocs.covfuncs
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=0.5))
+    u1 = prior.condition_on_observations(np.zeros(2), np.array([[0.0], [1.0]]))
+    u2 = u1.condition_on_observations(np.ones(2), np.array([[0.3], [0.6]]))
+    assert u2.mean(np.array([[0.3]])).shape == (1,)
+    with pytest.raises(RuntimeError):
+        u1.mean(np.array([[0.3]]))
+
+
+def test_api_errors(lp):
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.Matern((1,), nu=2.5))
+    with pytest.raises(ValueError):
+        prior.condition_on_observations(np.zeros(3))                      # X and L omitted
+    with pytest.raises(ValueError):
+        prior.condition_on_observations(np.zeros(3), L=diffops.Laplacian((1,)))   # operator without X
+    with pytest.raises(ValueError):
+        prior.condition_on_observations(np.zeros(4), np.zeros((3, 1)))    # Y shape
+    with pytest.raises(ValueError):
+        prior.condition_on_observations(np.zeros(3), np.zeros((3, 1)), b=lp.randvars.Normal(np.zeros(2), np.eye(2)))
+    L = diffops.Laplacian((1,)).to_linfunctl(np.zeros((3, 1)))
+    with pytest.raises(TypeError):
+        prior.condition_on_observations(np.zeros(3), np.zeros((3, 1)), L=L)   # functional + X
