@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- condition + predict on the BASELINE workload (c3: 2-D Poisson-Dirichlet,
+N = 16 384 collocation + 4 x 128 boundary observations, M = 64 x 64 prediction points).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the synthetic workload: block-by-block
+conditioning (Gram/cross-block assembly, blocked Cholesky with block append, representer
+weights) + prediction (cross-covariance assembly, posterior mean, marginal variance).
+Point sets are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+N > 1 (launched by `python -m torch.distributed.run`, env RANK/LOCAL_RANK/WORLD_SIZE/
+MASTER_ADDR/MASTER_PORT): one process per GPU.  This round every rank conditions its own
+independent c3 problem ("scaling": "weak"; no data-path collective) -- see DESIGN.md §7.
+The product path never imports torch; ranks rendezvous over a plain TCP star.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd"))
+
+import numpy as np  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor datasheet)
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(problems, n_side):
+    """Oracle (NumPy/SciPy restatement of the reference path) on a bounded sample."""
+    from oracle import workloads as owl
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        threads = max((p.get("num_threads", 1) for p in pools), default=os.cpu_count() or 1)
+        blas = ",".join(sorted({f"{p.get('internal_api')}-{p.get('version')}" for p in pools}))
+    except Exception:  # pragma: no cover
+        threads, blas = os.cpu_count() or 1, "unknown"
+    wl = problems.poisson_2d(n_side=n_side, m_side=32)
+    res = owl.run(wl)
+    sec = res["seconds"]
+    return {
+        "value": wl.total_flops() / sec["total"] / 1e9,
+        "unit": "GFLOP/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": (f"same workload at {n_side}x{n_side} collocation + 4x{n_side} boundary obs "
+                   f"(N_tot={wl.n_total}), M=32x32; NumPy/SciPy oracle, BLAS={blas}; "
+                   f"{sec['total']:.2f} s total: " + ", ".join(f"{k} {v:.2f}" for k, v in sec.items() if k != 'total')),
+        "seconds": sec["total"],
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-side", type=int, default=128, help="collocation grid side (c3: 128)")
+    ap.add_argument("--m-side", type=int, default=64, help="prediction grid side (c3: 64)")
+    ap.add_argument("--cpu-side", type=int, default=72, help="grid side of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also compare with the CPU oracle at full size")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _dist, _engine, problems
+
+    comm = _dist.Comm.from_env()
+    ctx = _engine.default_context()          # device = LOCAL_RANK
+    info = ctx.device_info()
+
+    wl = problems.poisson_2d(n_side=args.n_side, m_side=args.m_side)
+    lp.config.gram_capacity_hint = wl.n_total
+    dev = problems.upload(wl)                # point sets resident in HBM before timing
+    prior = problems.build_prior(wl)
+
+    def step():
+        u, mean, var = problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
+        return mean, var
+
+    for _ in range(args.warmup):
+        mean, var = step()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    comm.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mean, var = step()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    dt = comm.allreduce_max(dt)
+    comm.barrier()
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+
+    if rank != 0:
+        comm.close()
+        return
+    ms_per_step = dt / args.steps * 1e3
+    flops = wl.total_flops()
+    value = world * flops / (dt / args.steps) / 1e9
+
+    syrk = prof["syrk_trailing"]
+    asm = prof["assemble"]
+    achieved = syrk["flops"] / (syrk["ms"] * 1e-3) / 1e12 if syrk["ms"] > 0 else 0.0
+    out = {
+        "metric": "condition+predict fp64 GFLOP/s (algorithmic), N=16384 Poisson-2D",
+        "value": value,
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": wl.name,
+            "n_collocation": args.n_side**2,
+            "n_boundary": 4 * args.n_side,
+            "n_total": wl.n_total,
+            "m_predict": int(wl.Xtest.shape[0]),
+            "boundary_noise_var": 1e-8,
+            "algorithmic_flops_per_step": flops,
+            "multi_gpu": "independent replicas (one c3 problem per GPU)" if world > 1 else "single GPU",
+            "device": info["name"].strip(),
+        },
+        "roofline": {
+            "kernel": "gemm_f64_kernel<NT> (rank-nb SYRK trailing update of the blocked Cholesky)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_per_step": syrk["launches"] / max(args.steps, 1),
+            "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
+        },
+        "kernels": {
+            name: {
+                "ms_per_step": p["ms"] / args.steps,
+                "launches_per_step": p["launches"] / args.steps,
+                **({"tflops": p["flops"] / (p["ms"] * 1e-3) / 1e12} if p["flops"] > 0 and p["ms"] > 0 else {}),
+                **({"gbps": p["bytes"] / (p["ms"] * 1e-3) / 1e9} if p["bytes"] > 0 and p["ms"] > 0 else {}),
+            }
+            for name, p in prof.items()
+        },
+        "posterior": {"mean_max": float(np.max(mean)), "var_min": float(np.min(var)), "var_max": float(np.max(var))},
+    }
+    if asm["ms"] > 0:
+        out["roofline_assembly"] = {
+            "kernel": "assemble_kernel<2>", "bound": "hbm",
+            "achieved": asm["bytes"] / (asm["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": asm["bytes"] / (asm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "lower triangle only for diagonal blocks: 4 N(N+1) bytes",
+        }
+    if not args.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline(problems, args.cpu_side)
+    if args.check:
+        from oracle import workloads as owl
+        ref = owl.run(wl)
+        out["parity"] = {
+            "mean_rel_err": float(np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))),
+            "var_rel_err": float(np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))),
+            "cpu_seconds_full": ref["seconds"],
+        }
+    print(json.dumps(out))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

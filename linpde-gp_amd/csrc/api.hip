@@ -116,6 +116,53 @@ __global__ __launch_bounds__(256) void write_probe_kernel(double* out, int64_t n
     reinterpret_cast<double2*>(out)[i] = make_double2((double)i, 1.0);
 }
 
+int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh) {
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+    const auto& b = ctx->pool[i];
+    if (b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (1 << 20) && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = i;
+  }
+  if (best >= 0) {
+    *out = ctx->pool[best].p;
+    ctx->pool.erase(ctx->pool.begin() + best);
+    if (fresh) *fresh = false;
+    return 0;
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    // release cached buffers and retry once
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) {
+    set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return -1;
+  }
+  if (fresh) *fresh = true;
+  return 0;
+}
+
+void pool_free(lpgp_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (ctx->pool.size() >= 12) {
+    // drop the smallest cached buffer
+    int sm = 0;
+    for (int i = 1; i < (int)ctx->pool.size(); ++i)
+      if (ctx->pool[i].bytes < ctx->pool[sm].bytes) sm = i;
+    (void)hipFree(ctx->pool[sm].p);
+    ctx->pool.erase(ctx->pool.begin() + sm);
+  }
+  ctx->pool.push_back({p, bytes});
+}
+
+__global__ void clear_rows_kernel(double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc) {
+  // zero the strip rows [r0, r0+nr) x cols [c0, c0+nc)
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t c = blockIdx.y;
+  if (i < nr && c < nc) a[(r0 + i) + (c0 + c) * ld] = 0.0;
+}
+
 static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
   if (n <= ctx->tmp_cap) return 0;
   if (ctx->d_tmp) LPGP_HIP(hipFree(ctx->d_tmp));
@@ -126,17 +173,27 @@ static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
   return 0;
 }
 
+static size_t mat_bytes_a(int64_t cap) { return (size_t)cap * cap * sizeof(double); }
+static size_t mat_bytes_l(int64_t cap) { return (size_t)cap * TILE * sizeof(double); }
+static size_t mat_bytes_w(int64_t cap) { return (size_t)cap * sizeof(double); }
+
+static void mat_release(lpgp_ctx* ctx, lpgp_mat* mat) {
+  pool_free(ctx, mat->a, mat_bytes_a(mat->cap));
+  pool_free(ctx, mat->linv, mat_bytes_l(mat->cap));
+  pool_free(ctx, mat->w, mat_bytes_w(mat->cap));
+  mat->a = mat->linv = mat->w = nullptr;
+}
+
 static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
-  // (re)allocate to `cap` (multiple of TILE) keeping the content of the first mat->pn rows/cols
-  double *na = nullptr, *nl = nullptr, *nw = nullptr;
-  LPGP_HIP(hipMalloc(&na, (size_t)cap * cap * sizeof(double)));
-  LPGP_HIP(hipMalloc(&nl, (size_t)cap * TILE * sizeof(double)));
-  LPGP_HIP(hipMalloc(&nw, (size_t)cap * sizeof(double)));
-  LPGP_HIP(hipMemsetAsync(na, 0, (size_t)cap * cap * sizeof(double), ctx->s_main));
-  LPGP_HIP(hipMemsetAsync(nl, 0, (size_t)cap * TILE * sizeof(double), ctx->s_main));
-  LPGP_HIP(hipMemsetAsync(nw, 0, (size_t)cap * sizeof(double), ctx->s_main));
-  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, ctx->s_main, na, cap,
-                     (int64_t)0, cap);
+  // (re)allocate to `cap` (multiple of TILE) keeping the content of the first mat->pn rows/cols.
+  // Invariant kept for every buffer handed out: nothing is assumed about the lower triangle
+  // of logical blocks (assembly overwrites it) nor about tiles above the diagonal (never
+  // read); the padding strips of a block are cleared in lpgp_mat_add_block.
+  void *na = nullptr, *nl = nullptr, *nw = nullptr;
+  int rc = pool_alloc(ctx, &na, mat_bytes_a(cap), nullptr);
+  if (rc == 0) rc = pool_alloc(ctx, &nl, mat_bytes_l(cap), nullptr);
+  if (rc == 0) rc = pool_alloc(ctx, &nw, mat_bytes_w(cap), nullptr);
+  if (rc != 0) return rc;
   if (mat->a && mat->pn > 0) {
     LPGP_HIP(hipMemcpy2DAsync(na, (size_t)cap * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
                               (size_t)mat->pn * sizeof(double), (size_t)mat->pn, hipMemcpyDeviceToDevice,
@@ -144,14 +201,21 @@ static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
     LPGP_HIP(hipMemcpyAsync(nl, mat->linv, (size_t)mat->pn * TILE * sizeof(double), hipMemcpyDeviceToDevice,
                             ctx->s_main));
     LPGP_HIP(hipMemcpyAsync(nw, mat->w, (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+    // padding columns of the existing blocks must stay zero in the rows added by the growth
+    for (const auto& b : mat->blocks) {
+      const int64_t padc = b.pn - b.n;
+      if (padc > 0) {
+        const int64_t r0 = mat->pn, nr = cap - mat->pn;
+        hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((nr + 255) / 256), (unsigned)padc), dim3(256), 0,
+                           ctx->s_main, (double*)na, cap, r0, nr, b.poff + b.n, padc);
+      }
+    }
   }
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
-  if (mat->a) (void)hipFree(mat->a);
-  if (mat->linv) (void)hipFree(mat->linv);
-  if (mat->w) (void)hipFree(mat->w);
-  mat->a = na;
-  mat->linv = nl;
-  mat->w = nw;
+  if (mat->a) mat_release(ctx, mat);
+  mat->a = (double*)na;
+  mat->linv = (double*)nl;
+  mat->w = (double*)nw;
   mat->cap = cap;
   return 0;
 }
@@ -188,7 +252,26 @@ int lpgp_init(int device, lpgp_ctx** out) {
   int lo = 0, hi = 0;
   LPGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_main, hipStreamNonBlocking, hi));
-  LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd, hipStreamNonBlocking, lo));
+  // The trailing-update stream may use all CUs except a few reserved ones, so that the
+  // panel kernels of the look-ahead (a 156-KB-LDS tile Cholesky needs a whole CU) never queue
+  // behind thousands of resident update workgroups.  LPGP_RESERVE_CUS=0 disables the mask.
+  int reserve = 8;
+  if (const char* e = std::getenv("LPGP_RESERVE_CUS")) reserve = std::atoi(e);
+  ctx->s_upd = nullptr;
+  if (reserve > 0 && reserve < ctx->cus) {
+    const int words = (ctx->cus + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    // mask bit i = CU (i / 8) of XCD (i % 8) (measured, scratch/cumask.hip): clearing the low
+    // `reserve` bits takes the CUs round-robin from the XCDs, one per XCD for reserve == 8,
+    // so a single workgroup of the panel stream finds a free CU on whichever XCD it is dealt to
+    for (int cu = 0; cu < ctx->cus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+    for (int r = 0; r < reserve; ++r) mask[r / 32] &= ~(1u << (r % 32));
+    if (hipExtStreamCreateWithCUMask(&ctx->s_upd, (uint32_t)words, mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->s_upd = nullptr;
+    }
+  }
+  if (!ctx->s_upd) LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd, hipStreamNonBlocking, lo));
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
@@ -220,6 +303,8 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipFree(ctx->d_desc);
   (void)hipFree(ctx->d_info);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  for (auto& b : ctx->pool) (void)hipFree(b.p);
+  ctx->pool.clear();
   (void)hipStreamDestroy(ctx->s_main);
   (void)hipStreamDestroy(ctx->s_upd);
   delete ctx;
@@ -301,9 +386,7 @@ int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
 
 int lpgp_mat_destroy(lpgp_mat* m) {
   if (!m) return 0;
-  (void)hipFree(m->a);
-  (void)hipFree(m->linv);
-  (void)hipFree(m->w);
+  mat_release(m->ctx, m);
   delete m;
   return 0;
 }
@@ -318,6 +401,20 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   if (b.poff + b.pn > mat->cap) {
     int rc = mat_alloc(ctx, mat, b.poff + b.pn);
     if (rc != 0) return rc;
+  }
+  const int64_t pad = b.pn - b.n;
+  if (pad > 0) {
+    // identity tail of the block: zero the pad rows (all columns up to the block end) and the
+    // pad columns (all rows down to the capacity), then ones on the diagonal
+    const int64_t r0 = b.poff + b.n;
+    hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((pad + 255) / 256), (unsigned)(b.poff + b.pn)), dim3(256),
+                       0, ctx->s_main, mat->a, mat->cap, r0, pad, (int64_t)0, b.poff + b.pn);
+    const int64_t nr = mat->cap - r0;
+    hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((nr + 255) / 256), (unsigned)pad), dim3(256), 0,
+                       ctx->s_main, mat->a, mat->cap, r0, nr, r0, pad);
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, ctx->s_main, mat->a,
+                       mat->cap, r0, r0 + pad);
+    LPGP_HIP(hipGetLastError());
   }
   mat->blocks.push_back(b);
   mat->n += n;
@@ -449,27 +546,15 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
   LPGP_CHECK(ctx && mat && r_host, "lpgp_solve_weights: null argument");
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_solve_weights: matrix is not factored");
   const int64_t pn = mat->pn;
-  double* dv = nullptr;
-  LPGP_HIP(hipMalloc(&dv, (size_t)pn * TILE * sizeof(double)));
+  int rc = ensure_tmp(ctx, pn);
+  if (rc != 0) return rc;
   std::vector<double> hp((size_t)pn);
   scatter_padded(mat, r_host, hp.data());
-  int rc = 0;
-  do {
-    if (hipMemsetAsync(dv, 0, (size_t)pn * TILE * sizeof(double), ctx->s_main) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(dv, hp.data(), (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    rc = trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, TILE);
-    if (rc) break;
-    rc = trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, TILE);
-    if (rc) break;
-    if (hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(hp.data(), dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
-  } while (0);
-  (void)hipFree(dv);
-  if (rc != 0) {
-    if (rc == -1) set_error("lpgp_solve_weights: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
-    return rc;
-  }
+  LPGP_HIP(hipMemcpyAsync(mat->w, hp.data(), (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+  rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);
+  if (rc != 0) return rc;
+  LPGP_HIP(hipMemcpyAsync(hp.data(), mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   mat->has_w = 1;
   if (w_host) gather_padded(mat, hp.data(), w_host);
   return 0;
@@ -484,11 +569,12 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
   r->m = m;
   r->m_pad = round_up(m, TILE);
   r->v = nullptr;
-  if (hipMalloc(&r->v, (size_t)r->ld * r->m_pad * sizeof(double)) != hipSuccess) {
+  void* pv = nullptr;
+  if (pool_alloc(ctx, &pv, (size_t)r->ld * r->m_pad * sizeof(double), nullptr) != 0) {
     delete r;
-    set_error("lpgp_rhs_create: hipMalloc of %lld x %lld failed", (long long)mat->pn, (long long)r->m_pad);
     return -1;
   }
+  r->v = (double*)pv;
   LPGP_HIP(hipMemsetAsync(r->v, 0, (size_t)r->ld * r->m_pad * sizeof(double), ctx->s_main));
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   *out = r;
@@ -497,7 +583,7 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
 
 int lpgp_rhs_destroy(lpgp_rhs* r) {
   if (!r) return 0;
-  (void)hipFree(r->v);
+  pool_free(r->ctx, r->v, (size_t)r->ld * r->m_pad * sizeof(double));
   delete r;
   return 0;
 }

@@ -24,48 +24,38 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDM = 144;                 // [k][LDM] image (LDM % 32 == 16)
-constexpr int LDK = 18;                  // [idx][LDK] image
-constexpr int STAGE = BK * LDM;          // doubles per operand per stage (== 128*LDK)
-static_assert(BK * LDM == BM * LDK, "both LDS images have the same size");
+constexpr int STAGE = BK * LDM;          // doubles per operand per stage (K image uses 128*16 of it)
+
+// ---- staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4) -------------------------
+// One wave-instruction moves 64 x 16 B = 1 KiB to a wave-uniform LDS base + lane*16.
+//  * operand with its non-contracted index fastest in memory ("M image"): LDS image
+//    [k][LDM]; one piece = one k-row of 128 doubles (the row padding LDM-128 is never
+//    crossed by a piece);
+//  * k-fastest operand ("K image"): LDS image [idx][16] without padding; one piece = 8 rows
+//    of 128 B.  Bank conflicts are avoided by an XOR swizzle of the 16-byte chunks,
+//    chunk' = chunk ^ ((idx >> 1) & 7), applied on the per-lane SOURCE address (the LDS
+//    side of a DMA is always linear) and again on every fragment read.
+// Measured reason for DMA instead of register staging: a stage's global loads have
+// ~3000 cycles of latency under load and hipcc sinks register loads next to their ds_write
+// (exposing that latency every stage); DMA writes LDS, so it cannot be moved below the
+// stage's first ds_read and stays at the top of the stage.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <bool T>
-__device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t ld, int64_t idx0,
-                                          int64_t k0, int tid, v2f64 (&reg)[4]) {
-  // tile: 128 (idx) x 16 (k)
-  if constexpr (!T) {
-    // idx fastest in memory: element (idx,k) at P[idx + k*ld]
+__device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0,
+                                         int lane, int w, double* sdst) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = q * 4 + (tid >> 6);
-      const int i = (tid & 63) * 2;
-      reg[q] = *reinterpret_cast<const v2f64*>(P + (idx0 + i) + (k0 + k) * ld);
-    }
-  } else {
-    // k fastest in memory: element (idx,k) at P[k + idx*ld]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = q * 32 + (tid >> 3);
-      const int k = (tid & 7) * 2;
-      reg[q] = *reinterpret_cast<const v2f64*>(P + (k0 + k) + (idx0 + i) * ld);
-    }
-  }
-}
-
-template <bool T>
-__device__ __forceinline__ void store_tile(double* __restrict__ s, int tid, const v2f64 (&reg)[4]) {
-  if constexpr (!T) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = q * 4 + (tid >> 6);
-      const int i = (tid & 63) * 2;
-      *reinterpret_cast<v2f64*>(s + k * LDM + i) = reg[q];
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = q * 32 + (tid >> 3);
-      const int k = (tid & 7) * 2;
-      *reinterpret_cast<v2f64*>(s + i * LDK + k) = reg[q];
+  for (int q = 0; q < 4; ++q) {
+    const int piece = q * 4 + w;                         // wave-uniform
+    if constexpr (!T) {
+      const double* src = P + (idx0 + 2 * lane) + (k0 + piece) * ld;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sdst + piece * LDM), 16, 0, 0);
+    } else {
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const double* src = P + (k0 + 2 * c) + (idx0 + r) * ld;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sdst + piece * 128), 16, 0, 0);
     }
   }
 }
@@ -73,10 +63,35 @@ __device__ __forceinline__ void store_tile(double* __restrict__ s, int tid, cons
 template <bool T>
 __device__ __forceinline__ double read_frag(const double* __restrict__ s, int idx_base, int ks, int lane) {
   // fragment element: idx = idx_base + (lane & 15), k = ks*4 + (lane >> 4)
-  if constexpr (!T) return s[(ks * 4 + (lane >> 4)) * LDM + idx_base + (lane & 15)];
-  else              return s[(idx_base + (lane & 15)) * LDK + ks * 4 + (lane >> 4)];
+  const int k = ks * 4 + (lane >> 4);
+  if constexpr (!T) return s[k * LDM + idx_base + (lane & 15)];
+  else {
+    const int idx = idx_base + (lane & 15);
+    return s[idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1)];
+  }
 }
 
+// 4-wide fragment replicated over the four lane blocks: idx = idx_base + (lane & 3),
+// k = ks*4 + (lane >> 4); lanes that differ only in bits 2..3 read the same address (LDS
+// broadcast).  This is the "A" operand of v_mfma_f64_4x4x4_4b_f64 with one 4x4 block
+// shared by all four blocks of the instruction.
+template <bool T>
+__device__ __forceinline__ double read_frag4(const double* __restrict__ s, int idx_base, int ks, int lane) {
+  const int k = ks * 4 + (lane >> 4);
+  if constexpr (!T) return s[k * LDM + idx_base + (lane & 3)];
+  else {
+    const int idx = idx_base + (lane & 3);
+    return s[idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1)];
+  }
+}
+
+// MFMA shape: measured on MI355X, v_mfma_f64_16x16x4_f64 sustains only ~48 TFLOP/s chip-wide
+// (>= 88 cycles per instruction per SIMD at any occupancy) while v_mfma_f64_4x4x4_4b_f64
+// issues every 16.5 cycles = 75 TFLOP/s already at one wave per SIMD (scratch/mfma_probe.hip,
+// DESIGN.md section 5).  The 64x64 wave tile is therefore built from 4x4x4_4b instructions:
+// per k-step of 4, acc[t][u] (m = 16t + (lane&15), n = 4u + (lane>>4)) += Bfrag4[u] x Afrag[t],
+// where the instruction's four 4x4 blocks share the 4 n-columns (replicated "A" operand) and
+// cover 16 consecutive rows m ("B" operand) -- the same 128-byte-segment C layout as before.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -117,79 +132,118 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   double* sA = smem;                  // 2 stages
   double* sB = smem + 2 * STAGE;
 
-  v4f64 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-
   const int KT = g.k / BK;
-  v2f64 ra[4], rb[4];
-  load_tile<TA>(g.A, g.lda, m0, 0, tid, ra);
-  load_tile<TB>(g.B, g.ldb, n0, 0, tid, rb);
-  store_tile<TA>(sA, tid, ra);
-  store_tile<TB>(sB, tid, rb);
+  const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar (LDS-DMA base must be uniform)
+  dma_tile<TA>(g.A, g.lda, m0, 0, lane, wu, sA);
+  dma_tile<TB>(g.B, g.ldb, n0, 0, lane, wu, sB);
+
+  // The accumulators start from (beta/alpha) * C, so that the epilogue is stores only: the 64
+  // C loads per lane are all in flight at once, under the first tile's DMA latency, instead
+  // of 16 dependent load->fma->store round trips at the end of every tile (measured: ~33 us
+  // of a 165 us tile at K = 512).
+  const double alpha = g.alpha, beta = g.beta;
+  double* const cbase = g.C + (n0 + wn * 64 + (lane >> 4)) * g.ldc + m0 + wm * 64 + (lane & 15);
+  double acc[4][16];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][u] = sc * cbase[(int64_t)(4 * u) * g.ldc + t * 16];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[t][u] = 0.0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+#ifdef LPGP_STAMP
+  unsigned long long st_load = 0, st_mfma = 0, st_store = 0, st_bar = 0, t_a, t_b;
+#define STAMP(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
   int cur = 0;
   for (int kt = 0; kt < KT; ++kt) {
     const bool more = (kt + 1 < KT);
-    if (more) {
-      load_tile<TA>(g.A, g.lda, m0, (int64_t)(kt + 1) * BK, tid, ra);
-      load_tile<TB>(g.B, g.ldb, n0, (int64_t)(kt + 1) * BK, tid, rb);
+#ifdef LPGP_STAMP
+    STAMP(t_a);
+#endif
+    // next stage's tiles -> other LDS buffer (unconditional: the last stage harmlessly
+    // re-loads its own k-tile; a branch around the DMA would make hipcc drain vmcnt early)
+#ifdef LPGP_EXPERIMENT
+    if (!(g.ktrim & 1))
+#endif
+    {
+      const int64_t knext = (int64_t)(more ? kt + 1 : kt) * BK;
+      dma_tile<TA>(g.A, g.lda, m0, knext, lane, wu, sA + (cur ^ 1) * STAGE);
+      dma_tile<TB>(g.B, g.ldb, n0, knext, lane, wu, sB + (cur ^ 1) * STAGE);
     }
     const double* cA = sA + cur * STAGE;
     const double* cB = sB + cur * STAGE;
-    double fa[2][4], fb[2][4];
+    // 16 chunks of 16 MFMAs per stage (4 k-steps x 4 groups of 4 n-fragments).  Fragments
+    // are double-buffered in registers: the LDS reads of chunk c+1 are issued before the
+    // MFMAs of chunk c (264 cycles of matrix work cover the LDS latency); sched_barriers
+    // keep hipcc from sinking the reads back to their first use.
+#ifdef LPGP_STAMP
+    STAMP(t_b); st_load += t_b - t_a; t_a = t_b;
+#endif
+    double am[2][4], bn[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[0][i] = read_frag<TA>(cA, wm * 64 + i * 16, 0, lane);
-      fb[0][i] = read_frag<TB>(cB, wn * 64 + i * 16, 0, lane);
-    }
+    for (int t = 0; t < 4; ++t) am[0][t] = read_frag<TA>(cA, wm * 64 + t * 16, 0, lane);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks & 1, nx = c ^ 1;
-      if (ks < 3) {
+    for (int v = 0; v < 4; ++v) bn[0][v] = read_frag4<TB>(cB, wn * 64 + v * 4, 0, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          fa[nx][i] = read_frag<TA>(cA, wm * 64 + i * 16, ks + 1, lane);
-          fb[nx][i] = read_frag<TB>(cB, wn * 64 + i * 16, ks + 1, lane);
+    for (int c = 0; c < 16; ++c) {
+      const int ks = c >> 2, uc = c & 3, cb = c & 1;
+      if (c + 1 < 16) {
+        const int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bn[cb ^ 1][v] = read_frag4<TB>(cB, wn * 64 + (uc2 * 4 + v) * 4, ks2, lane);
+        if (uc2 == 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) am[ks2 & 1][t] = read_frag<TA>(cA, wm * 64 + t * 16, ks2, lane);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[t][uc * 4 + v] =
+              __builtin_amdgcn_mfma_f64_4x4x4f64(bn[cb][v], am[ks & 1][t], acc[t][uc * 4 + v], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      store_tile<TA>(sA + (cur ^ 1) * STAGE, tid, ra);
-      store_tile<TB>(sB + (cur ^ 1) * STAGE, tid, rb);
-    }
+#ifdef LPGP_STAMP
+    STAMP(t_b); st_mfma += t_b - t_a; t_a = t_b;
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+#ifdef LPGP_STAMP
+    STAMP(t_b); st_store += t_b - t_a; t_a = t_b;
+#endif
+#ifdef LPGP_EXPERIMENT
+    if (!(g.ktrim & 2))
+#endif
     __syncthreads();
+#ifdef LPGP_STAMP
+    STAMP(t_b); st_bar += t_b - t_a;
+#endif
     cur ^= 1;
   }
-
-  // ---- epilogue: lane holds C[m = l&15][n = (l>>4) + 4r] of each 16x16 sub-tile ----
-  const double alpha = g.alpha, beta = g.beta;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) + 4 * r;
-      double* col = g.C + n * g.ldc + m0 + wm * 64 + (lane & 15);
-      if (beta == 0.0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) col[i * 16] = alpha * acc[i][j][r];
-      } else {
-        double old[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) old[i] = col[i * 16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) col[i * 16] = fma(alpha, acc[i][j][r], beta * old[i]);
-      }
-    }
+#ifdef LPGP_STAMP
+  if (g.stamps && tid == 0) {
+    unsigned long long* o = g.stamps + 4 * (size_t)blockIdx.x;
+    o[0] = st_load; o[1] = st_mfma; o[2] = st_store; o[3] = st_bar;
   }
+#endif
+
+  // ---- epilogue: lane holds C[m = 16t + (l&15)][n = 4u + (l>>4)] in acc[t][u]; stores only ----
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cbase[(int64_t)(4 * u) * g.ldc + t * 16] = alpha * acc[t][u];
 }
 
 template <bool TA, bool TB>

@@ -91,6 +91,10 @@ struct lpgp_ctx {
   int* d_info = nullptr;           // potrf info word
   double* d_tmp = nullptr;         // small scratch (vectors)
   int64_t tmp_cap = 0;
+  // caching allocator: freed device buffers are kept for reuse (a hipMalloc/hipFree pair
+  // of a multi-GB Gram matrix costs more than the factorisation of a small problem)
+  struct PoolBuf { void* p; size_t bytes; };
+  std::vector<PoolBuf> pool;
   // profiling
   int prof_on = 0;
   lpgp::ProfSlot prof[LPGP_K_COUNT];
@@ -136,6 +140,10 @@ struct lpgp_rhs {
 
 namespace lpgp {
 
+// device memory pool (api.hip)
+int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh);
+void pool_free(lpgp_ctx* ctx, void* p, size_t bytes);
+
 // profiling helpers: bracket launches of `kernel` on `stream`
 void prof_begin(lpgp_ctx* ctx, hipStream_t stream, int kernel, double flops, double bytes);
 void prof_end(lpgp_ctx* ctx, hipStream_t stream);
@@ -158,6 +166,7 @@ struct GemmArgs {
   int32_t tri;
   int32_t row_tile0, col_tile0;    // global tile index of C(0,0) (for tri)
   int32_t ktrim;                   // 1: B (or A) lower-triangular in (n,k): skip k > n-range (invL products)
+  unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
 
@@ -167,6 +176,7 @@ int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda,
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
+int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp);
 
 // assemble.hip ----------------------------------------------------------------------------
 int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,

@@ -30,8 +30,22 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
 // In-place Cholesky of one 128x128 SPD tile (lower, column-major, leading dim lda) and the
 // explicit inverse of its factor (dense 128x128 column-major, zeros above the diagonal).
+//
+// One workgroup, tile resident in LDS.  16x16 blocks: the diagonal block is factored and
+// inverted by one wave with one matrix row per lane (register resident, broadcasts by
+// v_readlane, reciprocal square root instead of sqrt + divide), everything else is
+// 16x16x16 block products on v_mfma_f64_4x4x4_4b_f64 (gemm.hip explains the choice of
+// shape).  A 16x16 accumulator is four registers acc[q]: element (m = lane&15,
+// n = 4q + (lane>>4)); per 4-deep k-step it takes ONE "m-side" fragment
+// (lane -> M[m = lane&15][k = lane>>4]) and four replicated "n-side" fragments
+// (lane -> N[n = 4q + (lane&3)][k = lane>>4]).
 __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
                                                           double* __restrict__ linv, int* __restrict__ info,
                                                           int info_base) {
@@ -39,13 +53,13 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   double* s = sm;                       // s[c*TL + r]
   double* sD = sm + TILE * TL;          // 8 diagonal-block inverses, column-major 16x16: Linv[r][c] at [c*16 + r]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r16 = lane & 15, g = lane >> 4;
+  const int r16 = lane & 15, g = lane >> 4, l3 = lane & 3;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
 
-  // ---- load tile ----
-  for (int c = wid; c < TILE; c += 4) {
-    v2f64 v = *reinterpret_cast<const v2f64*>(a + (int64_t)c * lda + 2 * lane);
-    *reinterpret_cast<v2f64*>(s + c * TL + 2 * lane) = v;
-  }
+  // ---- load tile: one 1-KiB LDS-DMA piece per column ----
+  for (int c = wu; c < TILE; c += 4)
+    __builtin_amdgcn_global_load_lds((gptr_t)(a + (int64_t)c * lda + 2 * lane), (lptr_t)(s + c * TL), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int jb = 0; jb < 8; ++jb) {
@@ -65,8 +79,12 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
           if (!bad) bad = j0 + j + 1;
           piv = 1.0;
         }
-        const double l = sqrt(piv);
-        const double inv = 1.0 / l;
+        // inv = piv^{-1/2} (hardware estimate + two Newton steps), l = piv * inv
+        double inv = __builtin_amdgcn_rsq(piv);
+        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+        double l = piv * inv;
+        l = fma(0.5 * inv, fma(-l, l, piv), l);           // one Newton step on l: correctly rounded in practice
         invd[j] = inv;
         row[j] = (i == j) ? l : row[j] * inv;
 #pragma unroll
@@ -97,15 +115,16 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     __syncthreads();
     // ---- (b) panel below: X_ib = A_ib * Linv^T  (in place) ----
     for (int ib = jb + 1 + wid; ib < 8; ib += 4) {
-      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const double aop = sD[jb * 256 + (4 * ks + g) * 16 + r16];            // Linv[c=r16][k]
-        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];         // A[r=r16][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];          // A[r=r16][k]        (m side)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                             // Linv[c=4q+l3][k]   (n side)
+          acc[q] = MFMA4(sD[jb * 256 + (4 * ks + g) * 16 + 4 * q + l3], bop, acc[q]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[(j0 + g + 4 * q) * TL + ib * 16 + r16] = acc[q];
+      for (int q = 0; q < 4; ++q) s[(j0 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
     }
     __syncthreads();
     // ---- (c) trailing update inside the tile: A_ib,kb -= X_ib X_kb^T, jb < kb <= ib ----
@@ -116,17 +135,18 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       while ((u + 1) * (u + 2) / 2 <= pidx) ++u;
       const int v = pidx - u * (u + 1) / 2;
       const int ib = jb + 1 + u, kb = jb + 1 + v;
-      v4f64 acc;
+      double acc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = s[(kb * 16 + g + 4 * q) * TL + ib * 16 + r16];
+      for (int q = 0; q < 4; ++q) acc[q] = s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const double aop = -s[(j0 + 4 * ks + g) * TL + kb * 16 + r16];        // -X_kb[c=r16][k]
-        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];         //  X_ib[r=r16][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];          //  X_ib[r=r16][k]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                             // -X_kb[c=4q+l3][k]
+          acc[q] = MFMA4(-s[(j0 + 4 * ks + g) * TL + kb * 16 + 4 * q + l3], bop, acc[q]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[(kb * 16 + g + 4 * q) * TL + ib * 16 + r16] = acc[q];
+      for (int q = 0; q < 4; ++q) s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
     }
     __syncthreads();
   }
@@ -136,29 +156,32 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   for (int dlt = 1; dlt < 8; ++dlt) {
     for (int j = wid; j + dlt < 8; j += 4) {
       const int i = j + dlt;
-      v4f64 S = {0.0, 0.0, 0.0, 0.0};
+      double S[4] = {0.0, 0.0, 0.0, 0.0};                  // S[q]: (m = 4q + g, c = r16)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const double aop = s[(j * 16 + 4 * ks + g) * TL + i * 16 + r16];      // L_ij[m=r16][t]
-        const double bop = sD[j * 256 + r16 * 16 + 4 * ks + g];               // Linv_j[t][c=r16]
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, S, 0, 0, 0);
+        const double bop = sD[j * 256 + r16 * 16 + 4 * ks + g];                 // Linv_j[t][c=r16]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                             // L_ij[m=4q+l3][t]
+          S[q] = MFMA4(s[(j * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
       }
       for (int k = j + 1; k < i; ++k) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const double aop = s[(k * 16 + 4 * ks + g) * TL + i * 16 + r16];    // L_ik[m=r16][t]
-          const double bop = s[(k * 16 + 4 * ks + g) * TL + j * 16 + r16];    // X_kj[t][c=r16]
-          S = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, S, 0, 0, 0);
+          const double bop = s[(k * 16 + 4 * ks + g) * TL + j * 16 + r16];      // X_kj[t][c=r16]
+#pragma unroll
+          for (int q = 0; q < 4; ++q)                                           // L_ik[m=4q+l3][t]
+            S[q] = MFMA4(s[(k * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
         }
       }
-      v4f64 X = {0.0, 0.0, 0.0, 0.0};
+      double X[4] = {0.0, 0.0, 0.0, 0.0};                  // X[u]: (r = 4u + g, c = r16)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double aop = -sD[i * 256 + (g + 4 * q) * 16 + r16];             // -Linv_i[r=r16][m=g+4q]
-        X = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, S[q], X, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {                         // contraction index m = 4q + g: S[q] is the m-side operand
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                         // -Linv_i[r=4u+l3][m=4q+g]
+          X[u] = MFMA4(-sD[i * 256 + (4 * q + g) * 16 + 4 * u + l3], S[q], X[u]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[(i * 16 + g + 4 * q) * TL + j * 16 + r16] = X[q];
+      for (int u = 0; u < 4; ++u) s[(i * 16 + 4 * u + g) * TL + j * 16 + r16] = X[u];
     }
     __syncthreads();
   }
@@ -376,6 +399,145 @@ int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, i
                            LPGP_K_GEMM));
     p1 = p0;
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// single right-hand side: representer weights  w = L^{-T} L^{-1} r   (_conditional.py:44,108)
+// One fused launch per 128-row tile: every workgroup first forms the solution of the tile
+// from the explicit tile inverse (128x128 matvec, L2 resident), then applies it to its own
+// slice of the remaining right-hand side.  x and b are distinct vectors, so no workgroup
+// reads what another one writes inside a launch.
+// ---------------------------------------------------------------------------------------
+// 128x128 matvec with the tile inverse, 512 threads: out[r] = sum_c M[c*128 + r] * in[c]
+__device__ __forceinline__ void tile_matvec(const double* __restrict__ M, const double* sin, double* part, double* out_g,
+                                            double* out_s, int t) {
+  const int r = t & 127, qd = t >> 7;
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc = fma(M[(32 * qd + c) * TILE + r], sin[32 * qd + c], acc);
+  part[t] = acc;
+  __syncthreads();
+  if (t < TILE) {
+    const double v = (part[t] + part[t + 128]) + (part[t + 256] + part[t + 384]);
+    if (out_g) out_g[t] = v;
+    if (out_s) out_s[t] = v;
+  }
+}
+
+// x_0 = Linv_0 b_0
+__global__ __launch_bounds__(512) void trsv_fwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ b,
+                                                             double* __restrict__ x) {
+  __shared__ double sb[TILE], part[512];
+  const int t = threadIdx.x;
+  if (t < TILE) sb[t] = b[t];
+  __syncthreads();
+  tile_matvec(linv, sb, part, x, nullptr, t);
+}
+
+// step k: b[rows > tile k] -= L[rows, tile k] * x_k; the workgroup that owns tile k+1 then
+// forms x_{k+1} = Linv_{k+1} b_{k+1} (its right-hand side is final after this update).
+__global__ __launch_bounds__(512) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t ld,
+                                                             const double* __restrict__ linv_next,
+                                                             double* __restrict__ b, double* __restrict__ x,
+                                                             int64_t k0) {
+  __shared__ double sy[TILE], sb[TILE], part[512];
+  const int t = threadIdx.x, r = t & 127, qd = t >> 7;
+  if (t < TILE) sy[t] = x[k0 + t];
+  __syncthreads();
+  const int64_t row = k0 + TILE + (int64_t)blockIdx.x * TILE + r;
+  const double* Lp = L + row + (k0 + 32 * qd) * ld;
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc = fma(Lp[(int64_t)c * ld], sy[32 * qd + c], acc);
+  part[t] = acc;
+  __syncthreads();
+  if (t < TILE) {
+    const double nb = b[row] - ((part[t] + part[t + 128]) + (part[t + 256] + part[t + 384]));
+    b[row] = nb;
+    sb[t] = nb;
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  tile_matvec(linv_next, sb, part, x + k0 + TILE, nullptr, t);
+}
+
+// transposed 128x128 matvec, 8 waves: out[c] = sum_r M[c*128 + r] * in[r]
+__device__ __forceinline__ void tile_matvec_t(const double* __restrict__ M, const double* sin, double* out_g, int t) {
+  const int lane = t & 63, w = t >> 6;
+  double acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = w * 16 + j;
+    acc[j] = M[c * TILE + lane] * sin[lane] + M[c * TILE + lane + 64] * sin[lane + 64];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double a = acc[j];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) out_g[w * 16 + j] = a;
+  }
+}
+
+// x_last = Linv_last^T y_last
+__global__ __launch_bounds__(512) void trsv_bwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ y,
+                                                             double* __restrict__ x) {
+  __shared__ double sy[TILE];
+  const int t = threadIdx.x;
+  if (t < TILE) sy[t] = y[t];
+  __syncthreads();
+  tile_matvec_t(linv, sy, x, t);
+}
+
+// step k (descending): y[c] -= L[tile k rows, c]^T x_k for 128 columns c per workgroup; the
+// workgroup that owns tile k-1 (the last one) then forms x_{k-1} = Linv_{k-1}^T y_{k-1}.
+__global__ __launch_bounds__(512) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t ld,
+                                                             const double* __restrict__ linv_prev,
+                                                             double* __restrict__ y, double* __restrict__ x, int64_t k0) {
+  __shared__ double sx[TILE], sy[TILE];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < TILE) sx[t] = x[k0 + t];
+  __syncthreads();
+  const int64_t c0 = (int64_t)blockIdx.x * TILE;      // this workgroup's 128 columns (all < k0)
+  double acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double* Lp = L + k0 + (c0 + w * 16 + j) * ld;
+    acc[j] = Lp[lane] * sx[lane] + Lp[lane + 64] * sx[lane + 64];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double a = acc[j];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) {
+      const double ny = y[c0 + w * 16 + j] - a;
+      y[c0 + w * 16 + j] = ny;
+      sy[w * 16 + j] = ny;
+    }
+  }
+  if (c0 + TILE != k0) return;                         // not the owner of tile k-1
+  __syncthreads();
+  tile_matvec_t(linv_prev, sy, x + c0, t);
+}
+
+// v (padded length T*128, device) <- G^{-1} v, using scratch vector `tmp` of the same length
+int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp) {
+  const int T = (int)T64;
+  const int64_t ld = mat->cap;
+  hipStream_t st = ctx->s_main;
+  const double* a = mat->a;
+  auto linv = [&](int k) { return (const double*)(mat->linv + (int64_t)k * TILE * TILE); };
+  // forward: L tmp = v   (v is consumed as the running right-hand side)
+  hipLaunchKernelGGL(trsv_fwd_head_kernel, dim3(1), dim3(512), 0, st, linv(0), (const double*)v, tmp);
+  for (int k = 0; k + 1 < T; ++k)
+    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(T - k - 1), dim3(512), 0, st, a, ld, linv(k + 1), v, tmp,
+                       (int64_t)k * TILE);
+  // backward: L^T v = tmp  (tmp is consumed as the running right-hand side)
+  hipLaunchKernelGGL(trsv_bwd_head_kernel, dim3(1), dim3(512), 0, st, linv(T - 1),
+                     (const double*)(tmp + (int64_t)(T - 1) * TILE), v + (int64_t)(T - 1) * TILE);
+  for (int k = T - 1; k >= 1; --k)
+    hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k), dim3(512), 0, st, a, ld, linv(k - 1), tmp, v, (int64_t)k * TILE);
+  LPGP_HIP(hipGetLastError());
   return 0;
 }
 

@@ -10,10 +10,12 @@ built extension, and any evaluation needs a visible MI355X.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (fails loudly when liblpgp.so is missing)
+from . import config  # noqa: E402
+from ._engine import to_device  # noqa: E402
 from . import functions, linfuncops, linfunctls, randprocs, randvars  # noqa: E402
 from .randprocs import ConditionalGaussianProcess, GaussianProcess  # noqa: E402
 
 __all__ = [
     "functions", "linfuncops", "linfunctls", "randprocs", "randvars",
-    "GaussianProcess", "ConditionalGaussianProcess",
+    "GaussianProcess", "ConditionalGaussianProcess", "to_device", "config",
 ]

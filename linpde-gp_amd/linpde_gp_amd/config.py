@@ -1,0 +1,7 @@
+"""Run-time knobs of the MI355X path (the reference's only flag, `pn.config.block_triangular_solves`,
+`linops/_block.py:8-14`, has no counterpart: triangular solves are always blocked here)."""
+
+# Expected final number of observations of a chain of `condition_on_observations` calls.
+# The resident Gram/factor buffer is allocated once with this capacity instead of growing
+# (and being copied) with every appended block.  0 = grow on demand.
+gram_capacity_hint: int = 0

@@ -55,6 +55,12 @@ class LinearFunctional:
     def coefficients_dict(self) -> dict:
         raise NotImplementedError
 
+    def device_points(self, ctx):
+        """Device-resident evaluation points (reuses the handle of a `to_device` array)."""
+        from .. import _engine
+
+        return _engine.Points(ctx, self.points())
+
     def __call__(self, f, /, *, argnum: int = 0):
         from ..functions import Function
         from ..randprocs import _gaussian_process as gps
@@ -110,6 +116,11 @@ class _EvaluationFunctional(LinearFunctional):
         d = self._input_domain_shape[0] if self._input_domain_shape else 1
         return {(0,) * d: 1.0}
 
+    def device_points(self, ctx):
+        from .. import _engine
+
+        return _engine.as_points(ctx, self._X, self.points())
+
     def _apply_to_function(self, f):
         res = np.asarray(f(self._X))
         if f.output_ndim > 0:
@@ -139,6 +150,9 @@ class CompositeLinearFunctional(LinearFunctional):
 
     def points(self):
         return self._linfunctl.points()
+
+    def device_points(self, ctx):
+        return self._linfunctl.device_points(ctx)
 
     def coefficients_dict(self):
         inner = self._linfunctl.coefficients_dict()

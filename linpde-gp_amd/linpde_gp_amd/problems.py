@@ -1,0 +1,172 @@
+"""Synthetic workloads of BASELINE.json as plain arrays + host objects.
+
+What the reference's problem/domain builders *produce* for these configs
+(`problems/pde/_poisson.py:36-95`, `_heat.py:32-93`, `domains/_box.py:81-114`:
+`uniform_grid` = `linspace` / `meshgrid(indexing="ij")`, boundary enumeration
+`domains/_cartesian_product.py:75-82`), restated without the class machinery.
+Deterministic grids, no RNG.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class Observation:
+    X: np.ndarray                 # (n, d)
+    Y: np.ndarray                 # (n,)
+    op: dict                      # {multi_index: coeff} of the differential operator (identity = values)
+    noise_var: float | None = None
+
+
+@dataclass
+class Workload:
+    name: str
+    d: int
+    kernel: list                  # oracle-style [(scale, [factor, ...])]
+    observations: list = field(default_factory=list)
+    Xtest: np.ndarray | None = None
+
+    @property
+    def n_total(self) -> int:
+        return sum(o.X.shape[0] for o in self.observations)
+
+    def algorithmic_work(self) -> dict:
+        """bytes / flops the judge prices the phases with."""
+        n, m = float(self.n_total), float(self.Xtest.shape[0])
+        return {
+            "assembly_bytes": 8.0 * n * n,
+            "crosscov_bytes": 8.0 * m * n,
+            "potrf_flops": n**3 / 3.0,
+            "weights_flops": 2.0 * n * n,
+            "mean_flops": 2.0 * m * n,
+            "var_flops": n * n * m + 2.0 * n * m,
+        }
+
+    def total_flops(self) -> float:
+        w = self.algorithmic_work()
+        return w["potrf_flops"] + w["weights_flops"] + w["mean_flops"] + w["var_flops"]
+
+
+def poisson_2d(n_side: int = 128, n_bdry: int | None = None, m_side: int = 64,
+               noise_var: float = 1e-8) -> Workload:
+    """c3 / c4: -Lap u = 2 on [-1,1]^2, u = 0 on the boundary, prior 2^2 * M52(l=1) x M52(l=1)."""
+    n_bdry = n_side if n_bdry is None else n_bdry
+    g = np.linspace(-1.0, 1.0, n_side)
+    Xp = np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)
+    e = np.linspace(-1.0 + 1e-6, 1.0 - 1e-6, n_bdry)       # inset=1e-6 along the edge
+    lo, hi = np.full(n_bdry, -1.0), np.full(n_bdry, 1.0)
+    edges = [np.column_stack([lo, e]), np.column_stack([hi, e]),
+             np.column_stack([e, lo]), np.column_stack([e, hi])]
+    ident = {(0, 0): 1.0}
+    lap = {(2, 0): -1.0, (0, 2): -1.0}                       # L = -Laplacian
+    obs = [Observation(X, np.zeros(n_bdry), ident, noise_var) for X in edges]
+    obs.append(Observation(Xp, np.full(Xp.shape[0], 2.0), lap, None))
+    t = np.linspace(-1.0 + 1.0 / m_side, 1.0 - 1.0 / m_side, m_side)
+    Xt = np.stack(np.meshgrid(t, t, indexing="ij"), axis=-1).reshape(-1, 2)
+    kernel = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
+    return Workload(f"poisson2d_dirichlet_{n_side}x{n_side}", 2, kernel, obs, Xt)
+
+
+def poisson_1d(n: int = 8192, n_bdry_repeats: int = 1, m: int = 1024, noise_var: float | None = None) -> Workload:
+    """c1 / c2: -u'' = pi^2 sin(pi x) on [-1,1], u(+-1) = 0, prior 2^2 * M52(l=1)."""
+    X = np.linspace(-1.0, 1.0, n)[:, None]
+    Y = np.pi**2 * np.sin(np.pi * X[:, 0])
+    Xb = np.repeat(np.array([[-1.0], [1.0]]), n_bdry_repeats, axis=0)
+    obs = [Observation(Xb, np.zeros(Xb.shape[0]), {(0,): 1.0}, noise_var),
+           Observation(X, Y, {(2,): -1.0}, None)]
+    Xt = np.linspace(-1.0 + 1.0 / m, 1.0 - 1.0 / m, m)[:, None]
+    return Workload(f"poisson1d_dirichlet_{n}", 1, [(4.0, [("matern", 2.5, 1.0)])], obs, Xt)
+
+
+def heat_1d(nt: int = 512, nx: int = 64, alpha: float = 0.1, m_side: int = 64) -> Workload:
+    """c5: u_t - alpha u_xx = 0 on t in [0,5], x in [-1,1]; IC sin series, Dirichlet BCs with
+    noise 1e-5, plus noisy interior value observations; prior M32(l_t=2.5) x M52(l_x=2.0)."""
+    ident = {(0, 0): 1.0}
+    heat = {(1, 0): 1.0, (0, 2): -alpha}
+    x_ic = np.linspace(-1.0, 1.0, 64)
+    ic = Observation(np.column_stack([np.zeros(64), x_ic]), np.sin(np.pi * (x_ic + 1.0) / 2.0), ident, 1e-8)
+    t_bc = np.linspace(0.0, 5.0, 256)
+    bcs = [Observation(np.column_stack([t_bc, np.full(256, s)]), np.zeros(256), ident, 1e-5) for s in (-1.0, 1.0)]
+    tg = np.linspace(0.0, 5.0, nt)
+    xg = np.linspace(-1.0, 1.0, nx)
+    Xp = np.stack(np.meshgrid(tg, xg, indexing="ij"), axis=-1).reshape(-1, 2)
+    pde = Observation(Xp, np.zeros(Xp.shape[0]), heat, None)
+    ti = np.linspace(0.2, 4.8, 16)
+    xi = np.linspace(-0.9, 0.9, 16)
+    Xi = np.stack(np.meshgrid(ti, xi, indexing="ij"), axis=-1).reshape(-1, 2)
+    sol = np.exp(-alpha * (np.pi / 2.0) ** 2 * Xi[:, 0]) * np.sin(np.pi * (Xi[:, 1] + 1.0) / 2.0)
+    interior = Observation(Xi, sol, ident, 1e-4)
+    tt = np.linspace(0.05, 4.95, m_side)
+    xt = np.linspace(-0.95, 0.95, m_side)
+    Xt = np.stack(np.meshgrid(tt, xt, indexing="ij"), axis=-1).reshape(-1, 2)
+    kernel = [(1.0, [("matern", 1.5, 2.5), ("matern", 2.5, 2.0)])]
+    return Workload(f"heat1d_{nt}x{nx}", 2, kernel, [ic, *bcs, pde, interior], Xt)
+
+
+# ---- host-object side ------------------------------------------------------------------------
+def build_prior(wl: Workload):
+    """The `GaussianProcess` prior of a workload, from the reference-style constructors."""
+    from . import functions
+    from .randprocs import GaussianProcess, covfuncs
+
+    total = None
+    for scale, factors in wl.kernel:
+        fs = []
+        for f in factors:
+            if f[0] == "matern":
+                fs.append(covfuncs.Matern((), nu=f[1], lengthscales=f[2]))
+            else:
+                fs.append(covfuncs.ExpQuad((), lengthscales=f[1]))
+        k = covfuncs.TensorProduct(*fs) if len(fs) > 1 else _as_vector_input(fs[0], covfuncs)
+        k = scale * k
+        total = k if total is None else total + k
+    return GaussianProcess(functions.Zero((wl.d,)), total)
+
+
+def _as_vector_input(k, covfuncs):
+    if isinstance(k, covfuncs.Matern):
+        return covfuncs.Matern((1,), nu=k.nu, lengthscales=k.lengthscales)
+    return covfuncs.ExpQuad((1,), lengthscales=k.lengthscales)
+
+
+def operator_of(op: dict, d: int):
+    """`LinearDifferentialOperator` with the given coefficient map (None for plain values)."""
+    from .linfuncops import diffops
+
+    if set(op) == {(0,) * d} and op[(0,) * d] == 1.0:
+        return None
+    shape = (d,)
+    entries = {diffops.MultiIndex(np.array(mi)): float(c) for mi, c in op.items()}
+    coeffs = diffops.PartialDerivativeCoefficients({(): entries}, shape, ())
+    return diffops.LinearDifferentialOperator(coeffs, input_shapes=(shape, ()))
+
+
+def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True):
+    """The canonical user sequence (`experiments/0001_poisson_dirichlet_2d.ipynb` cells 6-22):
+    condition block by block, then posterior mean and marginal variance on the test grid."""
+    from . import randvars
+
+    prior = build_prior(wl) if prior is None else prior
+    u = prior
+    for i, o in enumerate(wl.observations):
+        X = o.X if device_arrays is None else device_arrays["obs"][i]
+        n = o.X.shape[0]
+        b = None if o.noise_var is None else randvars.Normal(np.zeros(n), np.full(n, o.noise_var))
+        u = u.condition_on_observations(o.Y, X=X, L=operator_of(o.op, wl.d), b=b)
+    Xt = wl.Xtest if device_arrays is None else device_arrays["test"]
+    if want_var:
+        mean, var = u.predict(Xt)
+    else:
+        mean, var = u.predict(Xt, return_var=False), None
+    return u, mean, var
+
+
+def upload(wl: Workload):
+    """Make every point set of the workload resident in HBM (outside any timed region)."""
+    from ._engine import to_device
+
+    return {"obs": [to_device(o.X) for o in wl.observations], "test": to_device(wl.Xtest)}

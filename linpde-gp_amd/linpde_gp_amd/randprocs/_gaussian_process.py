@@ -124,8 +124,10 @@ class _DeviceState:
     """Device-resident state shared along a chain of conditionings."""
 
     def __init__(self, ctx):
+        from .. import config
+
         self.ctx = ctx
-        self.mat = _engine.GramMatrix(ctx)
+        self.mat = _engine.GramMatrix(ctx, capacity_hint=config.gram_capacity_hint)
         self.generation = 0
 
 
@@ -134,7 +136,7 @@ class ConditionalGaussianProcess(GaussianProcess):
     def from_observations(cls, prior: GaussianProcess, Y, X=None, *, L=None, b=None):
         Yf, Lf, bf, Xpts, coeffs, pred_mean = cls._preprocess_observations(prior=prior, Y=Y, X=X, L=L, b=b)
         state = _DeviceState(_engine.default_context())
-        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, _engine.Points(state.ctx, Xpts), pred_mean)
+        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, Lf.device_points(state.ctx), pred_mean)
         return cls._extend(prior, state, (), block)
 
     @classmethod
@@ -153,14 +155,15 @@ class ConditionalGaussianProcess(GaussianProcess):
         mat.assemble(k.lower(), new_block.points, None, bi, bi)
         # measurement noise  gram + b.cov   (`_conditional.py:392-394`)
         if new_block.b is not None and isinstance(new_block.b, randvars.Normal):
-            cov = np.asarray(new_block.b.cov)
             n = new_block.points.n
-            cov = cov.reshape(n, n)
-            off = cov - np.diag(np.diag(cov))
-            if np.any(off != 0.0):
-                mat.add_dense(bi, cov)
+            if new_block.b.cov_diag is not None:
+                mat.add_diag(bi, np.ascontiguousarray(new_block.b.cov_diag))
             else:
-                mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
+                cov = np.asarray(new_block.b.cov).reshape(n, n)
+                if np.any(cov - np.diag(np.diag(cov)) != 0.0):
+                    mat.add_dense(bi, cov)
+                else:
+                    mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
         info = mat.potrf()
         if info != 0:
             raise np.linalg.LinAlgError(
@@ -211,7 +214,7 @@ class ConditionalGaussianProcess(GaussianProcess):
             raise NotImplementedError("conditioning a transformed posterior is not supported")
         Yf, Lf, bf, Xpts, coeffs, pred_mean = self._preprocess_observations(
             prior=self._prior, Y=Y, X=X, L=L, b=b)
-        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, _engine.Points(self._state.ctx, Xpts), pred_mean)
+        block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, Lf.device_points(self._state.ctx), pred_mean)
         return ConditionalGaussianProcess._extend(self._prior, self._state, self._blocks, block)
 
     @classmethod
@@ -287,7 +290,7 @@ class ConditionalGaussianProcess(GaussianProcess):
         """Posterior mean and marginal variance at `x` in one pass over the factor."""
         self._check_current()
         X, batch = self._flat(x)
-        pts = _engine.Points(self._state.ctx, X)
+        pts = _engine.as_points(self._state.ctx, x, X)
         rhs = self._cross(pts)
         pm = self._prior_mean_at(x, X.shape[0])
         kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None

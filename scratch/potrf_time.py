@@ -1,0 +1,33 @@
+import os, sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'linpde-gp_amd')
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _engine, problems
+from linpde_gp_amd.randprocs import covfuncs
+import linpde_gp_amd.randprocs._gaussian_process as G
+ctx = _engine.default_context()
+wl = problems.poisson_2d(128, m_side=64)
+dev = problems.upload(wl)
+prior = problems.build_prior(wl)
+pts = [d_._lpgp_points for d_ in dev["obs"]]
+coeffs = [o.op for o in wl.observations]
+def build():
+    mat = _engine.GramMatrix(ctx, wl.n_total)
+    for bi in range(5):
+        mat.add_block(pts[bi].n)
+        for bj in range(bi + 1):
+            k = covfuncs.DifferentiatedCovarianceFunction(prior.cov, *G._combine(prior.cov, coeffs[bi], coeffs[bj]))
+            mat.assemble(k.lower(), pts[bi], None if bi == bj else pts[bj], bi, bj)
+        if wl.observations[bi].noise_var: mat.add_diag(bi, None, wl.observations[bi].noise_var)
+    ctx.sync()
+    return mat
+for nb in (256, 512, 1024):
+    for la in (0, 1):
+        ctx.set_option("nb", nb); ctx.set_option("lookahead", la)
+        ts = []
+        for rep in range(3):
+            mat = build(); t0 = time.perf_counter(); info = mat.potrf(); ctx.sync(); ts.append(time.perf_counter() - t0)
+            if rep == 2:
+                t0 = time.perf_counter(); w = mat.solve_weights(np.ones(wl.n_total)); ctx.sync(); tw = time.perf_counter() - t0
+            del mat
+        print(f"nb={nb} lookahead={la}: potrf {min(ts)*1e3:.2f} ms ({1.608e12/min(ts)/1e12:.1f} TF)  weights {tw*1e3:.2f} ms  info={info}")
