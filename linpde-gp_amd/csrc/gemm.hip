@@ -60,30 +60,26 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
   }
 }
 
+// Fragment element addresses (in doubles, relative to the stage base).
+//   m-side fragment:  idx = idx_base + (lane & 15), k = ks*4 + (lane >> 4)
+//   n-side fragment:  idx = idx_base + (lane & 3),  k = ks*4 + (lane >> 4)   (replicated over lane bits 2..3:
+//                     the "A" operand of v_mfma_f64_4x4x4_4b_f64 with one 4x4 block shared by all four blocks)
 template <bool T>
-__device__ __forceinline__ double read_frag(const double* __restrict__ s, int idx_base, int ks, int lane) {
-  // fragment element: idx = idx_base + (lane & 15), k = ks*4 + (lane >> 4)
-  const int k = ks * 4 + (lane >> 4);
-  if constexpr (!T) return s[k * LDM + idx_base + (lane & 15)];
-  else {
-    const int idx = idx_base + (lane & 15);
-    return s[idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1)];
-  }
+__device__ __forceinline__ int frag_off(int idx, int k) {
+  if constexpr (!T) return k * LDM + idx;
+  else              return idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1);
 }
 
-// 4-wide fragment replicated over the four lane blocks: idx = idx_base + (lane & 3),
-// k = ks*4 + (lane >> 4); lanes that differ only in bits 2..3 read the same address (LDS
-// broadcast).  This is the "A" operand of v_mfma_f64_4x4x4_4b_f64 with one 4x4 block
-// shared by all four blocks of the instruction.
-template <bool T>
-__device__ __forceinline__ double read_frag4(const double* __restrict__ s, int idx_base, int ks, int lane) {
-  const int k = ks * 4 + (lane >> 4);
-  if constexpr (!T) return s[k * LDM + idx_base + (lane & 3)];
-  else {
-    const int idx = idx_base + (lane & 3);
-    return s[idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1)];
-  }
+// LDS read whose completion the COMPILER does not track: with LDS-DMA in flight hipcc turns
+// every wait for a ds_read result into s_waitcnt lgkmcnt(0), which also waits for the
+// prefetch just issued for the next chunk.  The reads are therefore issued from inline asm
+// and retired by hand-counted s_waitcnt lgkmcnt(N) (LDS operations return in order).
+__device__ __forceinline__ double lds_read_async(unsigned byte_addr) {
+  double d;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(byte_addr));
+  return d;
 }
+#define LDS_WAIT(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // MFMA shape: measured on MI355X, v_mfma_f64_16x16x4_f64 sustains only ~48 TFLOP/s chip-wide
 // (>= 88 cycles per instruction per SIMD at any occupancy) while v_mfma_f64_4x4x4_4b_f64
@@ -131,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
   double* sA = smem;                  // 2 stages
   double* sB = smem + 2 * STAGE;
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
 
   const int KT = g.k / BK;
   const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar (LDS-DMA base must be uniform)
@@ -181,33 +178,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
       dma_tile<TA>(g.A, g.lda, m0, knext, lane, wu, sA + (cur ^ 1) * STAGE);
       dma_tile<TB>(g.B, g.ldb, n0, knext, lane, wu, sB + (cur ^ 1) * STAGE);
     }
-    const double* cA = sA + cur * STAGE;
-    const double* cB = sB + cur * STAGE;
     // 16 chunks of 16 MFMAs per stage (4 k-steps x 4 groups of 4 n-fragments).  Fragments
     // are double-buffered in registers: the LDS reads of chunk c+1 are issued before the
-    // MFMAs of chunk c (264 cycles of matrix work cover the LDS latency); sched_barriers
-    // keep hipcc from sinking the reads back to their first use.
-#ifdef LPGP_STAMP
-    STAMP(t_b); st_load += t_b - t_a; t_a = t_b;
-#endif
+    // MFMAs of chunk c (264 cycles of matrix work cover the LDS latency) and retired with a
+    // counted wait that leaves exactly those newer reads in flight.
+    const unsigned baseA = lds_base + (unsigned)(cur * STAGE) * 8u;
+    const unsigned baseB = lds_base + (unsigned)((2 + cur) * STAGE) * 8u;
     double am[2][4], bn[2][4];
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 4; ++t) am[0][t] = read_frag<TA>(cA, wm * 64 + t * 16, 0, lane);
+    for (int t = 0; t < 4; ++t)
+      am[0][t] = lds_read_async(baseA + 8u * (unsigned)frag_off<TA>(wm * 64 + t * 16 + (lane & 15), (lane >> 4)));
 #pragma unroll
-    for (int v = 0; v < 4; ++v) bn[0][v] = read_frag4<TB>(cB, wn * 64 + v * 4, 0, lane);
+    for (int v = 0; v < 4; ++v)
+      bn[0][v] = lds_read_async(baseB + 8u * (unsigned)frag_off<TB>(wn * 64 + v * 4 + (lane & 3), (lane >> 4)));
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int ks = c >> 2, uc = c & 3, cb = c & 1;
       if (c + 1 < 16) {
         const int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bn[cb ^ 1][v] = read_frag4<TB>(cB, wn * 64 + (uc2 * 4 + v) * 4, ks2, lane);
+        for (int v = 0; v < 4; ++v)
+          bn[cb ^ 1][v] = lds_read_async(
+              baseB + 8u * (unsigned)frag_off<TB>(wn * 64 + (uc2 * 4 + v) * 4 + (lane & 3), ks2 * 4 + (lane >> 4)));
         if (uc2 == 0) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) am[ks2 & 1][t] = read_frag<TA>(cA, wm * 64 + t * 16, ks2, lane);
+          for (int t = 0; t < 4; ++t)
+            am[ks2 & 1][t] = lds_read_async(
+                baseA + 8u * (unsigned)frag_off<TA>(wm * 64 + t * 16 + (lane & 15), ks2 * 4 + (lane >> 4)));
+          LDS_WAIT(8);
+        } else {
+          LDS_WAIT(4);
         }
+      } else {
+        LDS_WAIT(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < 4; ++v)
 #pragma unroll

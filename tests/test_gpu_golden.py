@@ -1,0 +1,90 @@
+"""HIP path vs the committed golden vectors (SymPy + 50-digit mpmath, tests/golden)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-12):
+    np.testing.assert_allclose(a, b, rtol=0, atol=rtol * max(np.max(np.abs(b)), 1e-300))
+
+
+def test_kernel_blocks_vs_golden(golden_dir):
+    import linpde_gp_amd as lp
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    g = np.load(os.path.join(golden_dir, "kernel_blocks.npz"))
+    x0, x1 = g["x0_1d"], g["x1_1d"]
+    for nu in (1.5, 2.5, 3.5):
+        p = int(nu - 0.5)
+        k = cf.Matern((), nu=nu, lengthscales=0.7)
+        for n0 in range(3):
+            for n1 in range(3):
+                if n0 + n1 > 2 * p:
+                    continue
+                kk = diffops.Derivative(n0)(diffops.Derivative(n1)(k, argnum=1), argnum=0)
+                _close(kk.matrix(x0[:, 0], x1[:, 0]), g[f"matern{int(2*nu)}2_l0.7_{n0}{n1}"])
+    ke = cf.ExpQuad((), lengthscales=0.25)
+    for n0 in range(3):
+        for n1 in range(3):
+            kk = diffops.Derivative(n0)(diffops.Derivative(n1)(ke, argnum=1), argnum=0)
+            _close(kk.matrix(x0[:, 0] / 3, x1[:, 0] / 3), g[f"expquad_l0.25_{n0}{n1}"], rtol=1e-11)
+    k2 = 4.0 * cf.TensorProduct(cf.Matern((), nu=2.5), cf.Matern((), nu=2.5))
+    D = -1.0 * diffops.Laplacian((2,))
+    _close(D(D(k2, argnum=1), argnum=0).matrix(g["X0_2d"], g["X1_2d"]), g["poisson_LkL"])
+    _close(D(k2, argnum=1).matrix(g["X0_2d"], g["X1_2d"]), g["poisson_kL"])
+    _close(k2.matrix(g["X0_2d"], g["X1_2d"]), g["poisson_k"])
+    kh = cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
+    H = diffops.HeatOperator((2,), alpha=0.1)
+    _close(H(H(kh, argnum=1), argnum=0).matrix(g["Xh0"], g["Xh1"]), g["heat_LkL"])
+    _close(H(kh, argnum=0).matrix(g["Xh0"], g["Xh1"]), g["heat_Lk"])
+
+
+def test_posterior_vs_golden(golden_dir):
+    import linpde_gp_amd as lp
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    g = np.load(os.path.join(golden_dir, "posterior_small.npz"))
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), 4.0 * cf.Matern((1,), nu=2.5, lengthscales=1.0))
+    u = prior.condition_on_observations(np.zeros(2), X=g["Xb"])
+    u = u.condition_on_observations(g["Yp"], X=g["Xp"], L=-1.0 * diffops.Laplacian((1,)))
+    mean, var = u.predict(g["Xt"])
+    # cond(G) ~ 1e9: fp64 agrees with the 50-digit solve to ~cond*eps
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=1e-7 * np.max(np.abs(g["mean"])))
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=1e-7 * np.max(np.abs(g["var"])) + 1e-10)
+    np.testing.assert_allclose(u.representer_weights, g["weights"], rtol=1e-5, atol=1e-6 * np.max(np.abs(g["weights"])))
+
+
+def test_full_size_properties():
+    """BASELINE size (c3, N_tot = 16896): size-independent properties instead of a CPU replay --
+    G w = r through an independent GPU assembly, symmetry of the posterior covariance, variance
+    reduction, and agreement of the two prediction paths (fused predict vs. covariance matrix)."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import problems
+    wl = problems.poisson_2d(128, m_side=16)
+    lp.config.gram_capacity_hint = wl.n_total
+    u, mean, var = problems.condition_and_predict(wl)
+    lp.config.gram_capacity_hint = 0
+    assert np.all(np.isfinite(mean)) and np.all(var > -1e-10) and np.all(var < 4.0)
+    # residual of the linear system on a sample of rows: (G w)_i = sum_j G_ij w_j with G_ij re-evaluated
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    k = prior_cov = u.prior.cov
+    D = -1.0 * diffops.Laplacian((2,))
+    w = u.representer_weights
+    pde = wl.observations[-1]
+    rows = np.array([0, 17, 4099, 16383])
+    Gr = np.concatenate(
+        [D(k, argnum=0).matrix(pde.X[rows], o.X) for o in wl.observations[:-1]]
+        + [D(D(k, argnum=1), argnum=0).matrix(pde.X[rows], pde.X)], axis=1)
+    np.testing.assert_allclose(Gr @ w, pde.Y[rows], rtol=0, atol=1e-6 * np.max(np.abs(pde.Y)))
+    # posterior covariance on a few points: symmetric, PSD, diagonal == fused variance
+    Xs = wl.Xtest[:12]
+    C = u.cov.matrix(Xs)
+    np.testing.assert_allclose(C, C.T, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.diag(C), var[:12], rtol=1e-8, atol=1e-12)
+    assert np.linalg.eigvalsh(C).min() > -1e-10
+    # solution of -Lap u = 2, u|boundary = 0 on [-1,1]^2: max is u(0,0) = 0.5894 (series solution)
+    assert abs(mean.max() - 0.5894) < 2e-2

@@ -1,0 +1,150 @@
+"""Host mirror of the reference's operator interface: everything that needs no GPU.
+
+Covers the coefficient algebra the reference pins in
+`tests/linpde_gp/linfuncops/diffops/test_coefficients.py:61-144`, the lowering of
+(kernel, L0, L1) to the C-ABI descriptor, shape/argument validation, and that liblpgp.so
+loads and exports every symbol declared in include/lpgp.h."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import linpde_gp_amd as lp
+from linpde_gp_amd import _lib
+from linpde_gp_amd.linfuncops import diffops
+from linpde_gp_amd.randprocs import covfuncs as cf
+
+
+def test_c_abi_exports_every_declared_symbol():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "lpgp.h")).read()
+    declared = set(re.findall(r"\b(lpgp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lpgp_kernel_id", "lpgp_family"}
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(_lib.lib, name), f"{name} declared in lpgp.h but not exported by liblpgp.so"
+    assert set(_lib.EXPORTED) <= declared
+
+
+def test_multi_index_and_coefficients_algebra():
+    mi = diffops.MultiIndex((1, 2, 0))
+    assert mi.order == 3 and mi.is_mixed and mi == diffops.MultiIndex([1, 2, 0]) and hash(mi) == hash(diffops.MultiIndex([1, 2, 0]))
+    with pytest.raises(ValueError):
+        diffops.MultiIndex((1, -1))
+    assert diffops.MultiIndex.from_index((1,), (3,), 2) == diffops.MultiIndex((0, 2, 0))
+    a = diffops.PartialDerivativeCoefficients({(): {diffops.MultiIndex((2, 0)): 1.0, diffops.MultiIndex((0, 2)): 1.0}}, (2,), ())
+    b = diffops.PartialDerivativeCoefficients({(): {diffops.MultiIndex((2, 0)): 3.0, diffops.MultiIndex((1, 1)): -1.0}}, (2,), ())
+    s = a + b
+    assert s[()][diffops.MultiIndex((2, 0))] == 4.0 and s[()][diffops.MultiIndex((1, 1))] == -1.0 and s.num_entries == 3
+    assert (-a)[()][diffops.MultiIndex((0, 2))] == -1.0
+    assert (2.5 * a)[()][diffops.MultiIndex((2, 0))] == 2.5
+    assert (a - a)[()][diffops.MultiIndex((2, 0))] == 0.0
+    assert s.has_mixed and not a.has_mixed
+    with pytest.raises(ValueError):
+        a + diffops.PartialDerivativeCoefficients({(): {diffops.MultiIndex((2,)): 1.0}}, (1,), ())
+    with pytest.raises(ValueError):
+        diffops.PartialDerivativeCoefficients({(): {diffops.MultiIndex((2,)): 1.0}}, (2,), ())
+    with pytest.raises(ValueError):
+        diffops.PartialDerivativeCoefficients({(1,): {diffops.MultiIndex((2,)): 1.0}}, (1,), ())
+
+
+def test_operator_classes():
+    lap = diffops.Laplacian((2,))
+    assert lap.coefficients_dict() == {(2, 0): 1.0, (0, 2): 1.0}
+    assert (-0.5 * lap).coefficients_dict() == {(2, 0): -0.5, (0, 2): -0.5}
+    assert (3.0 * (-0.5 * lap)).scalar == pytest.approx(-1.5)
+    assert diffops.WeightedLaplacian([0.0, 2.0]).coefficients_dict() == {(0, 2): 2.0}
+    assert diffops.SpatialLaplacian((3,)).coefficients_dict() == {(0, 2, 0): 1.0, (0, 0, 2): 1.0}
+    assert diffops.TimeDerivative((2,)).coefficients_dict() == {(1, 0): 1.0}
+    assert diffops.HeatOperator((2,), alpha=0.1).coefficients_dict() == {(1, 0): 1.0, (0, 2): -0.1}
+    assert diffops.DirectionalDerivative([0.5, -2.0]).coefficients_dict() == {(1, 0): 0.5, (0, 1): -2.0}
+    assert diffops.Derivative(2).coefficients_dict() == {(2,): 1.0}
+    assert (lap + diffops.TimeDerivative((2,))).coefficients_dict() == {(2, 0): 1.0, (0, 2): 1.0, (1, 0): 1.0}
+    with pytest.raises(ValueError):
+        diffops.HeatOperator(((2, 2)))
+    with pytest.raises(ValueError):
+        diffops.SpatialLaplacian((1,))
+    with pytest.raises(ValueError):
+        diffops.Derivative(-1)
+
+
+def test_lowering_poisson_and_heat():
+    k = 2.0**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=0.5))
+    D = -1.0 * diffops.Laplacian((2,))
+    (g,) = D(D(k, argnum=1), argnum=0).lower()
+    assert g["d"] == 2 and g["scale"] == 4.0 and g["family"] == [1, 1] and g["p"] == [2, 2] and g["lengthscale"] == [1.0, 0.5]
+    assert sorted(g["terms"]) == sorted([(1.0, (2, 0), (2, 0)), (1.0, (2, 0), (0, 2)), (1.0, (0, 2), (2, 0)), (1.0, (0, 2), (0, 2))])
+    (gc,) = D(k, argnum=1).lower()
+    assert sorted(gc["terms"]) == sorted([(-1.0, (0, 0), (2, 0)), (-1.0, (0, 0), (0, 2))])
+    kh = cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
+    H = diffops.HeatOperator((2,), alpha=0.1)
+    (gh,) = H(H(kh, argnum=1), argnum=0).lower()
+    assert {(a, b) for _, a, b in gh["terms"]} == {((1, 0), (1, 0)), ((1, 0), (0, 2)), ((0, 2), (1, 0)), ((0, 2), (0, 2))}
+    # sum kernels give one group per summand, scalars distribute
+    groups = (1.5 * cf.ExpQuad((2,), lengthscales=[0.4, 1.3]) + k).lower()
+    assert len(groups) == 2 and groups[0]["family"] == [2, 2] and groups[0]["scale"] == 1.5
+    # ctypes marshalling
+    arr = _lib.make_kdesc_array(groups)
+    assert arr[1].nterms == 1 and arr[1].p[0] == 2 and arr[0].lengthscale[1] == 1.3
+
+
+def test_lowering_errors():
+    k = cf.TensorProduct(cf.Matern((), nu=1.5), cf.Matern((), nu=2.5))
+    lap = diffops.Laplacian((2,))
+    with pytest.raises(ValueError):           # Matern-3/2 is not 4x differentiable
+        lap(lap(k, argnum=1), argnum=0).lower()
+    with pytest.raises(ValueError):           # dimension mismatch
+        diffops.Laplacian((3,))(k, argnum=0)
+    with pytest.raises(NotImplementedError):  # no closed form for non-half-integer nu
+        cf.Matern((), nu=2.2)
+    with pytest.raises(NotImplementedError):  # multivariate isotropic Matern: not on this path
+        cf.Matern((2,), nu=2.5)
+    with pytest.raises(ValueError):
+        cf.TensorProduct(cf.Matern((1,), nu=2.5))
+    with pytest.raises(ValueError):
+        cf.ExpQuad((2,), lengthscales=[1.0, -1.0])
+
+
+def test_functionals_and_shapes():
+    X = np.zeros((4, 3, 2))
+    L = diffops.Laplacian((2,)).to_linfunctl(X)
+    assert L.output_shape == (4, 3) and L.points().shape == (12, 2)
+    assert L.coefficients_dict() == {(2, 0): 1.0, (0, 2): 1.0}
+    ev = lp.linfunctls._EvaluationFunctional((2,), (), X)
+    assert ev.coefficients_dict() == {(0, 0): 1.0}
+    assert np.array_equal(ev(lp.functions.Constant((2,), 3.0)), np.full((4, 3), 3.0))
+    assert np.array_equal(L(lp.functions.Constant((2,), 3.0)), np.zeros((4, 3)))
+    with pytest.raises(ValueError):
+        lp.linfunctls._EvaluationFunctional((2,), (), np.zeros((4, 3)))
+    with pytest.raises(ValueError):
+        lp.GaussianProcess(lp.functions.Zero((2,)), cf.Matern((1,), nu=2.5))
+    with pytest.raises(TypeError):
+        lp.GaussianProcess(lambda x: x, cf.Matern((1,), nu=2.5))
+
+
+def test_normal_randvar():
+    n = lp.randvars.Normal(np.zeros(3), 0.25)
+    assert np.array_equal(n.cov, 0.25 * np.eye(3)) and np.array_equal(n.cov_diag, np.full(3, 0.25))
+    d = lp.randvars.Normal(np.zeros(3), np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(d.var, [1.0, 2.0, 3.0]) and d.cov.shape == (3, 3)
+    full = lp.randvars.Normal(np.zeros(2), np.array([[2.0, 0.5], [0.5, 1.0]]))
+    assert full.cov_diag is None and np.allclose(full.std, np.sqrt([2.0, 1.0]))
+    with pytest.raises(ValueError):
+        lp.randvars.Normal(np.zeros(3), np.eye(2))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every evaluation raises (there is no CPU path in the product)."""
+    import ctypes
+    ndev = ctypes.c_int(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipGetDeviceCount(ctypes.byref(ndev))
+    except OSError:
+        rc, ndev = 1, ctypes.c_int(0)
+    if rc == 0 and ndev.value > 0:
+        pytest.skip("a GPU is visible")
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.Matern((1,), nu=2.5))
+    with pytest.raises(_lib.LpgpError):
+        prior.condition_on_observations(np.zeros(2), np.array([[0.0], [1.0]]))
