@@ -10,8 +10,9 @@ weights) + prediction (cross-covariance assembly, posterior mean, marginal varia
 Point sets are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 N > 1 (launched by `python -m torch.distributed.run`, env RANK/LOCAL_RANK/WORLD_SIZE/
-MASTER_ADDR/MASTER_PORT): one process per GPU.  This round every rank conditions its own
-independent c3 problem ("scaling": "weak"; no data-path collective) -- see DESIGN.md §7.
+MASTER_ADDR/MASTER_PORT): one process per GPU, all ranks factor ONE problem: panels of 512
+columns are owned cyclically by rank and broadcast with RCCL; "scaling":
+"strong".  LPGP_BENCH_REPLICAS=1 runs one independent problem per rank instead ("weak").
 The product path never imports torch; ranks rendezvous over a plain TCP star.
 """
 import argparse
@@ -78,6 +79,9 @@ def main():
 
     comm = _dist.Comm.from_env()
     ctx = _engine.default_context()          # device = LOCAL_RANK
+    replicas = bool(int(os.environ.get("LPGP_BENCH_REPLICAS", "0")))
+    if world > 1 and not replicas:
+        ctx.dist_init(comm)                  # RCCL communicator: distributed factorisation of ONE problem
     info = ctx.device_info()
 
     wl = problems.poisson_2d(n_side=args.n_side, m_side=args.m_side)
@@ -110,7 +114,8 @@ def main():
         return
     ms_per_step = dt / args.steps * 1e3
     flops = wl.total_flops()
-    value = world * flops / (dt / args.steps) / 1e9
+    # distributed: all ranks work on ONE problem (strong scaling); replicas: one problem per rank
+    value = (world if replicas else 1) * flops / (dt / args.steps) / 1e9
 
     syrk = prof["syrk_trailing"]
     asm = prof["assemble"]
@@ -124,7 +129,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (replicas and world > 1) else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -136,7 +141,10 @@ def main():
             "m_predict": int(wl.Xtest.shape[0]),
             "boundary_noise_var": 1e-8,
             "algorithmic_flops_per_step": flops,
-            "multi_gpu": "independent replicas (one c3 problem per GPU)" if world > 1 else "single GPU",
+            "multi_gpu": ("single GPU" if world == 1 else
+                          "independent replicas (one problem per GPU)" if replicas else
+                          f"one problem, panels of 512 columns owned cyclically by {world} ranks (1x{world} grid), "
+                          "RCCL panel broadcast, replicated factor, prediction points sharded"),
             "device": info["name"].strip(),
         },
         "roofline": {

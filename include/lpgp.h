@@ -64,6 +64,17 @@ int  lpgp_sync(lpgp_ctx* ctx);                       /* hipDeviceSynchronize */
  * blocked Cholesky (multiple of 128) and look-ahead on/off                              */
 int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
+ * Panels of the blocked Cholesky (nb columns) are owned cyclically by rank (a 1 x P
+ * block-cyclic process grid); the owner factors a panel and broadcasts it (ncclBroadcast)
+ * while every rank applies it to the columns it owns.  Received panels are kept, so every
+ * rank ends with the full factor and prediction needs no further communication.  Rank 0
+ * creates the id, the caller ships the 128 bytes to the other ranks (any control plane),
+ * every rank then calls lpgp_dist_init before its first lpgp_gram_assemble.               */
+int  lpgp_dist_unique_id(char* out128);
+int  lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128);
+int  lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world);
+
 /* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) ----- */
 int  lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out);
 int  lpgp_pts_destroy(lpgp_pts* pts);

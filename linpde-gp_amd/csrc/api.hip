@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rccl/rccl.h>
+
 #include "lpgp_internal.h"
 
 namespace lpgp {
@@ -303,6 +305,8 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipFree(ctx->d_desc);
   (void)hipFree(ctx->d_info);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+  if (ctx->nccl_comm) (void)ncclCommDestroy((ncclComm_t)ctx->nccl_comm);
   for (auto& b : ctx->pool) (void)hipFree(b.p);
   ctx->pool.clear();
   (void)hipStreamDestroy(ctx->s_main);
@@ -337,6 +341,38 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   } else {
     LPGP_CHECK(false, "unknown option %s", key);
   }
+  return 0;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------
+int lpgp_dist_unique_id(char* out128) {
+  LPGP_CHECK(out128 != nullptr, "lpgp_dist_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  LPGP_CHECK(r == ncclSuccess, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+  std::memcpy(out128, &id, 128);
+  return 0;
+}
+
+int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128) {
+  LPGP_CHECK(ctx && uid128 && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init: bad argument");
+  LPGP_CHECK(ctx->nccl_comm == nullptr, "lpgp_dist_init: already initialised");
+  LPGP_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, uid128, 128);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+  LPGP_CHECK(r == ncclSuccess, "ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r));
+  ctx->nccl_comm = comm;
+  ctx->rank = rank;
+  ctx->world = world;
+  return 0;
+}
+
+int lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world) {
+  if (rank) *rank = ctx->rank;
+  if (world) *world = ctx->world;
   return 0;
 }
 
@@ -441,8 +477,13 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   DevDesc desc;
   int rc = lower_kdesc(kd, ngroups, &desc);
   if (rc != 0) return rc;
+  // distributed factorisation: a rank assembles only the columns of the panels it will factor
+  // (the others arrive as factored panels); columns that are already factored (cross blocks of
+  // a block append) are needed by every rank
+  OwnFilter own;
+  own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
   rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->cap,
-                       Bi.poff, Bj.poff, sym ? 1 : 0);
+                       Bi.poff, Bj.poff, sym ? 1 : 0, own);
   if (rc != 0) return rc;
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));   // desc is a stack object
   return 0;
@@ -507,7 +548,9 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   if (info) *info = 0;
   if (mat->pn_fact == mat->pn) return 0;
   int32_t h = 0;
-  int rc = potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
+  int rc = (ctx->nccl_comm != nullptr)
+               ? potrf_blocked_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
+               : potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
   if (rc != 0) return rc;
   if (info) *info = h;
   if (h == 0) mat->pn_fact = mat->pn;

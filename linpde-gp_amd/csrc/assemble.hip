@@ -182,6 +182,8 @@ struct AsmArgs {
   int64_t row_off, col_off;
   int32_t lower_only;           // symmetric diagonal block: skip tiles strictly above diagonal
   int32_t tiles_r, tiles_c;
+  int32_t own_world, own_rank;  // distributed factorisation: only tile columns of panels owned by this rank
+  int64_t own_from, own_width;
 };
 
 template <int D>
@@ -286,6 +288,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
   const int tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
   if (a.lower_only && c0 > r0 + AT - 1) return;
+  if (a.own_world > 1) {
+    const int64_t gc = a.col_off + c0;
+    if (gc >= a.own_from && (int)(((gc - a.own_from) / a.own_width) % a.own_world) != a.own_rank) return;
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // stage column coordinates
   if (threadIdx.x < AT) {
@@ -330,11 +336,13 @@ __global__ void add_dense_lower_kernel(double* a, int64_t ld, int64_t off, int64
 
 int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
-                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only) {
+                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
+                    const OwnFilter& own) {
   LPGP_HIP(hipMemcpyAsync(ctx->d_desc, &host_desc, sizeof(DevDesc), hipMemcpyHostToDevice, stream));
   AsmArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
+  a.own_world = own.world; a.own_rank = own.rank; a.own_from = own.from; a.own_width = own.width;
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;

@@ -95,6 +95,11 @@ struct lpgp_ctx {
   // of a multi-GB Gram matrix costs more than the factorisation of a small problem)
   struct PoolBuf { void* p; size_t bytes; };
   std::vector<PoolBuf> pool;
+  // multi-GPU (one process per GPU): cyclic panel ownership + RCCL panel broadcast
+  int rank = 0, world = 1;
+  void* nccl_comm = nullptr;       // ncclComm_t
+  double* d_pack = nullptr;        // packed panel staging for the broadcast
+  size_t pack_cap = 0;             // doubles
   // profiling
   int prof_on = 0;
   lpgp::ProfSlot prof[LPGP_K_COUNT];
@@ -174,14 +179,23 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base);
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
+int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp);
 
 // assemble.hip ----------------------------------------------------------------------------
+// own_*: column ownership filter of the distributed factorisation: 64-wide tile columns whose
+// padded column index c >= own_from belong to panel (c - own_from) / own_width, owned by rank
+// panel % own_world; tiles of other ranks are skipped (own_world <= 1: no filter).
+struct OwnFilter {
+  int32_t world = 1, rank = 0;
+  int64_t from = 0, width = 512;
+};
 int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
-                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only);
+                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
+                    const OwnFilter& own = OwnFilter());
 int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar);
 int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b);
 

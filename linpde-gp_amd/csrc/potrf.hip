@@ -14,6 +14,8 @@
 
 #include <climits>
 
+#include <rccl/rccl.h>
+
 #include "lpgp_internal.h"
 
 namespace lpgp {
@@ -336,6 +338,171 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   int h_info = 0;
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
+  if (info) *info = h_info;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Distributed factorisation, one process per GPU.  Process grid 1 x P:
+// panel i (nb columns, counted from the first unfactored tile) is owned by rank i % P.
+//   owner:      factors the panel (same kernels as above), packs  [L panel | tile inverses]
+//               and broadcasts it (ncclBroadcast over xGMI);
+//   every rank: unpacks received panels in place (so it ends with the FULL factor and all
+//               tile inverses -> triangular solves and prediction need no communication) and
+//               applies the rank-nb update only to the panel columns it owns.
+// Look-ahead: the owner of panel k+1 updates that panel's columns first on the panel stream,
+// factors and broadcasts it while its update stream (and everybody else's) still applies
+// panel k.  The only collective is the panel broadcast; message size (T-p0)*128*nb*8 B
+// (c4: up to 272 MB), total received per rank ~ 4 N^2 bytes.
+// ---------------------------------------------------------------------------------------
+static int ensure_pack(lpgp_ctx* ctx, size_t doubles) {
+  if (doubles <= ctx->pack_cap) return 0;
+  if (ctx->d_pack) LPGP_HIP(hipFree(ctx->d_pack));
+  ctx->d_pack = nullptr;
+  ctx->pack_cap = 0;
+  LPGP_HIP(hipMalloc(&ctx->d_pack, doubles * sizeof(double)));
+  ctx->pack_cap = doubles;
+  return 0;
+}
+
+#define LPGP_NCCL(expr)                                                                    \
+  do {                                                                                     \
+    ncclResult_t _r = (expr);                                                              \
+    if (_r != ncclSuccess) {                                                               \
+      ::lpgp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      return -3;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
+  const int T = (int)T64, t_done = (int)t_done64;
+  const int64_t ld = mat->cap;
+  double* a = mat->a;
+  const int nbt = (int)(ctx->nb / TILE);
+  const int64_t tb = TILE;
+  const int P = ctx->world, me = ctx->rank;
+  ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+  hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
+  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
+  auto owner_of = [&](int p0) { return ((p0 - t_done) / nbt) % P; };
+
+  // ---- phase A (append): every rank pushes the new rows through the factored columns
+  //      (replicated: n_new * n_old^2 flops), but updates only the new columns it owns ----
+  if (t_done > 0 && T > t_done) {
+    const int mnew = T - t_done;
+    double* rows = a + (int64_t)t_done * tb;
+    for (int p0 = 0; p0 < t_done; p0 += nbt) {
+      const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
+      for (int jt = p0; jt < p1; ++jt) {
+        double* X = rows + (int64_t)jt * tb * ld;
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(X, ld, mat->linv + (int64_t)jt * tb * tb, tb, X, ld, mnew, 1, TILE, 1.0, 0.0, 0),
+                             LPGP_K_TRSM));
+        if (jt + 1 < p1)
+          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                               mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
+                                  rows + (int64_t)(jt + 1) * tb * ld, ld, mnew, p1 - jt - 1, TILE, -1.0, 1.0, 0),
+                               LPGP_K_GEMM));
+      }
+      const int K = (p1 - p0) * TILE;
+      double* Xp = rows + (int64_t)p0 * tb * ld;
+      if (p1 < t_done)
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(Xp, ld, a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld,
+                                rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+      for (int q0 = t_done; q0 < T; q0 += nbt) {           // owned panels of the new region
+        if (owner_of(q0) != me) continue;
+        const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
+        const double* Xq = a + (int64_t)q0 * tb + (int64_t)p0 * tb * ld;
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(Xq, ld, Xq, ld, a + (int64_t)q0 * tb * (ld + 1), ld, T - q0, q1 - q0, K, -1.0, 1.0, 1),
+                             LPGP_K_SYRK));
+      }
+    }
+  }
+
+  // ---- phase B ----
+  int it = 0;
+  bool have_upd_event = false;
+  for (int p0 = t_done; p0 < T; p0 += nbt, ++it) {
+    const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
+    const int own = owner_of(p0);
+    const int rows = (T - p0) * TILE, cols = (p1 - p0) * TILE;
+    const size_t cnt = (size_t)rows * cols + (size_t)(p1 - p0) * TILE * TILE;
+    LPGP_TRY(ensure_pack(ctx, cnt));
+    double* pk = ctx->d_pack;
+    double* panel = a + (int64_t)p0 * tb * (ld + 1);
+    double* linv0 = mat->linv + (int64_t)p0 * tb * tb;
+    if (own == me) {
+      for (int jt = p0; jt < p1; ++jt) {
+        double* dj = a + (int64_t)jt * tb * (ld + 1);
+        double* linv = mat->linv + (int64_t)jt * tb * tb;
+        LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
+        if (jt + 1 < T) {
+          double* X = dj + tb;
+          LPGP_TRY(launch_gemm(ctx, sP, 0, 0, mk(X, ld, linv, tb, X, ld, T - jt - 1, 1, TILE, 1.0, 0.0, 0),
+                               LPGP_K_TRSM));
+          if (jt + 1 < p1)
+            LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                                 mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
+                                    p1 - jt - 1, TILE, -1.0, 1.0, 1),
+                                 LPGP_K_GEMM));
+        }
+      }
+      LPGP_HIP(hipMemcpy2DAsync(pk, (size_t)rows * sizeof(double), panel, (size_t)ld * sizeof(double),
+                                (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyDeviceToDevice, sP));
+      LPGP_HIP(hipMemcpyAsync(pk + (size_t)rows * cols, linv0, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
+                              hipMemcpyDeviceToDevice, sP));
+    }
+    LPGP_NCCL(ncclBroadcast(pk, pk, cnt, ncclDouble, own, comm, sP));
+    if (own != me) {
+      LPGP_HIP(hipMemcpy2DAsync(panel, (size_t)ld * sizeof(double), pk, (size_t)rows * sizeof(double),
+                                (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyDeviceToDevice, sP));
+      LPGP_HIP(hipMemcpyAsync(linv0, pk + (size_t)rows * cols, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
+                              hipMemcpyDeviceToDevice, sP));
+    }
+    if (p1 >= T) break;
+    const int K = cols;
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
+    // (a) look-ahead: the owner of the next panel brings its columns up to date on the panel stream
+    const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
+    if (owner_of(p1) == me) {
+      if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
+      const double* P1 = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                           mk(P1, ld, P1, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+    }
+    // (b) the other owned panels on the update stream
+    LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+    for (int q0 = p2; q0 < T; q0 += nbt) {
+      if (owner_of(q0) != me) continue;
+      const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
+      const double* Pq = a + (int64_t)q0 * tb + (int64_t)p0 * tb * ld;
+      LPGP_TRY(launch_gemm(ctx, sU, 0, 0,
+                           mk(Pq, ld, Pq, ld, a + (int64_t)q0 * tb * (ld + 1), ld, T - q0, q1 - q0, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+    }
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+    have_upd_event = true;
+    // the pack buffer is reused by the next broadcast: the panel stream must not overwrite it while
+    // this rank's unpack is still running -- both are on sP, in order.
+  }
+  LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+  LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
+  int h_info = 0;
+  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
+  LPGP_HIP(hipStreamSynchronize(sP));
+  // a failed pivot is detected by the panel's owner only: agree on it (max over ranks)
+  {
+    int* d = ctx->d_info;
+    LPGP_HIP(hipMemcpyAsync(d, &h_info, sizeof(int), hipMemcpyHostToDevice, sP));
+    LPGP_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMax, comm, sP));
+    LPGP_HIP(hipMemcpyAsync(&h_info, d, sizeof(int), hipMemcpyDeviceToHost, sP));
+    LPGP_HIP(hipStreamSynchronize(sP));
+  }
   if (info) *info = h_info;
   return 0;
 }

@@ -24,6 +24,24 @@ class Context:
         check(lib.lpgp_init(int(device), C.byref(h)), "lpgp_init")
         self._h = h
         self.device = int(device)
+        self.rank, self.world, self.comm = 0, 1, None
+
+    def dist_init(self, comm) -> None:
+        """Join the RCCL communicator of a one-process-per-GPU job.  `comm` is the control
+        plane (`_dist.Comm`): rank 0 creates the unique id, everybody receives it, then
+        `ncclCommInitRank`.  From here on `GramMatrix.assemble/potrf` run the distributed
+        factorisation (cyclic panel ownership, replicated factor)."""
+        if comm.world == 1 and not os.environ.get("LPGP_FORCE_RCCL"):
+            self.comm = comm
+            return
+        uid = None
+        if comm.rank == 0:
+            buf = C.create_string_buffer(128)
+            check(lib.lpgp_dist_unique_id(buf), "lpgp_dist_unique_id")
+            uid = buf.raw
+        uid = comm.bcast(uid)
+        check(lib.lpgp_dist_init(self._h, comm.rank, comm.world, uid), "lpgp_dist_init")
+        self.rank, self.world, self.comm = comm.rank, comm.world, comm
 
     def close(self):
         if self._h:

@@ -63,6 +63,9 @@ def _load() -> C.CDLL:
     sig("lpgp_device_info", C.c_int, vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64))
     sig("lpgp_sync", C.c_int, vp)
     sig("lpgp_set_option", C.c_int, vp, C.c_char_p, i64)
+    sig("lpgp_dist_unique_id", C.c_int, C.c_char_p)
+    sig("lpgp_dist_init", C.c_int, vp, i32, i32, C.c_char_p)
+    sig("lpgp_dist_info", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
     sig("lpgp_pts_create", C.c_int, vp, pd, i64, i32, C.POINTER(vp))
     sig("lpgp_pts_destroy", C.c_int, vp)
     sig("lpgp_mat_create", C.c_int, vp, i64, C.POINTER(vp))
@@ -100,7 +103,7 @@ lib = _load()
 
 EXPORTED = [
     "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
-    "lpgp_set_option", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
+    "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_rhs_create", "lpgp_rhs_destroy",

@@ -287,16 +287,33 @@ class ConditionalGaussianProcess(GaussianProcess):
         return c0 * np.asarray(m(x), dtype=np.double).reshape(-1)
 
     def predict(self, x, *, return_var: bool = True):
-        """Posterior mean and marginal variance at `x` in one pass over the factor."""
+        """Posterior mean and marginal variance at `x` in one pass over the factor.
+
+        In a multi-GPU job every rank holds the full factor, so the prediction points are
+        simply sharded over the ranks (contiguous slices) and the results gathered over the
+        control plane; every rank returns the full arrays."""
         self._check_current()
         X, batch = self._flat(x)
-        pts = _engine.as_points(self._state.ctx, x, X)
-        rhs = self._cross(pts)
-        pm = self._prior_mean_at(x, X.shape[0])
-        kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None
-        mean, var = rhs.predict(pm, kxx, want_mean=True, want_var=return_var)
+        ctx = self._state.ctx
+        if ctx.world > 1 and X.shape[0] >= ctx.world:
+            bounds = np.linspace(0, X.shape[0], ctx.world + 1).astype(int)
+            lo, hi = bounds[ctx.rank], bounds[ctx.rank + 1]
+            m_loc, v_loc = self._predict_local(None, X[lo:hi], return_var)
+            parts = ctx.comm.allgather((m_loc, v_loc))
+            mean = np.concatenate([p[0] for p in parts]).reshape(batch)
+            if not return_var:
+                return mean
+            return mean, np.concatenate([p[1] for p in parts]).reshape(batch)
+        mean, var = self._predict_local(x, X, return_var)
         mean = mean.reshape(batch)
         return (mean, var.reshape(batch)) if return_var else mean
+
+    def _predict_local(self, x_original, X, return_var):
+        pts = _engine.as_points(self._state.ctx, x_original, X)
+        rhs = self._cross(pts)
+        pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])
+        kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None
+        return rhs.predict(pm, kxx, want_mean=True, want_var=return_var)
 
     def var(self, x):
         return self.predict(x, return_var=True)[1]

@@ -53,3 +53,113 @@ def test_comm_world2_matches_gloo():
         assert p.exitcode == 0
     for rank, mx, uid, ag, gl in res:
         assert mx == 11.0 == gl and uid == b"\x01\x02" and ag == [0, 2]
+
+
+# ---- model of the distributed factorisation (csrc/potrf.hip: potrf_blocked_dist) ------------
+def _model_potrf_dist(A, t_done, T, nbt, tile, rank, world, bcast):
+    """NumPy mirror of potrf_blocked_dist, step for step: cyclic panel ownership, owner factors
+    + broadcasts, everybody unpacks, only owned panels are updated.  `A` holds valid data only in
+    the (unfactored) columns this rank owns and in the already factored columns."""
+    import numpy as np
+    import scipy.linalg as sla
+    tb = tile
+    owner_of = lambda p0: ((p0 - t_done) // nbt) % world
+    # phase A (append): replicated push of the new rows through the old columns
+    if t_done > 0 and T > t_done:
+        r0 = t_done * tb
+        for p0 in range(0, t_done, nbt):
+            p1 = min(p0 + nbt, t_done)
+            c0, c1 = p0 * tb, p1 * tb
+            Lpp = np.tril(A[c0:c1, c0:c1])
+            X = sla.solve_triangular(Lpp, A[r0:T * tb, c0:c1].T, lower=True).T
+            A[r0:T * tb, c0:c1] = X
+            if p1 < t_done:
+                A[r0:T * tb, c1:t_done * tb] -= X @ A[c1:t_done * tb, c0:c1].T
+            for q0 in range(t_done, T, nbt):
+                if owner_of(q0) != rank:
+                    continue
+                q1 = min(q0 + nbt, T)
+                A[q0 * tb:T * tb, q0 * tb:q1 * tb] -= A[q0 * tb:T * tb, c0:c1] @ A[q0 * tb:q1 * tb, c0:c1].T
+    for p0 in range(t_done, T, nbt):
+        p1 = min(p0 + nbt, T)
+        own = owner_of(p0)
+        c0, c1 = p0 * tb, p1 * tb
+        if own == rank:
+            Lpp = np.linalg.cholesky(A[c0:c1, c0:c1])
+            A[c0:c1, c0:c1] = Lpp
+            if p1 < T:
+                A[c1:T * tb, c0:c1] = sla.solve_triangular(Lpp, A[c1:T * tb, c0:c1].T, lower=True).T
+            pk = np.ascontiguousarray(A[c0:T * tb, c0:c1])
+        else:
+            pk = np.empty((T * tb - c0, c1 - c0))
+        pk = bcast(pk, own)
+        if own != rank:
+            A[c0:T * tb, c0:c1] = pk
+        for q0 in range(p1, T, nbt):
+            if owner_of(q0) != rank:
+                continue
+            q1 = min(q0 + nbt, T)
+            A[q0 * tb:T * tb, q0 * tb:q1 * tb] -= A[q0 * tb:T * tb, c0:c1] @ A[q0 * tb:q1 * tb, c0:c1].T
+    return A
+
+
+def _dist_model_worker(rank, world, gloo_port, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{gloo_port}", rank=rank, world_size=world)
+
+    def bcast(arr, root):
+        t = torch.from_numpy(arr)
+        dist.broadcast(t, src=root)
+        return t.numpy()
+
+    rng = np.random.default_rng(5)               # same matrix on every rank
+    tile, nbt = 8, 2                             # scaled-down tiles; panel = 2 tiles
+    T1, T2 = 5, 12                               # first conditioning: 5 tiles; append up to 12 (ragged vs nbt)
+    n = T2 * tile
+    M = rng.standard_normal((n, n + 10))
+    G = M @ M.T + 0.5 * np.eye(n)
+    ok = True
+    for t_done, T in ((0, T1), (T1, T2)):
+        A = np.full((n, n), np.nan) if t_done == 0 else A
+        owner_of = lambda p0: ((p0 - t_done) // nbt) % world
+        # "assemble": unfactored columns only where owned; cross blocks (factored columns) everywhere
+        for p0 in range(t_done, T, nbt):
+            p1 = min(p0 + nbt, T)
+            if owner_of(p0) == rank:
+                A[p0 * tile:T * tile, p0 * tile:p1 * tile] = G[p0 * tile:T * tile, p0 * tile:p1 * tile]
+        if t_done > 0:
+            A[t_done * tile:T * tile, :t_done * tile] = G[t_done * tile:T * tile, :t_done * tile]
+        A = _model_potrf_dist(A, t_done, T, nbt, tile, rank, world, bcast)
+        L = np.tril(A[:T * tile, :T * tile])
+        ref = np.linalg.cholesky(G[:T * tile, :T * tile])
+        ok = ok and bool(np.all(np.isfinite(L))) and float(np.max(np.abs(L - ref))) < 1e-10
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_cholesky_model_gloo(world):
+    """Every rank must end with the FULL factor although it assembled only its own panels
+    (unowned columns start as NaN: reading one before it is received would poison the result),
+    for a fresh factorisation and for a block append with a ragged last panel."""
+    gloo_port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_model_worker, args=(r, world, gloo_port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def test_predict_sharding_bounds():
+    import numpy as np
+    for n, world in ((4096, 8), (10, 3), (7, 7)):
+        b = np.linspace(0, n, world + 1).astype(int)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and np.diff(b).max() - np.diff(b).min() <= 1

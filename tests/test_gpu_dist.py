@@ -1,0 +1,40 @@
+"""Distributed code path on ONE GPU: world_size 1 through RCCL (ncclCommInitRank, panel
+pack / ncclBroadcast / all-reduce of info) must reproduce the single-GPU factorisation.
+Multi-rank behaviour is modelled on CPU in tests/test_dist_cpu.py (the 8-GPU node is only
+available to the driver)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine, problems
+from oracle import workloads as owl
+os.environ["LPGP_FORCE_RCCL"] = "1"
+comm = _dist.Comm(0, 1)
+ctx = _engine.default_context()
+ctx.dist_init(comm)
+assert ctx.world == 1 and ctx.comm is comm
+wl = problems.poisson_2d(n_side=40, n_bdry=33, m_side=9)      # ragged sizes, 3 panels of 512
+u, mean, var = problems.condition_and_predict(wl)
+ref = owl.run(wl)
+em = np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))
+ev = np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))
+print("DIST1", em, ev)
+assert em < 1e-8 and ev < 1e-8
+"""
+
+
+def test_world1_rccl_path_matches_oracle():
+    out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "DIST1" in out.stdout
