@@ -57,6 +57,16 @@ def cpu_baseline(problems, n_side):
     }
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench_c3_summary.json")) as f:
+            return json.load(f).get("syrk_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,8 +105,7 @@ def main():
 
     for _ in range(args.warmup):
         mean, var = step()
-    ctx.profile_reset()
-    ctx.profile_enable(True)
+    # ---- timed region: exactly K steps, no instrumentation ----
     comm.barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -106,8 +115,26 @@ def main():
     dt = time.perf_counter() - t0
     dt = comm.allreduce_max(dt)
     comm.barrier()
-    prof = ctx.profile_get()
-    ctx.profile_enable(False)
+    # ---- per-kernel HIP-event timing (same process, same workload, right after the timed
+    #      region: event records between launches cost ~25 % wall time, so they stay out of it) ----
+    prof_steps = max(1, min(args.steps, 3))
+
+    def profiled(which):
+        ctx.profile_reset()
+        ctx.profile_enable(which)
+        for _ in range(prof_steps):
+            step()
+        ctx.sync()
+        out_ = ctx.profile_get()
+        ctx.profile_enable(False)
+        for p_ in out_.values():
+            for k_ in ("ms", "launches", "flops", "bytes"):
+                p_[k_] = p_[k_] * (args.steps / prof_steps)
+        return out_
+
+    prof_syrk = profiled(["syrk_trailing"])      # dominant kernel alone: least perturbation
+    prof = profiled(True)                        # every kernel (table)
+    prof["syrk_trailing"] = prof_syrk["syrk_trailing"]
 
     if rank != 0:
         comm.close()
@@ -148,13 +175,13 @@ def main():
             "device": info["name"].strip(),
         },
         "roofline": {
-            "kernel": "gemm_f64_kernel<NT> (rank-nb SYRK trailing update of the blocked Cholesky)",
+            "kernel": "gemm_f64_kernel<false,false,true> (SYRK: rank-nb trailing update + in-panel rank-128 updates of the blocked Cholesky)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": _pmc_traffic(),
             "launches_per_step": syrk["launches"] / max(args.steps, 1),
             "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
         },

@@ -153,7 +153,8 @@ int  lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
 /* ---- measurement: HIP-event timing of the hot kernels on their own streams ---------- */
 enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1, LPGP_K_GEMM = 2,
                       LPGP_K_POTRF_TILE = 3, LPGP_K_TRSM = 4, LPGP_K_COUNT = 5 };
-int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t on);
+/* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
+int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);
 /* accumulated over all launches since reset: device milliseconds (HIP events on the
  * launching stream), launch count, algorithmic flops, algorithmic bytes                */

@@ -34,7 +34,9 @@ static hipEvent_t get_event(lpgp_ctx* ctx) {
 }
 
 void prof_begin(lpgp_ctx* ctx, hipStream_t stream, int kernel, double flops, double bytes) {
-  if (!ctx->prof_on) return;
+  ctx->prof_open = 0;
+  if (!(ctx->prof_on & (1 << kernel))) return;
+  ctx->prof_open = 1;
   PendingEvent p;
   p.e0 = get_event(ctx);
   p.e1 = get_event(ctx);
@@ -47,7 +49,8 @@ void prof_begin(lpgp_ctx* ctx, hipStream_t stream, int kernel, double flops, dou
 }
 
 void prof_end(lpgp_ctx* ctx, hipStream_t stream) {
-  if (!ctx->prof_on) return;
+  if (!ctx->prof_open) return;
+  ctx->prof_open = 0;
   (void)hipEventRecord(ctx->pending.back().e1, stream);
 }
 
@@ -285,6 +288,11 @@ int lpgp_init(int device, lpgp_ctx** out) {
     if (v >= TILE && v % TILE == 0) ctx->nb = v;
   }
   if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_NB_BIG")) {
+    long v = std::atol(e);
+    if (v >= 0 && v % TILE == 0) ctx->nb_big = v;
+  }
+  if (const char* e = std::getenv("LPGP_NB_BIG_MIN_TILES")) ctx->nb_big_min_tiles = std::atoi(e);
   *out = ctx;
   return 0;
 }
@@ -336,6 +344,11 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
+  } else if (std::strcmp(key, "nb_big") == 0) {
+    LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_big must be a multiple of %d (0 disables)", TILE);
+    ctx->nb_big = value;
+  } else if (std::strcmp(key, "nb_big_min_tiles") == 0) {
+    ctx->nb_big_min_tiles = (int)value;
   } else if (std::strcmp(key, "lookahead") == 0) {
     ctx->lookahead = value != 0;
   } else {
@@ -759,9 +772,9 @@ int lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
 }
 
 // ---- measurement ----------------------------------------------------------------------------
-int lpgp_profile_enable(lpgp_ctx* ctx, int32_t on) {
+int lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask) {
   int rc = prof_collect(ctx);
-  ctx->prof_on = on != 0;
+  ctx->prof_on = mask;
   return rc;
 }
 

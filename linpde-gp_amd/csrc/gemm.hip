@@ -88,7 +88,9 @@ __device__ __forceinline__ double lds_read_async(unsigned byte_addr) {
 // per k-step of 4, acc[t][u] (m = 16t + (lane&15), n = 4u + (lane>>4)) += Bfrag4[u] x Afrag[t],
 // where the instruction's four 4x4 blocks share the 4 n-columns (replicated "A" operand) and
 // cover 16 consecutive rows m ("B" operand) -- the same 128-byte-segment C layout as before.
-template <bool TA, bool TB>
+// TRI: lower-triangular output (symmetric rank-k update): a distinct instantiation so that the
+// SYRK launches show up under their own kernel symbol in rocprofv3 --stats.
+template <bool TA, bool TB, bool TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // ---- block -> tile (XCD-aware 8x8 super-tiles) ----
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int xcd = b & 7, q = b >> 3;
   const int s = (q >> 6) * 8 + xcd, inner = q & 63;
   int sr, sc;
-  if (g.tri) {
+  if (TRI) {
     const int ntri = SC * (SC + 1) / 2;             // super-tiles of the leading SC x SC triangle
     if (s < ntri) {
       sr = (int)((sqrtf(8.0f * (float)s + 1.0f) - 1.0f) * 0.5f);
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   if (sr >= SR || sc >= SC) return;
   const int tr = sr * 8 + (inner & 7), tc = sc * 8 + (inner >> 3);
   if (tr >= g.mt || tc >= g.nt) return;
-  if (g.tri && tr < tc) return;
+  if (TRI && tr < tc) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;
@@ -251,23 +253,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int t = 0; t < 4; ++t) cbase[(int64_t)(4 * u) * g.ldc + t * 16] = alpha * acc[t][u];
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   static bool attr_set = false;
   const size_t shmem = (size_t)4 * STAGE * sizeof(double);
   if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB>),
+    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set = true;
   }
   const int SR = (g.mt + 7) / 8, SC = (g.nt + 7) / 8;
   int nsuper = SR * SC;
-  if (g.tri) {
+  if (TRI) {
     LPGP_CHECK(g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
     nsuper = SC * (SC + 1) / 2 + (SR - SC) * SC;
   }
   const int64_t blocks = (int64_t)((nsuper + 7) / 8) * 8 * 64;
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB>), dim3((unsigned)blocks), dim3(256), shmem, stream, g);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)blocks), dim3(256), shmem, stream, g);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
@@ -275,18 +277,20 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel) {
   if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return 0;
   LPGP_CHECK(g.k % BK == 0, "gemm: k=%d not a multiple of %d", g.k, BK);
+  LPGP_CHECK(!g.tri || (!ta && !tb), "gemm: the triangular update exists for the NT form only");
   if (prof_kernel >= 0) {
+    if (g.tri) prof_kernel = LPGP_K_SYRK;        // one profiling slot == one kernel symbol
     const double m = (double)g.mt * BM, n = (double)g.nt * BN, k = (double)g.k;
-    // algorithmic flops: symmetric update counts the lower triangle only
     // algorithmic flops: a symmetric update counts the lower trapezoid (m >= n) only
     const double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
     prof_begin(ctx, stream, prof_kernel, flops, 0.0);
   }
   int rc;
-  if (!ta && !tb) rc = launch_impl<false, false>(ctx, stream, g);
-  else if (!ta && tb) rc = launch_impl<false, true>(ctx, stream, g);
-  else if (ta && !tb) rc = launch_impl<true, false>(ctx, stream, g);
-  else rc = launch_impl<true, true>(ctx, stream, g);
+  if (g.tri) rc = launch_impl<false, false, true>(ctx, stream, g);
+  else if (!ta && !tb) rc = launch_impl<false, false, false>(ctx, stream, g);
+  else if (!ta && tb) rc = launch_impl<false, true, false>(ctx, stream, g);
+  else if (ta && !tb) rc = launch_impl<true, false, false>(ctx, stream, g);
+  else rc = launch_impl<true, true, false>(ctx, stream, g);
   if (prof_kernel >= 0) prof_end(ctx, stream);
   return rc;
 }

@@ -85,6 +85,8 @@ struct lpgp_ctx {
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};
   int64_t nb = 512;                // panel width of the blocked Cholesky
+  int64_t nb_big = 0;              // optional wider panels while more than nb_big_min_tiles tile rows remain (0 = off; measured: no gain at c3)
+  int nb_big_min_tiles = 96;
   int lookahead = 1;
   // workspace
   lpgp::DevDesc* d_desc = nullptr; // device copy of the current descriptor
@@ -101,7 +103,8 @@ struct lpgp_ctx {
   double* d_pack = nullptr;        // packed panel staging for the broadcast
   size_t pack_cap = 0;             // doubles
   // profiling
-  int prof_on = 0;
+  int prof_on = 0;                 // bit k: bracket launches of kernel id k with HIP events
+  int prof_open = 0;
   lpgp::ProfSlot prof[LPGP_K_COUNT];
   std::vector<lpgp::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

@@ -58,11 +58,19 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   const int r16 = lane & 15, g = lane >> 4, l3 = lane & 3;
   const int wu = __builtin_amdgcn_readfirstlane(wid);
 
+#ifdef LPGP_TILE_STAMP
+  unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tA_, tB_;
+#define TSTAMP(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_) :: "memory"); ts_[i] += tB_ - tA_; tA_ = tB_; } while (0)
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_) :: "memory");
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
   // ---- load tile: one 1-KiB LDS-DMA piece per column ----
   for (int c = wu; c < TILE; c += 4)
     __builtin_amdgcn_global_load_lds((gptr_t)(a + (int64_t)c * lda + 2 * lane), (lptr_t)(s + c * TL), 16, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  TSTAMP(0);
 
   for (int jb = 0; jb < 8; ++jb) {
     const int j0 = jb * 16;
@@ -72,8 +80,13 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       const int i = r16;
 #pragma unroll
       for (int k = 0; k < 16; ++k) row[k] = s[(j0 + k) * TL + j0 + i];
-      double invd[16];
       int bad = 0;
+      // Factorisation and inversion share one pivot loop: column c of X = L^{-1} (lane c) needs
+      // row j of L, which is final right after pivot step j, so the two recurrences are
+      // interleaved and overlap in the instruction stream (the pivot chain
+      // readlane -> rsq -> scale -> readlane is latency bound).
+      double x[16];
+      const int c = r16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double piv = bcast_lane(row[j], j);
@@ -81,14 +94,19 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
           if (!bad) bad = j0 + j + 1;
           piv = 1.0;
         }
-        // inv = piv^{-1/2} (hardware estimate + two Newton steps), l = piv * inv
+        // inv = piv^{-1/2}: hardware estimate + one Newton step; l = piv*inv refined once more
         double inv = __builtin_amdgcn_rsq(piv);
-        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
-        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+        inv = fma(inv, 0.5 * fma(-piv * inv, inv, 1.0), inv);
         double l = piv * inv;
-        l = fma(0.5 * inv, fma(-l, l, piv), l);           // one Newton step on l: correctly rounded in practice
-        invd[j] = inv;
+        const double res = fma(-l, l, piv);
+        l = fma(0.5 * inv, res, l);
+        inv = fma(inv, -0.5 * inv * inv * res, inv);       // keep inv consistent with the refined l
         row[j] = (i == j) ? l : row[j] * inv;
+        // x[j] = (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]   (row j of L is final now)
+        double acc = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) acc = fma(-bcast_lane(row[k], j), x[k], acc);
+        x[j] = (j >= c) ? acc * inv : 0.0;
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
           const double lkj = bcast_lane(row[j], k);
@@ -96,16 +114,6 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
         }
       }
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
-      // inverse: lane c computes column c of X = L^{-1}
-      double x[16];
-      const int c = r16;
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) {
-        double acc = (ii == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < ii; ++k) acc = fma(-bcast_lane(row[k], ii), x[k], acc);
-        x[ii] = (ii >= c) ? acc * invd[ii] : 0.0;
-      }
       if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       }
     }
     __syncthreads();
+    TSTAMP(1);
     // ---- (b) panel below: X_ib = A_ib * Linv^T  (in place) ----
     for (int ib = jb + 1 + wid; ib < 8; ib += 4) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       for (int q = 0; q < 4; ++q) s[(j0 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
     }
     __syncthreads();
+    TSTAMP(2);
     // ---- (c) trailing update inside the tile: A_ib,kb -= X_ib X_kb^T, jb < kb <= ib ----
     const int cnt = 7 - jb;
     const int npairs = cnt * (cnt + 1) / 2;
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       for (int q = 0; q < 4; ++q) s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
     }
     __syncthreads();
+    TSTAMP(3);
   }
 
   // ---- inverse of the whole tile by block forward substitution; X_ij (i>j) is kept
@@ -188,6 +199,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     __syncthreads();
   }
 
+  TSTAMP(4);
   // ---- write back L (zeros above the diagonal) and Linv ----
   for (int c = wid; c < TILE; c += 4) {
 #pragma unroll
@@ -201,6 +213,11 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       linv[c * TILE + r] = xv;
     }
   }
+#ifdef LPGP_TILE_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSTAMP(5);
+  if (tid == 0) for (int i = 0; i < 6; ++i) g_stamps[i] = ts_[i];
+#endif
 }
 
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
@@ -278,11 +295,20 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   }
 
   // ---- phase B: right-looking with look-ahead ----
+  // Panel width schedule: while the trailing matrix is large the pipeline is bound by the
+  // SYRK update, whose efficiency grows with K (46 TFLOP/s at K = 512, ~52 at K = 1024, in
+  // situ), and the longer panel chain hides behind it; once the update gets short the
+  // pipeline is bound by the panel chain and the narrow panel wins.
   const bool la = ctx->lookahead != 0;
+  auto width_at = [&](int p0) {
+    const int rem = T - p0;
+    return (ctx->nb_big > ctx->nb && rem > ctx->nb_big_min_tiles) ? (int)(ctx->nb_big / TILE) : nbt;
+  };
   int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
   int it = 0;
-  for (int p0 = t_done; p0 < T; p0 += nbt, ++it) {
-    const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
+  for (int p0 = t_done; p0 < T; ++it) {
+    const int w0 = width_at(p0);
+    const int p1 = (p0 + w0 < T) ? p0 + w0 : T;
     // panel factorisation on sP
     for (int jt = p0; jt < p1; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
@@ -306,9 +332,11 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
       LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                            mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, T - p1, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
+      p0 = p1;
       continue;
     }
-    const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
+    const int w1 = width_at(p1);
+    const int p2 = (p1 + w1 < T) ? p1 + w1 : T;
     // panel done -> the remainder update may start
     hipEvent_t evp = ctx->ev_panel[it & 1];
     LPGP_HIP(hipEventRecord(evp, sP));
@@ -329,6 +357,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     } else {
       have_upd_event = 0;
     }
+    p0 = p1;
   }
   if (la) {
     // join: sP must not run ahead of outstanding sU work
@@ -508,31 +537,65 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
 }
 
 // V <- L^{-1} V for a padded (T*128) x m_pad block, column-major with leading dim ldv.
+// Right-looking by panels with the same look-ahead as the factorisation: the latency-bound
+// tile steps of panel p+1 (products with tile inverses, K = 128) run on the panel stream while
+// the update stream still applies panel p to the rows below.
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
   const int T = (int)T64;
   const int64_t ld = mat->cap, tb = TILE;
   const int mtl = (int)(m_pad / TILE);
   const int nbt = (int)(ctx->nb / TILE);
   const double* a = mat->a;
-  hipStream_t st = ctx->s_main;
-  for (int p0 = 0; p0 < T; p0 += nbt) {
+  const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
+  hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd : ctx->s_main;
+  bool have_upd_event = false;
+  int it = 0;
+  for (int p0 = 0; p0 < T; p0 += nbt, ++it) {
     const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
     for (int jt = p0; jt < p1; ++jt) {
       double* Vj = v + (int64_t)jt * tb;
-      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                            mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
                            LPGP_K_TRSM));
       if (jt + 1 < p1)
-        LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                              mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, ldv,
                                 v + (int64_t)(jt + 1) * tb, ldv, p1 - jt - 1, mtl, TILE, -1.0, 1.0, 0),
                              LPGP_K_GEMM));
     }
-    if (p1 < T)
-      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
-                           mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, v + (int64_t)p0 * tb, ldv,
-                              v + (int64_t)p1 * tb, ldv, T - p1, mtl, (p1 - p0) * TILE, -1.0, 1.0, 0),
+    if (p1 >= T) break;
+    const int K = (p1 - p0) * TILE;
+    const double* Vp = v + (int64_t)p0 * tb;
+    if (!la) {
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
+                           mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p1 * tb, ldv,
+                              T - p1, mtl, K, -1.0, 1.0, 0),
                            LPGP_K_GEMM));
+      continue;
+    }
+    const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
+    if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
+    LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
+                         mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p1 * tb, ldv,
+                            p2 - p1, mtl, K, -1.0, 1.0, 0),
+                         LPGP_K_GEMM));
+    if (p2 < T) {
+      LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+      LPGP_TRY(launch_gemm(ctx, sU, 0, 1,
+                           mk(a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p2 * tb, ldv,
+                              T - p2, mtl, K, -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+      have_upd_event = true;
+    } else {
+      have_upd_event = false;
+    }
+  }
+  if (la) {
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
   }
   return 0;
 }

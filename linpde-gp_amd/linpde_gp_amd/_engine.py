@@ -68,8 +68,18 @@ class Context:
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
 
     # ---- measurement ----
-    def profile_enable(self, on: bool = True):
-        check(lib.lpgp_profile_enable(self._h, int(on)), "lpgp_profile_enable")
+    def profile_enable(self, on=True):
+        """`on`: False/0 = off, True = every kernel, or an iterable of kernel names
+        (`_lib.KERNEL_NAMES`) to bracket only those (fewer event records = less perturbation)."""
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            mask = 0
+            for name in on:
+                mask |= 1 << _lib.KERNEL_NAMES.index(name)
+        check(lib.lpgp_profile_enable(self._h, mask), "lpgp_profile_enable")
 
     def profile_reset(self):
         check(lib.lpgp_profile_reset(self._h), "lpgp_profile_reset")

@@ -169,10 +169,10 @@ class ConditionalGaussianProcess(GaussianProcess):
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
         blocks = tuple(old_blocks) + (new_block,)
-        r = np.concatenate([ob.Y - ob.pred_mean for ob in blocks])
-        w = mat.solve_weights(r)
         state.generation += 1
-        return cls(prior=prior, blocks=blocks, state=state, representer_weights=w)
+        # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
+        # in a chain of conditionings only the last object's weights are ever needed
+        return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)
 
     def __init__(self, *, prior, blocks, state, representer_weights, test_coeffs=None):
         self._prior = prior
@@ -195,7 +195,22 @@ class ConditionalGaussianProcess(GaussianProcess):
 
     @property
     def representer_weights(self) -> np.ndarray:
+        """G^{-1}(Y - L[m] - b.mean)  (`_conditional.py:96-110`: computed lazily there too)."""
+        self._ensure_weights()
         return self._representer_weights
+
+    def _ensure_weights(self):
+        if self._representer_weights is None:
+            self._check_current()
+            r = np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
+            self._representer_weights = self._state.mat.solve_weights(r)
+            self._state.weights_generation = self._generation
+        elif getattr(self._state, "weights_generation", None) != self._generation:
+            # the device copy of the weights belongs to another view of the same factor
+            self._check_current()
+            r = np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
+            self._representer_weights = self._state.mat.solve_weights(r)
+            self._state.weights_generation = self._generation
 
     @property
     def prior(self):
@@ -309,6 +324,7 @@ class ConditionalGaussianProcess(GaussianProcess):
         return (mean, var.reshape(batch)) if return_var else mean
 
     def _predict_local(self, x_original, X, return_var):
+        self._ensure_weights()
         pts = _engine.as_points(self._state.ctx, x_original, X)
         rhs = self._cross(pts)
         pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])
@@ -393,12 +409,14 @@ class _PosteriorCovarianceFunction(covfuncs.CovarianceFunction):
 def apply_linfuncop_to_conditional_gp(L, cgp: ConditionalGaussianProcess) -> ConditionalGaussianProcess:
     cgp._check_current()
     coeffs = covfuncs._compose(L.coefficients_dict(), cgp._test_coeffs)
+    cgp._ensure_weights()
     return ConditionalGaussianProcess(
         prior=cgp._prior, blocks=cgp._blocks, state=cgp._state,
         representer_weights=cgp._representer_weights, test_coeffs=coeffs)
 
 
 def apply_linfunctl_to_conditional_gp(L, cgp: ConditionalGaussianProcess) -> randvars.Normal:
+    cgp._ensure_weights()
     view = ConditionalGaussianProcess(
         prior=cgp._prior, blocks=cgp._blocks, state=cgp._state,
         representer_weights=cgp._representer_weights,

@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path.insert(0, ".."); sys.path.insert(0, "../linpde-gp_amd")
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _engine, problems
+from linpde_gp_amd.randprocs import covfuncs
+import linpde_gp_amd.randprocs._gaussian_process as G
+ctx = _engine.default_context()
+wl = problems.poisson_2d(128, m_side=64)
+dev = problems.upload(wl)
+prior = problems.build_prior(wl)
+pts = [d_._lpgp_points for d_ in dev["obs"]]
+coeffs = [o.op for o in wl.observations]
+def build():
+    mat = _engine.GramMatrix(ctx, wl.n_total)
+    for bi in range(5):
+        mat.add_block(pts[bi].n)
+        for bj in range(bi + 1):
+            k = covfuncs.DifferentiatedCovarianceFunction(prior.cov, *G._combine(prior.cov, coeffs[bi], coeffs[bj]))
+            mat.assemble(k.lower(), pts[bi], None if bi == bj else pts[bj], bi, bj)
+        if wl.observations[bi].noise_var: mat.add_diag(bi, None, wl.observations[bi].noise_var)
+    ctx.sync()
+    return mat
