@@ -12,10 +12,10 @@ __version__ = "0.1.0"
 from . import _lib  # noqa: F401  (fails loudly when liblpgp.so is missing)
 from . import config  # noqa: E402
 from ._engine import to_device  # noqa: E402
-from . import functions, linfuncops, linfunctls, randprocs, randvars  # noqa: E402
+from . import domains, functions, linfuncops, linfunctls, problems, randprocs, randvars  # noqa: E402
 from .randprocs import ConditionalGaussianProcess, GaussianProcess  # noqa: E402
 
 __all__ = [
-    "functions", "linfuncops", "linfunctls", "randprocs", "randvars",
+    "domains", "functions", "linfuncops", "linfunctls", "problems", "randprocs", "randvars",
     "GaussianProcess", "ConditionalGaussianProcess", "to_device", "config",
 ]

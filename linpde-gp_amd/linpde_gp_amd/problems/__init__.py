@@ -1,0 +1,20 @@
+"""Problem definitions: the reference's `problems.pde` builders (API surface) and the
+synthetic BASELINE workloads used by bench.py and the tests."""
+
+from . import pde
+from ._workloads import (
+    Observation,
+    Workload,
+    build_prior,
+    condition_and_predict,
+    heat_1d,
+    operator_of,
+    poisson_1d,
+    poisson_2d,
+    upload,
+)
+
+__all__ = [
+    "pde", "Observation", "Workload", "build_prior", "condition_and_predict", "heat_1d",
+    "operator_of", "poisson_1d", "poisson_2d", "upload",
+]

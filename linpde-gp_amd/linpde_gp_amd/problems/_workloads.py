@@ -110,8 +110,8 @@ def heat_1d(nt: int = 512, nx: int = 64, alpha: float = 0.1, m_side: int = 64) -
 # ---- host-object side ------------------------------------------------------------------------
 def build_prior(wl: Workload):
     """The `GaussianProcess` prior of a workload, from the reference-style constructors."""
-    from . import functions
-    from .randprocs import GaussianProcess, covfuncs
+    from .. import functions
+    from ..randprocs import GaussianProcess, covfuncs
 
     total = None
     for scale, factors in wl.kernel:
@@ -135,7 +135,7 @@ def _as_vector_input(k, covfuncs):
 
 def operator_of(op: dict, d: int):
     """`LinearDifferentialOperator` with the given coefficient map (None for plain values)."""
-    from .linfuncops import diffops
+    from ..linfuncops import diffops
 
     if set(op) == {(0,) * d} and op[(0,) * d] == 1.0:
         return None
@@ -148,7 +148,7 @@ def operator_of(op: dict, d: int):
 def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True):
     """The canonical user sequence (`experiments/0001_poisson_dirichlet_2d.ipynb` cells 6-22):
     condition block by block, then posterior mean and marginal variance on the test grid."""
-    from . import randvars
+    from .. import randvars
 
     prior = build_prior(wl) if prior is None else prior
     u = prior
@@ -167,6 +167,6 @@ def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var
 
 def upload(wl: Workload):
     """Make every point set of the workload resident in HBM (outside any timed region)."""
-    from ._engine import to_device
+    from .._engine import to_device
 
     return {"obs": [to_device(o.X) for o in wl.observations], "test": to_device(wl.Xtest)}

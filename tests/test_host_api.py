@@ -148,3 +148,33 @@ def test_no_cpu_fallback():
     prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.Matern((1,), nu=2.5))
     with pytest.raises(_lib.LpgpError):
         prior.condition_on_observations(np.zeros(2), np.array([[0.0], [1.0]]))
+
+
+def test_domains_and_problem_builders():
+    from linpde_gp_amd import domains
+    from linpde_gp_amd.problems import pde
+    box = domains.Box([[-1.0, 1.0], [0.0, 2.0]])
+    assert box.shape == (2,) and len(box.boundary) == 4 and box.volume == 4.0 and [0.0, 1.0] in box
+    g = box.uniform_grid((3, 4))
+    assert isinstance(g, domains.TensorProductGrid) and g.shape == (3, 4, 2) and len(g.factors) == 2
+    np.testing.assert_array_equal(g[:, 0, 0], [-1.0, 0.0, 1.0])
+    edge = box.boundary[0]
+    ge = edge.uniform_grid(5, inset=1e-6)
+    assert ge.shape == (1, 5, 2) and np.all(ge[..., 0] == -1.0) and ge[0, 0, 1] == pytest.approx(1e-6)
+    iv = domains.asdomain([-1.0, 1.0])
+    assert isinstance(iv, domains.Interval) and [float(np.asarray(p)) for p in iv.boundary] == [-1.0, 1.0]
+    np.testing.assert_allclose(iv.uniform_grid(3, inset=0.5), [-0.5, 0.0, 0.5])
+    with pytest.raises(ValueError):
+        domains.Interval(1.0, 0.0)
+    with pytest.raises(ValueError):
+        domains.Box([[0.0, 1.0, 2.0]])
+    bvp = pde.PoissonEquationDirichletProblem(box, rhs=lp.functions.Constant((2,), 2.0))
+    assert bvp.pde.diffop.coefficients_dict() == {(2, 0): -1.0, (0, 2): -1.0} and len(bvp.boundary_conditions) == 4
+    b1 = pde.PoissonEquationDirichletProblem(iv, rhs=lp.functions.Constant((), 2.0), boundary_values=(0.0, 1.0))
+    # -u'' = 2, u(-1) = 0, u(1) = 1  =>  u = (x+1)/2 + (1 - x^2)
+    np.testing.assert_allclose(b1.solution(np.array([-1.0, 0.0, 1.0])), [0.0, 1.5, 1.0])
+    h = pde.HeatEquationDirichletProblem(0.0, iv, T=5.0, alpha=0.1, initial_values=pde.TruncatedSineSeries(iv, [1.0, 2.0]))
+    assert h.pde.diffop.coefficients_dict() == {(1, 0): 1.0, (0, 2): -0.1}
+    assert h.initial_domain.uniform_grid(5).shape == (1, 5, 2)
+    x = np.linspace(-1, 1, 7)
+    np.testing.assert_allclose(h.solution(np.stack([np.zeros(7), x], -1)), h.initial_condition.values(x), atol=1e-14)
