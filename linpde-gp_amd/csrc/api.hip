@@ -344,6 +344,10 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
+  } else if (std::strcmp(key, "min_supertiles") == 0) {
+    ctx->min_supertiles = (int)value;
+  } else if (std::strcmp(key, "solo_small") == 0) {
+    ctx->solo_small = value != 0;
   } else if (std::strcmp(key, "nb_big") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_big must be a multiple of %d (0 disables)", TILE);
     ctx->nb_big = value;

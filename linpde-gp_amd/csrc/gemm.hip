@@ -97,10 +97,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // Blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): each run of 64 of them
   // is one 8x8 super-tile.  For the triangular case only super-tiles on or below the
   // diagonal are enumerated, so every XCD gets the same number of them.
-  const int SR = (g.mt + 7) >> 3, SC = (g.nt + 7) >> 3;
+  // S x S super-tiles, S = 1 << g.sshift in {8, 4, 2}: 8 for large grids (most L2 reuse), smaller
+  // when there would be too few super-tiles to balance the 8 XCDs (measured with S = 8 only:
+  // a 32x32-tile SYRK ran two rounds on two XCDs and one on the others, 27 instead of ~50 TFLOP/s).
+  const int sh = g.sshift, S = 1 << sh, SS = S * S;
+  const int SR = (g.mt + S - 1) >> sh, SC = (g.nt + S - 1) >> sh;
   const int b = blockIdx.x;
   const int xcd = b & 7, q = b >> 3;
-  const int s = (q >> 6) * 8 + xcd, inner = q & 63;
+  const int s = (q / SS) * 8 + xcd, inner = q % SS;
   int sr, sc;
   if (TRI) {
     const int ntri = SC * (SC + 1) / 2;             // super-tiles of the leading SC x SC triangle
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     sc = s / SR;
   }
   if (sr >= SR || sc >= SC) return;
-  const int tr = sr * 8 + (inner & 7), tc = sc * 8 + (inner >> 3);
+  const int tr = (sr << sh) + (inner & (S - 1)), tc = (sc << sh) + (inner >> sh);
   if (tr >= g.mt || tc >= g.nt) return;
   if (TRI && tr < tc) return;
 
@@ -256,20 +260,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 template <bool TA, bool TB, bool TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   static bool attr_set = false;
-  const size_t shmem = (size_t)4 * STAGE * sizeof(double);
+  size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
+  // 82 KB: more than half of the 160 KB, so two such workgroups never share a CU, yet one of
+  // them still fits beside a 73.7 KB workgroup of a concurrent large update.
+  const size_t shmem_solo = 82 * 1024;
   if (!attr_set) {
     LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_solo));
     attr_set = true;
   }
-  const int SR = (g.mt + 7) / 8, SC = (g.nt + 7) / 8;
-  int nsuper = SR * SC;
-  if (TRI) {
-    LPGP_CHECK(g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
-    nsuper = SC * (SC + 1) / 2 + (SR - SC) * SC;
+  // Small launches (the latency-bound panel steps): the dispatcher packs two workgroups per CU
+  // and leaves other CUs idle; each workgroup then gets half of the matrix pipe.  Spread them.
+  {
+    const int64_t tiles = TRI ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
+    if (ctx->solo_small && tiles <= ctx->cus) shmem = shmem_solo;
   }
-  const int64_t blocks = (int64_t)((nsuper + 7) / 8) * 8 * 64;
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)blocks), dim3(256), shmem, stream, g);
+  GemmArgs ga = g;
+  int nsuper = 0, SS = 64;
+  for (int sh = 3; sh >= 0; --sh) {
+    const int S = 1 << sh;
+    const int SR = (g.mt + S - 1) / S, SC = (g.nt + S - 1) / S;
+    nsuper = SR * SC;
+    if (TRI) {
+      LPGP_CHECK(g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
+      nsuper = SC * (SC + 1) / 2 + (SR - SC) * SC;
+    }
+    ga.sshift = sh;
+    SS = S * S;
+    if (nsuper >= ctx->min_supertiles) break;      // enough super-tiles per XCD to balance the 8 XCDs
+  }
+  const int64_t blocks = (int64_t)((nsuper + 7) / 8) * 8 * SS;
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)blocks), dim3(256), shmem, stream, ga);
   LPGP_HIP(hipGetLastError());
   return 0;
 }

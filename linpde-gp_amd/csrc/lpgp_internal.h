@@ -88,6 +88,8 @@ struct lpgp_ctx {
   int64_t nb_big = 0;              // optional wider panels while more than nb_big_min_tiles tile rows remain (0 = off; measured: no gain at c3)
   int nb_big_min_tiles = 96;
   int lookahead = 1;
+  int min_supertiles = 256;        // GEMM grid: shrink the super-tile edge until there are this many
+  int solo_small = 0;              // small GEMM launches: one workgroup per CU (82 KB LDS request); measured: no gain
   // workspace
   lpgp::DevDesc* d_desc = nullptr; // device copy of the current descriptor
   int* d_info = nullptr;           // potrf info word
@@ -174,6 +176,7 @@ struct GemmArgs {
   int32_t tri;
   int32_t row_tile0, col_tile0;    // global tile index of C(0,0) (for tri)
   int32_t ktrim;                   // 1: B (or A) lower-triangular in (n,k): skip k > n-range (invL products)
+  int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm)
   unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
