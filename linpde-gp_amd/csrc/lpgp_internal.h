@@ -88,7 +88,7 @@ struct lpgp_ctx {
   int64_t nb_big = 0;              // optional wider panels while more than nb_big_min_tiles tile rows remain (0 = off; measured: no gain at c3)
   int nb_big_min_tiles = 96;
   int lookahead = 1;
-  int min_supertiles = 256;        // GEMM grid: shrink the super-tile edge until there are this many
+  int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int solo_small = 0;              // small GEMM launches: one workgroup per CU (82 KB LDS request); measured: no gain
   // workspace
   lpgp::DevDesc* d_desc = nullptr; // device copy of the current descriptor
