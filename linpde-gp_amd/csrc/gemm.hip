@@ -16,6 +16,7 @@
 // super-tile at a time (its 16 operand panels stay in that XCD's L2).
 
 #include "lpgp_internal.h"
+#include <type_traits>
 
 namespace lpgp {
 
@@ -42,20 +43,30 @@ constexpr int STAGE = BK * LDM;          // doubles per operand per stage (K ima
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Addresses are formed as (wave-uniform base) + (32-bit per-lane byte offset) so that hipcc
+// selects the SGPR-base addressing mode: one VGPR of lane offsets instead of a 64-bit
+// address pair per piece.
 template <bool T>
 __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0,
                                          int lane, int w, double* sdst) {
+  if constexpr (!T) {
+    const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int piece = q * 4 + w;                         // wave-uniform
-    if constexpr (!T) {
-      const double* src = P + (idx0 + 2 * lane) + (k0 + piece) * ld;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sdst + piece * LDM), 16, 0, 0);
-    } else {
-      const int r = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      const double* src = P + (k0 + 2 * c) + (idx0 + r) * ld;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sdst + piece * 128), 16, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      const int piece = q * 4 + w;                         // wave-uniform
+      const char* ub = reinterpret_cast<const char*>(P + idx0 + (k0 + piece) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * LDM), 16, 0, 0);
+    }
+  } else {
+    const unsigned row8 = (unsigned)(lane >> 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = q * 4 + w;
+      // r = piece*8 + (lane>>3); swizzle term ((r >> 1) & 7) = ((piece*4) + (lane>>4)) & 7
+      const unsigned c = ((unsigned)lane & 7u) ^ ((((unsigned)piece << 2) + ((unsigned)lane >> 4)) & 7u);
+      const unsigned voff = (c * 2u + row8 * (unsigned)ld) * 8u;
+      const char* ub = reinterpret_cast<const char*>(P + k0 + (idx0 + (int64_t)piece * 8) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * 128), 16, 0, 0);
     }
   }
 }
@@ -64,22 +75,48 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ P, int64_t l
 //   m-side fragment:  idx = idx_base + (lane & 15), k = ks*4 + (lane >> 4)
 //   n-side fragment:  idx = idx_base + (lane & 3),  k = ks*4 + (lane >> 4)   (replicated over lane bits 2..3:
 //                     the "A" operand of v_mfma_f64_4x4x4_4b_f64 with one 4x4 block shared by all four blocks)
+// Every address splits into a per-lane part (held in a VGPR, computed once per kernel) and a
+// compile-time part that goes into the ds_read offset field:
+//   M image  off = k*LDM + idx                              lane: (lane>>4)*LDM + w*64 + (lane&15 | lane&3)
+//                                                           imm : ks*4*LDM + idx_const
+//   K image  off = idx*16 + (((k>>1) ^ ((idx>>1)&7))<<1) + (k&1)
+//     m-side: the swizzle term (lane&15)>>1 is XORed with ks*2 + (lane>>5): one lane part per ks
+//     n-side: (idx>>1)&7 = vv*2 + ((lane&3)>>1) and the XOR separates: imm part ((ks^vv)&3)*4
 template <bool T>
-__device__ __forceinline__ int frag_off(int idx, int k) {
-  if constexpr (!T) return k * LDM + idx;
-  else              return idx * 16 + (((k >> 1) ^ ((idx >> 1) & 7)) << 1) + (k & 1);
+__device__ __forceinline__ unsigned frag_lane_m(int lane, int w, int ks) {
+  if constexpr (!T) return (unsigned)((lane >> 4) * LDM + w * 64 + (lane & 15));
+  else return (unsigned)((w * 64 + (lane & 15)) * 16 + ((((ks * 2) + (lane >> 5)) ^ ((lane & 15) >> 1)) << 1) + ((lane >> 4) & 1));
+}
+template <bool T>
+__device__ __forceinline__ unsigned frag_lane_n(int lane, int w) {
+  if constexpr (!T) return (unsigned)((lane >> 4) * LDM + w * 64 + (lane & 3));
+  else return (unsigned)((w * 64 + (lane & 3)) * 16 + (((((lane & 3) >> 1) ^ (lane >> 5)) & 1) << 1) + ((lane >> 4) & 1));
+}
+template <bool T> constexpr int frag_imm_m(int ks, int t) { return T ? t * 256 : ks * 4 * LDM + t * 16; }
+template <bool T> constexpr int frag_imm_n(int ks, int nf) {       // nf = n-fragment 0..15 (4 columns each)
+  return T ? nf * 64 + (((ks ^ nf) & 3) << 2) : ks * 4 * LDM + nf * 4;
 }
 
 // LDS read whose completion the COMPILER does not track: with LDS-DMA in flight hipcc turns
 // every wait for a ds_read result into s_waitcnt lgkmcnt(0), which also waits for the
 // prefetch just issued for the next chunk.  The reads are therefore issued from inline asm
 // and retired by hand-counted s_waitcnt lgkmcnt(N) (LDS operations return in order).
+template <int OFF_DOUBLES>
 __device__ __forceinline__ double lds_read_async(unsigned byte_addr) {
+  static_assert(OFF_DOUBLES >= 0 && OFF_DOUBLES * 8 < 65536, "ds_read offset field");
   double d;
-  asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(byte_addr));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF_DOUBLES * 8));
   return d;
 }
 #define LDS_WAIT(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 // MFMA shape: measured on MI355X, v_mfma_f64_16x16x4_f64 sustains only ~48 TFLOP/s chip-wide
 // (>= 88 cycles per instruction per SIMD at any occupancy) while v_mfma_f64_4x4x4_4b_f64
@@ -88,22 +125,17 @@ __device__ __forceinline__ double lds_read_async(unsigned byte_addr) {
 // per k-step of 4, acc[t][u] (m = 16t + (lane&15), n = 4u + (lane>>4)) += Bfrag4[u] x Afrag[t],
 // where the instruction's four 4x4 blocks share the 4 n-columns (replicated "A" operand) and
 // cover 16 consecutive rows m ("B" operand) -- the same 128-byte-segment C layout as before.
-// TRI: lower-triangular output (symmetric rank-k update): a distinct instantiation so that the
-// SYRK launches show up under their own kernel symbol in rocprofv3 --stats.
-template <bool TA, bool TB, bool TRI>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  // ---- block -> tile (XCD-aware 8x8 super-tiles) ----
-  // Blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): each run of 64 of them
-  // is one 8x8 super-tile.  For the triangular case only super-tiles on or below the
-  // diagonal are enumerated, so every XCD gets the same number of them.
-  // S x S super-tiles, S = 1 << g.sshift in {8, 4, 2}: 8 for large grids (most L2 reuse), smaller
-  // when there would be too few super-tiles to balance the 8 XCDs (measured with S = 8 only:
-  // a 32x32-tile SYRK ran two rounds on two XCDs and one on the others, 27 instead of ~50 TFLOP/s).
+// Virtual block id -> tile.  Blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so
+// every run of S*S ids with equal (b & 7) is one S x S super-tile worked on by ONE XCD (its
+// operand panels stay in that XCD's L2).  S = 1 << sshift in {8,4,2,1}: 8 for large grids, smaller
+// when there would be too few super-tiles to balance the 8 XCDs (measured with S = 8 only: a
+// 32x32-tile SYRK ran two rounds on two XCDs and one on the others, 27 instead of ~50 TFLOP/s).
+// For the triangular case only super-tiles on or below the diagonal are enumerated.
+template <bool TRI>
+__device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int& tc) {
   const int sh = g.sshift, S = 1 << sh, SS = S * S;
   const int SR = (g.mt + S - 1) >> sh, SC = (g.nt + S - 1) >> sh;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q = b >> 3;
+  const int xcd = v & 7, q = v >> 3;
   const int s = (q / SS) * 8 + xcd, inner = q % SS;
   int sr, sc;
   if (TRI) {
@@ -122,37 +154,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     sr = s % SR;
     sc = s / SR;
   }
-  if (sr >= SR || sc >= SC) return;
-  const int tr = (sr << sh) + (inner & (S - 1)), tc = (sc << sh) + (inner >> sh);
-  if (tr >= g.mt || tc >= g.nt) return;
-  if (TRI && tr < tc) return;
+  if (sr >= SR || sc >= SC) return false;
+  // (sqrtf went through the vector ALU: bring the wave-uniform results back to scalar registers,
+  // or every address derived from them lives in VGPRs)
+  tr = __builtin_amdgcn_readfirstlane((sr << sh) + (inner & (S - 1)));
+  tc = __builtin_amdgcn_readfirstlane((sc << sh) + (inner >> sh));
+  if (tr >= g.mt || tc >= g.nt) return false;
+  if (TRI && tr < tc) return false;
+  return true;
+}
 
+// TRI: lower-triangular output (symmetric rank-k update): a distinct instantiation so that the
+// SYRK launches show up under their own kernel symbol in rocprofv3 --stats.
+//
+// One 128x128 tile per workgroup, two workgroups per CU.  (A persistent variant -- 2 workgroups
+// per CU walking the tile list with cross-tile prefetch and a half-tile stagger between the two
+// co-resident workgroups -- was measured and is 1-4 % SLOWER: the dispatcher already overlaps
+// one workgroup's prologue with its neighbour's k-loop.  In-kernel stamps (-DLPGP_STAMP,
+// scratch/stamp_test.hip) show the k-loop at 16.1 cycles per MFMA per SIMD, i.e. the matrix pipe
+// is saturated; what is left is the C prologue (~15k of ~280k cycles per tile at k = 512) and
+// the clock: 2.35 GHz on all-zero operands, 1.97-2.07 GHz on random data.)
+template <bool TA, bool TB, bool TRI>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;
-  const int64_t m0 = (int64_t)tr * BM, n0 = (int64_t)tc * BN;
-
   double* sA = smem;                  // 2 stages
   double* sB = smem + 2 * STAGE;
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
-
   const int KT = g.k / BK;
   const int wu = __builtin_amdgcn_readfirstlane(wid);    // wave index as a scalar (LDS-DMA base must be uniform)
-  dma_tile<TA>(g.A, g.lda, m0, 0, lane, wu, sA);
-  dma_tile<TB>(g.B, g.ldb, n0, 0, lane, wu, sB);
-
-  // The accumulators start from (beta/alpha) * C, so that the epilogue is stores only: the 64
-  // C loads per lane are all in flight at once, under the first tile's DMA latency, instead
-  // of 16 dependent load->fma->store round trips at the end of every tile (measured: ~33 us
-  // of a 165 us tile at K = 512).
+  const int wum = wu & 1, wun = wu >> 1;
   const double alpha = g.alpha, beta = g.beta;
-  double* const cbase = g.C + (n0 + wn * 64 + (lane >> 4)) * g.ldc + m0 + wm * 64 + (lane & 15);
+
+  int tr, tc;
+  if (!map_tile<TRI>(g, (int)blockIdx.x, tr, tc)) return;
+
+  // per-lane byte addresses of the fragment reads (stage 0 of each operand; see frag_lane_*)
+  unsigned laneM[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) laneM[ks] = lds_base + 8u * frag_lane_m<TA>(lane, wm, TA ? ks : 0);
+  const unsigned laneN = lds_base + (unsigned)(2 * STAGE) * 8u + 8u * frag_lane_n<TB>(lane, wn);
+
+  dma_tile<TA>(g.A, g.lda, (int64_t)tr * BM, 0, lane, wu, sA);
+  dma_tile<TB>(g.B, g.ldb, (int64_t)tc * BN, 0, lane, wu, sB);
+
+#ifdef LPGP_STAMP
+  const unsigned long long st_pro0 = __builtin_amdgcn_s_memtime();
+#endif
+  // The accumulators start from (beta/alpha) * C, so that the epilogue is stores only: the 64
+  // C loads per lane are all in flight at once instead of 16 dependent load->fma->store
+  // round trips at the end of the tile.
+  // C element (t,u) of this lane: uniform tile/wave origin + uniform (4u*ldc + 16t) + lane offset
+  char* const cub = reinterpret_cast<char*>(g.C + ((int64_t)tc * BN + wun * 64) * g.ldc + (int64_t)tr * BM + wum * 64);
+  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldc + (unsigned)(lane & 15)) * 8u;
   double acc[4][16];
   if (beta != 0.0) {
-    const double sc = beta / alpha;
+    const double sc_ = beta / alpha;
 #pragma unroll
     for (int u = 0; u < 16; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t][u] = sc * cbase[(int64_t)(4 * u) * g.ldc + t * 16];
+      for (int t = 0; t < 4; ++t)
+        acc[t][u] = sc_ * *reinterpret_cast<const double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff);
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -163,55 +226,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   __syncthreads();
 
 #ifdef LPGP_STAMP
-  unsigned long long st_load = 0, st_mfma = 0, st_store = 0, st_bar = 0, t_a, t_b;
-#define STAMP(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
-#else
-#define STAMP(var) do { } while (0)
+  unsigned long long st_acc[4] = {0, 0, 0, 0};
+  const unsigned long long st_tile0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int cur = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const bool more = (kt + 1 < KT);
 #ifdef LPGP_STAMP
-    STAMP(t_a);
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-    // next stage's tiles -> other LDS buffer (unconditional: the last stage harmlessly
-    // re-loads its own k-tile; a branch around the DMA would make hipcc drain vmcnt early)
-#ifdef LPGP_EXPERIMENT
-    if (!(g.ktrim & 1))
-#endif
+    // next stage -> other LDS buffer (unconditional: a branch around the DMA would make hipcc
+    // drain vmcnt early; the last stage harmlessly re-loads its own k-tile)
     {
-      const int64_t knext = (int64_t)(more ? kt + 1 : kt) * BK;
-      dma_tile<TA>(g.A, g.lda, m0, knext, lane, wu, sA + (cur ^ 1) * STAGE);
-      dma_tile<TB>(g.B, g.ldb, n0, knext, lane, wu, sB + (cur ^ 1) * STAGE);
+      const int knext = (kt + 1 < KT ? kt + 1 : kt) * BK;
+      dma_tile<TA>(g.A, g.lda, (int64_t)tr * BM, knext, lane, wu, sA + (cur ^ 1) * STAGE);
+      dma_tile<TB>(g.B, g.ldb, (int64_t)tc * BN, knext, lane, wu, sB + (cur ^ 1) * STAGE);
     }
     // 16 chunks of 16 MFMAs per stage (4 k-steps x 4 groups of 4 n-fragments).  Fragments
     // are double-buffered in registers: the LDS reads of chunk c+1 are issued before the
     // MFMAs of chunk c (264 cycles of matrix work cover the LDS latency) and retired with a
     // counted wait that leaves exactly those newer reads in flight.
-    const unsigned baseA = lds_base + (unsigned)(cur * STAGE) * 8u;
-    const unsigned baseB = lds_base + (unsigned)((2 + cur) * STAGE) * 8u;
+    const unsigned stoff = (unsigned)(cur * STAGE) * 8u;
+    const unsigned aM0 = laneM[0] + stoff, aM1 = laneM[1] + stoff, aM2 = laneM[2] + stoff, aM3 = laneM[3] + stoff;
+    const unsigned aN = laneN + stoff;
     double am[2][4], bn[2][4];
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      am[0][t] = lds_read_async(baseA + 8u * (unsigned)frag_off<TA>(wm * 64 + t * 16 + (lane & 15), (lane >> 4)));
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      bn[0][v] = lds_read_async(baseB + 8u * (unsigned)frag_off<TB>(wn * 64 + v * 4 + (lane & 3), (lane >> 4)));
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int ks = c >> 2, uc = c & 3, cb = c & 1;
-      if (c + 1 < 16) {
-        const int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          bn[cb ^ 1][v] = lds_read_async(
-              baseB + 8u * (unsigned)frag_off<TB>(wn * 64 + (uc2 * 4 + v) * 4 + (lane & 3), ks2 * 4 + (lane >> 4)));
-        if (uc2 == 0) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            am[ks2 & 1][t] = lds_read_async(
-                baseA + 8u * (unsigned)frag_off<TA>(wm * 64 + t * 16 + (lane & 15), ks2 * 4 + (lane >> 4)));
+#ifdef LPGP_STAMP
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+    static_for<0, 4>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      am[0][t] = lds_read_async<frag_imm_m<TA>(0, t)>(aM0);
+    });
+    static_for<0, 4>([&](auto V_) {
+      constexpr int vv = decltype(V_)::value;
+      bn[0][vv] = lds_read_async<frag_imm_n<TB>(0, vv)>(aN);
+    });
+    static_for<0, 16>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      constexpr int ks = c >> 2, uc = c & 3, cb = c & 1;
+      if constexpr (c + 1 < 16) {
+        constexpr int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
+        static_for<0, 4>([&](auto V_) {
+          constexpr int vv = decltype(V_)::value;
+          bn[cb ^ 1][vv] = lds_read_async<frag_imm_n<TB>(ks2, uc2 * 4 + vv)>(aN);
+        });
+        if constexpr (uc2 == 0) {
+          const unsigned aMk = ks2 == 1 ? aM1 : (ks2 == 2 ? aM2 : aM3);
+          static_for<0, 4>([&](auto T_) {
+            constexpr int t = decltype(T_)::value;
+            am[ks2 & 1][t] = lds_read_async<frag_imm_m<TA>(ks2, t)>(aMk);
+          });
           LDS_WAIT(8);
         } else {
           LDS_WAIT(4);
@@ -220,33 +285,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         LDS_WAIT(0);
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int vv = 0; vv < 4; ++vv)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[t][uc * 4 + v] =
-              __builtin_amdgcn_mfma_f64_4x4x4f64(bn[cb][v], am[ks & 1][t], acc[t][uc * 4 + v], 0, 0, 0);
+          acc[t][uc * 4 + vv] =
+              __builtin_amdgcn_mfma_f64_4x4x4f64(bn[cb][vv], am[ks & 1][t], acc[t][uc * 4 + vv], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 #ifdef LPGP_STAMP
-    STAMP(t_b); st_mfma += t_b - t_a; t_a = t_b;
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
 #ifdef LPGP_STAMP
-    STAMP(t_b); st_store += t_b - t_a; t_a = t_b;
-#endif
-#ifdef LPGP_EXPERIMENT
-    if (!(g.ktrim & 2))
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
-#ifdef LPGP_STAMP
-    STAMP(t_b); st_bar += t_b - t_a;
-#endif
     cur ^= 1;
+#ifdef LPGP_STAMP
+    const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+    st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3;
+#endif
   }
 #ifdef LPGP_STAMP
-  if (g.stamps && tid == 0) {
-    unsigned long long* o = g.stamps + 4 * (size_t)blockIdx.x;
-    o[0] = st_load; o[1] = st_mfma; o[2] = st_store; o[3] = st_bar;
+  if (g.stamps != nullptr && tid == 0) {
+    unsigned long long* o = g.stamps + (size_t)blockIdx.x * 8;
+    o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; o[3] = st_acc[3];
+    o[4] = st_tile0 - st_pro0;                            // prologue (C loads + first DMA wait)
+    o[5] = __builtin_amdgcn_s_memtime() - st_tile0;       // whole k loop, core clocks
+    o[6] = __builtin_amdgcn_s_memrealtime() - st_real0;   // same in 100 MHz ticks
   }
 #endif
 
@@ -254,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
   for (int u = 0; u < 16; ++u)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) cbase[(int64_t)(4 * u) * g.ldc + t * 16] = alpha * acc[t][u];
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
 }
 
 template <bool TA, bool TB, bool TRI>
@@ -289,8 +356,8 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     SS = S * S;
     if (nsuper >= ctx->min_supertiles) break;      // enough super-tiles per XCD to balance the 8 XCDs
   }
-  const int64_t blocks = (int64_t)((nsuper + 7) / 8) * 8 * SS;
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)blocks), dim3(256), shmem, stream, ga);
+  const int64_t nvirtual = (int64_t)((nsuper + 7) / 8) * 8 * SS;
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)nvirtual), dim3(256), shmem, stream, ga);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
