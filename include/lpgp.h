@@ -119,6 +119,11 @@ int  lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs);
 /* representer weights w = G^{-1} r; keeps w resident for lpgp_predict; w_host may be
  * NULL (_conditional.py:96-110)                                                         */
 int  lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host);
+/* hands the residual r = Y - L[m] - b.mean (_conditional.py:44) to the factored matrix
+ * WITHOUT solving for the weights: lpgp_predict with both mean and variance requested then
+ * forms the mean as V^T z with z = L^{-1} r (forward substitution only, overlapped with the
+ * solve of the cross-covariance).  Invalidated by lpgp_mat_add_block / lpgp_potrf.        */
+int  lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host);
 
 /* ---- prediction: replaces `PriorPredictiveCrossCovariance._evaluate`
  *      (_conditional.py:140-153), `Mean._evaluate` (:193-197) and
@@ -131,7 +136,9 @@ int  lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                          lpgp_rhs* rhs, const lpgp_mat* mat, int32_t bi);
 /* mean_host[j] = prior_mean_host[j] + K_Xx[:, j] . w     (prior_mean_host may be NULL)
  * var_host[j]  = kxx_host[j] - || L^{-1} K_Xx[:, j] ||^2  (skipped if var_host == NULL)
- * K_Xx is overwritten by V = L^{-1} K_Xx when the variance is requested.               */
+ * K_Xx is overwritten by V = L^{-1} K_Xx when the variance is requested.  If no weights
+ * are resident but a residual is (lpgp_mat_set_residual) and both outputs are requested,
+ * the mean is formed as prior_mean + V[:, j] . (L^{-1} r) instead.                       */
 int  lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K,
                   const double* prior_mean_host, const double* kxx_host,
                   double* mean_host, double* var_host);

@@ -98,6 +98,38 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const double* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// both read-outs of the solved cross-covariance V = L^{-1} K in one pass:
+//   out_dot[j] = sum_i V[i,j] z[i]   (posterior mean term  K_xX G^{-1} r = V^T z,  z = L^{-1} r)
+//   out_sq[j]  = sum_i V[i,j]^2      (variance reduction)
+__global__ __launch_bounds__(256) void col_reduce2_kernel(const double* __restrict__ V, int64_t ld, int64_t rows,
+                                                           const double* __restrict__ z, double* __restrict__ out_dot,
+                                                           double* __restrict__ out_sq) {
+  __shared__ double red[8];
+  const double* col = V + (int64_t)blockIdx.x * ld;
+  double ad = 0.0, as = 0.0;
+  for (int64_t i = threadIdx.x * 2; i < rows; i += 512) {
+    const double2 v = *reinterpret_cast<const double2*>(col + i);
+    const double2 zz = *reinterpret_cast<const double2*>(z + i);
+    ad = fma(v.x, zz.x, ad);
+    ad = fma(v.y, zz.y, ad);
+    as = fma(v.x, v.x, as);
+    as = fma(v.y, v.y, as);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ad += __shfl_down(ad, off);
+    as += __shfl_down(as, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = ad;
+    red[4 + (threadIdx.x >> 6)] = as;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out_dot[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    out_sq[blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters) {
@@ -180,7 +212,7 @@ static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
 
 static size_t mat_bytes_a(int64_t cap) { return (size_t)cap * cap * sizeof(double); }
 static size_t mat_bytes_l(int64_t cap) { return (size_t)cap * TILE * sizeof(double); }
-static size_t mat_bytes_w(int64_t cap) { return (size_t)cap * sizeof(double); }
+static size_t mat_bytes_w(int64_t cap) { return (size_t)2 * cap * sizeof(double); }   // w | r
 
 static void mat_release(lpgp_ctx* ctx, lpgp_mat* mat) {
   pool_free(ctx, mat->a, mat_bytes_a(mat->cap));
@@ -222,6 +254,7 @@ static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
   mat->linv = (double*)nl;
   mat->w = (double*)nw;
   mat->cap = cap;
+  mat->has_r = 0;            // the residual segment is addressed relative to cap
   return 0;
 }
 
@@ -427,6 +460,7 @@ int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
   m->a = m->linv = m->w = nullptr;
   m->n = m->pn = m->pn_fact = 0;
   m->has_w = 0;
+  m->has_r = 0;
   int64_t cap = round_up(capacity_hint > 0 ? capacity_hint : TILE, TILE);
   int rc = mat_alloc(ctx, m, cap);
   if (rc != 0) {
@@ -473,6 +507,7 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   mat->n += n;
   mat->pn += b.pn;
   mat->has_w = 0;
+  mat->has_r = 0;
   return (int)mat->blocks.size() - 1;
 }
 
@@ -572,6 +607,7 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   if (info) *info = h;
   if (h == 0) mat->pn_fact = mat->pn;
   mat->has_w = 0;
+  mat->has_r = 0;
   return 0;
 }
 
@@ -620,6 +656,17 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
   return 0;
 }
 
+int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
+  LPGP_CHECK(ctx && mat && r_host, "lpgp_mat_set_residual: null argument");
+  LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_mat_set_residual: matrix is not factored");
+  std::vector<double> hp((size_t)mat->pn);
+  scatter_padded(mat, r_host, hp.data());
+  LPGP_HIP(hipMemcpyAsync(mat->r(), hp.data(), (size_t)mat->pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  mat->has_r = 1;
+  return 0;
+}
+
 // ---- prediction -----------------------------------------------------------------------------
 int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out) {
   LPGP_CHECK(ctx && mat && out && m >= 1, "lpgp_rhs_create: bad argument");
@@ -627,7 +674,7 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
   r->ctx = ctx;
   r->ld = mat->pn;
   r->m = m;
-  r->m_pad = round_up(m, TILE);
+  r->m_pad = round_up(m + 1, TILE);       // at least one spare column (see lpgp_predict)
   r->v = nullptr;
   void* pv = nullptr;
   if (pool_alloc(ctx, &pv, (size_t)r->ld * r->m_pad * sizeof(double), nullptr) != 0) {
@@ -682,9 +729,17 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
   const int64_t m = K->m;
   int rc = ensure_tmp(ctx, 2 * K->m_pad);
   if (rc != 0) return rc;
-  std::vector<double> h((size_t)m);
-  if (mean_host) {
-    LPGP_CHECK(mat->has_w, "lpgp_predict: representer weights not computed (call lpgp_solve_weights)");
+  std::vector<double> h((size_t)m), h2;
+  // Mean and variance together: the variance needs V = L^{-1} K_Xx anyway, and
+  //   K_xX G^{-1} r = V^T z  with  z = L^{-1} r,
+  // so no representer weights are needed: the residual rides through the blocked solve as
+  // the spare column m of the right-hand side (a side-stream triangular solve for z was
+  // measured instead: its 132 dependent launches queue behind the resident GEMM workgroups
+  // and stretch the step from 68 to 100 ms).
+  const bool via_z = mean_host && var_host && !mat->has_w && mat->has_r;
+  if (mean_host && !via_z) {
+    LPGP_CHECK(mat->has_w, "lpgp_predict: representer weights not computed (call lpgp_solve_weights%s)",
+               var_host ? " or lpgp_mat_set_residual" : "");
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                        (const double*)mat->w, ctx->d_tmp);
     LPGP_HIP(hipGetLastError());
@@ -694,13 +749,28 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
   }
   if (var_host) {
     LPGP_CHECK(kxx_host != nullptr, "lpgp_predict: kxx_host required for the variance");
+    double* zcol = K->v + (int64_t)m * K->ld;
+    if (via_z)
+      LPGP_HIP(hipMemcpyAsync(zcol, mat->r(), (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
     rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
-                       (const double*)nullptr, ctx->d_tmp);
-    LPGP_HIP(hipGetLastError());
-    LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    if (via_z) {
+      hipLaunchKernelGGL(col_reduce2_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
+                         (const double*)zcol, ctx->d_tmp, ctx->d_tmp + K->m_pad);
+      LPGP_HIP(hipGetLastError());
+      h2.resize((size_t)m);
+      LPGP_HIP(hipMemcpyAsync(h2.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+      LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp + K->m_pad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->s_main));
+      LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+      for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h2[j];
+    } else {
+      hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
+                         (const double*)nullptr, ctx->d_tmp);
+      LPGP_HIP(hipGetLastError());
+      LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+      LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    }
     for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - h[j];
   }
   return 0;

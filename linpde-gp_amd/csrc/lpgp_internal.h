@@ -132,19 +132,21 @@ struct lpgp_mat {
   int64_t cap;                     // padded capacity (multiple of TILE) == leading dimension
   double* a;                       // device cap x cap column-major (lower part meaningful)
   double* linv;                    // device (cap/TILE) tiles of TILE x TILE: inverse of each diagonal tile of L
-  double* w;                       // device cap: representer weights (padded layout)
+  double* w;                       // device 2*cap: [representer weights | residual r] (padded layout)
   std::vector<lpgp_block> blocks;
   int64_t n;                       // logical size
   int64_t pn;                      // padded size in use
   int64_t pn_fact;                 // padded columns factored so far
   int has_w;
+  int has_r;                       // residual resident (lpgp_mat_set_residual)
+  double* r() const { return w + cap; }
 };
 
 struct lpgp_rhs {
   lpgp_ctx* ctx;
   int64_t ld;                      // padded row capacity (multiple of TILE)
   int64_t m;                       // columns
-  int64_t m_pad;                   // multiple of TILE
+  int64_t m_pad;                   // multiple of TILE, > m: column m is spare (carries the residual through the solve)
   double* v;                       // device ld x m_pad column-major
 };
 
@@ -189,6 +191,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, 
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp);
+int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T, double* b, double* x);
 
 // assemble.hip ----------------------------------------------------------------------------
 // own_*: column ownership filter of the distributed factorisation: 64-wide tile columns whose

@@ -750,6 +750,20 @@ __global__ __launch_bounds__(512) void trsv_bwd_step_kernel(const double* __rest
   tile_matvec_t(linv_prev, sy, x + c0, t);
 }
 
+// x <- L^{-1} b on `st` (padded length T*128, device); b is consumed as the running right-hand side
+int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T64, double* b, double* x) {
+  const int T = (int)T64;
+  const int64_t ld = mat->cap;
+  const double* a = mat->a;
+  auto linv = [&](int k) { return (const double*)(mat->linv + (int64_t)k * TILE * TILE); };
+  hipLaunchKernelGGL(trsv_fwd_head_kernel, dim3(1), dim3(512), 0, st, linv(0), (const double*)b, x);
+  for (int k = 0; k + 1 < T; ++k)
+    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(T - k - 1), dim3(512), 0, st, a, ld, linv(k + 1), b, x,
+                       (int64_t)k * TILE);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
 // v (padded length T*128, device) <- G^{-1} v, using scratch vector `tmp` of the same length
 int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp) {
   const int T = (int)T64;
@@ -758,10 +772,8 @@ int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp)
   const double* a = mat->a;
   auto linv = [&](int k) { return (const double*)(mat->linv + (int64_t)k * TILE * TILE); };
   // forward: L tmp = v   (v is consumed as the running right-hand side)
-  hipLaunchKernelGGL(trsv_fwd_head_kernel, dim3(1), dim3(512), 0, st, linv(0), (const double*)v, tmp);
-  for (int k = 0; k + 1 < T; ++k)
-    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(T - k - 1), dim3(512), 0, st, a, ld, linv(k + 1), v, tmp,
-                       (int64_t)k * TILE);
+  int rc = solve_vec_fwd(ctx, st, mat, T64, v, tmp);
+  if (rc != 0) return rc;
   // backward: L^T v = tmp  (tmp is consumed as the running right-hand side)
   hipLaunchKernelGGL(trsv_bwd_head_kernel, dim3(1), dim3(512), 0, st, linv(T - 1),
                      (const double*)(tmp + (int64_t)(T - 1) * TILE), v + (int64_t)(T - 1) * TILE);

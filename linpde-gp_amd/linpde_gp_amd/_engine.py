@@ -248,6 +248,13 @@ class GramMatrix:
         check(lib.lpgp_solve_weights(self.ctx._h, self._h, as_pd(r), as_pd(w)), "lpgp_solve_weights")
         return w
 
+    def set_residual(self, r: np.ndarray) -> None:
+        """Residual for the weight-free mean of `Rhs.predict(mean + variance)` (`lpgp_mat_set_residual`)."""
+        r = np.ascontiguousarray(r, dtype=np.double)
+        if r.shape != (self.n,):
+            raise ValueError(f"residual must have shape ({self.n},), got {r.shape}")
+        check(lib.lpgp_mat_set_residual(self.ctx._h, self._h, as_pd(r)), "lpgp_mat_set_residual")
+
 
 class Rhs:
     """Device-resident n x m block sharing the row layout of a GramMatrix (`lpgp_rhs_*`)."""

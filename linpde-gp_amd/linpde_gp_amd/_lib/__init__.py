@@ -80,6 +80,7 @@ def _load() -> C.CDLL:
     sig("lpgp_potrf", C.c_int, vp, vp, C.POINTER(i32))
     sig("lpgp_potrs", C.c_int, vp, vp, pd, i64)
     sig("lpgp_solve_weights", C.c_int, vp, vp, pd, pd)
+    sig("lpgp_mat_set_residual", C.c_int, vp, vp, pd)
     sig("lpgp_rhs_create", C.c_int, vp, vp, i64, C.POINTER(vp))
     sig("lpgp_rhs_destroy", C.c_int, vp)
     sig("lpgp_cross_assemble", C.c_int, vp, pk, i32, vp, vp, vp, vp, i32)
@@ -106,7 +107,7 @@ EXPORTED = [
     "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
-    "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_rhs_create", "lpgp_rhs_destroy",
+    "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_probe_mfma_f64",

@@ -199,18 +199,28 @@ class ConditionalGaussianProcess(GaussianProcess):
         self._ensure_weights()
         return self._representer_weights
 
+    def _residual(self) -> np.ndarray:
+        return np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
+
     def _ensure_weights(self):
         if self._representer_weights is None:
             self._check_current()
-            r = np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
-            self._representer_weights = self._state.mat.solve_weights(r)
+            self._representer_weights = self._state.mat.solve_weights(self._residual())
             self._state.weights_generation = self._generation
         elif getattr(self._state, "weights_generation", None) != self._generation:
             # the device copy of the weights belongs to another view of the same factor
             self._check_current()
-            r = np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
-            self._representer_weights = self._state.mat.solve_weights(r)
+            self._representer_weights = self._state.mat.solve_weights(self._residual())
             self._state.weights_generation = self._generation
+
+    def _ensure_residual(self):
+        """Mean AND variance need no weights: `K_xX G^{-1} r = V^T (L^{-1} r)` with the solved
+        cross-covariance `V = L^{-1} K_Xx` the variance computes anyway; the library only needs
+        the residual (its forward substitution hides under the solve for `V`)."""
+        if getattr(self._state, "residual_generation", None) != self._generation:
+            self._check_current()
+            self._state.mat.set_residual(self._residual())
+            self._state.residual_generation = self._generation
 
     @property
     def prior(self):
@@ -324,7 +334,10 @@ class ConditionalGaussianProcess(GaussianProcess):
         return (mean, var.reshape(batch)) if return_var else mean
 
     def _predict_local(self, x_original, X, return_var):
-        self._ensure_weights()
+        if return_var and self._representer_weights is None:
+            self._ensure_residual()
+        else:
+            self._ensure_weights()
         pts = _engine.as_points(self._state.ctx, x_original, X)
         rhs = self._cross(pts)
         pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])

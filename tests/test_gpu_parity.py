@@ -171,6 +171,36 @@ def test_poisson2d_posterior_small(lp):
     assert mean.min() > 0.0
 
 
+def test_mean_without_weights_matches_weight_path(lp):
+    """predict(mean + variance) forms the mean as V^T (L^{-1} r) (lpgp_mat_set_residual, no
+    representer weights); mean-only prediction uses K_xX w.  Both against the oracle and
+    against each other, on a point count that is / is not a multiple of the 128-tile."""
+    cf = lp.randprocs.covfuncs
+    blocks = _poisson_blocks(nb=20, npde=18)
+    okern = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
+    prior = lp.GaussianProcess(
+        lp.functions.Zero((2,)),
+        2.0**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=1.0)))
+    post = ogp.condition(okern, blocks)
+    rng = np.random.default_rng(77)
+    for m in (128, 201):
+        u = _condition_host(lp, prior, blocks)
+        Xt = rng.uniform(-0.95, 0.95, size=(m, 2))
+        assert u._representer_weights is None
+        mean_z, var = u.predict(Xt)                    # residual path
+        assert u._representer_weights is None          # ... really did not solve for the weights
+        mean_w = u.predict(Xt, return_var=False)       # weights path
+        assert u._representer_weights is not None
+        mean_w2, var2 = u.predict(Xt)                  # weights now resident: K w, then the solve
+        ref = post.mean(Xt)
+        assert _rel(mean_z, ref) < 1e-8 and _rel(mean_w, ref) < 1e-8
+        assert _rel(mean_z, mean_w) < 1e-8
+        np.testing.assert_array_equal(mean_w, mean_w2)
+        # two reduction kernels; var = k(x,x) - sum v^2 cancels against k(x,x) = 4
+        np.testing.assert_allclose(var, var2, rtol=0, atol=1e-13 * 4.0)
+        assert _rel(var, post.var(Xt)) < 1e-8
+
+
 def test_iterative_equals_oneshot_and_linop_readout(lp):
     """Reference `tests/linpde_gp/randprocs/test_posterior_gp.py:152-178`: 4 batches (2,3,2,4),
     two with Normal noise, prior 4*ExpQuad(l=0.25); also the Laplacian read-out."""
