@@ -175,7 +175,7 @@ def main():
             "device": info["name"].strip(),
         },
         "roofline": {
-            "kernel": "gemm_f64_kernel<false,false,true> (SYRK: rank-nb trailing update + in-panel rank-128 updates of the blocked Cholesky)",
+            "kernel": "gemm_f64_kernel<false,false,1> (SYRK: rank-512 trailing update of the blocked Cholesky, both look-ahead halves)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,

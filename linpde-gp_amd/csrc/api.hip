@@ -295,26 +295,37 @@ int lpgp_init(int device, lpgp_ctx** out) {
   // behind thousands of resident update workgroups.  LPGP_RESERVE_CUS=0 disables the mask.
   int reserve = 8;
   if (const char* e = std::getenv("LPGP_RESERVE_CUS")) reserve = std::atoi(e);
-  ctx->s_upd = nullptr;
-  if (reserve > 0 && reserve < ctx->cus) {
+  if (const char* e = std::getenv("LPGP_RESERVE_CUS_NARROW")) ctx->reserve_narrow = std::atoi(e);
+  // mask bit i = CU (i / 8) of XCD (i % 8) (measured, scratch/cumask.hip): clearing the low
+  // `reserve` bits takes the CUs round-robin from the XCDs, one per XCD for reserve == 8,
+  // so a single workgroup of the panel stream finds a free CU on whichever XCD it is dealt to
+  auto masked_stream = [&](int nreserve, hipStream_t* out) {
+    *out = nullptr;
+    if (nreserve <= 0 || nreserve >= ctx->cus) return;
     const int words = (ctx->cus + 31) / 32;
     std::vector<uint32_t> mask(words, 0u);
-    // mask bit i = CU (i / 8) of XCD (i % 8) (measured, scratch/cumask.hip): clearing the low
-    // `reserve` bits takes the CUs round-robin from the XCDs, one per XCD for reserve == 8,
-    // so a single workgroup of the panel stream finds a free CU on whichever XCD it is dealt to
     for (int cu = 0; cu < ctx->cus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
-    for (int r = 0; r < reserve; ++r) mask[r / 32] &= ~(1u << (r % 32));
-    if (hipExtStreamCreateWithCUMask(&ctx->s_upd, (uint32_t)words, mask.data()) != hipSuccess) {
+    for (int r = 0; r < nreserve; ++r) mask[r / 32] &= ~(1u << (r % 32));
+    if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) != hipSuccess) {
       (void)hipGetLastError();
-      ctx->s_upd = nullptr;
+      *out = nullptr;
     }
-  }
+  };
+  masked_stream(reserve, &ctx->s_upd);
   if (!ctx->s_upd) LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd, hipStreamNonBlocking, lo));
+  // While the panel chain bounds the pipeline (small trailing matrix) the update can spare a
+  // quarter of the chip: with only 8 reserved CUs the chain's TRSM / in-panel update wait for
+  // update workgroups to retire (measured at panel 20 of c3: 92 + 154 us instead of 21 + 15).
+  masked_stream(ctx->reserve_narrow, &ctx->s_upd_narrow);
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
   }
-  LPGP_HIP(hipMalloc(&ctx->d_desc, sizeof(DevDesc)));
+  for (auto& sl : ctx->desc_ring) {
+    LPGP_HIP(hipHostMalloc(&sl.h, sizeof(DevDesc), hipHostMallocDefault));
+    LPGP_HIP(hipMalloc(&sl.d, sizeof(DevDesc)));
+    LPGP_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
   LPGP_HIP(hipMalloc(&ctx->d_info, sizeof(int)));
   if (const char* e = std::getenv("LPGP_NB")) {
     long v = std::atol(e);
@@ -343,7 +354,11 @@ int lpgp_finalize(lpgp_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
   }
-  (void)hipFree(ctx->d_desc);
+  for (auto& sl : ctx->desc_ring) {
+    (void)hipHostFree(sl.h);
+    (void)hipFree(sl.d);
+    (void)hipEventDestroy(sl.done);
+  }
   (void)hipFree(ctx->d_info);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
@@ -352,6 +367,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   ctx->pool.clear();
   (void)hipStreamDestroy(ctx->s_main);
   (void)hipStreamDestroy(ctx->s_upd);
+  if (ctx->s_upd_narrow) (void)hipStreamDestroy(ctx->s_upd_narrow);
   delete ctx;
   return 0;
 }
@@ -377,6 +393,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
+  } else if (std::strcmp(key, "small_tiles_max") == 0) {
+    ctx->small_tiles_max = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
   } else if (std::strcmp(key, "solo_small") == 0) {
@@ -536,9 +554,7 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
   rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->cap,
                        Bi.poff, Bj.poff, sym ? 1 : 0, own);
-  if (rc != 0) return rc;
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));   // desc is a stack object
-  return 0;
+  return rc;       // asynchronous: consumers are ordered behind it on the main stream
 }
 
 int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar) {
@@ -554,7 +570,7 @@ int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_
   }
   int rc = launch_add_diag(ctx->s_main, mat->a, mat->cap, B.poff, B.n, dv, scalar);
   if (rc != 0) return rc;
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  if (v_host) LPGP_HIP(hipStreamSynchronize(ctx->s_main));     // borrowed host vector, shared scratch
   return 0;
 }
 
@@ -578,6 +594,7 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
   if (what == 1) LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_to_host: matrix is not (fully) factored");
   const int64_t pn = mat->pn, n = mat->n;
   std::vector<double> tmp((size_t)pn * pn);
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
   LPGP_HIP(hipMemcpy2D(tmp.data(), (size_t)pn * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
                        (size_t)pn * sizeof(double), (size_t)pn, hipMemcpyDeviceToHost));
   // tmp is column-major pn x pn: element (r,c) at tmp[r + c*pn]
@@ -683,7 +700,6 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
   }
   r->v = (double*)pv;
   LPGP_HIP(hipMemsetAsync(r->v, 0, (size_t)r->ld * r->m_pad * sizeof(double), ctx->s_main));
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   *out = r;
   return 0;
 }
@@ -708,9 +724,7 @@ int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, co
   if (rc != 0) return rc;
   rc = launch_assemble(ctx, ctx->s_main, desc, X_obs->x, X_obs->n, X_obs->n_pad, X_test->x, X_test->n,
                        X_test->n_pad, rhs->v, rhs->ld, B.poff, 0, 0);
-  if (rc != 0) return rc;
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
-  return 0;
+  return rc;       // asynchronous (see lpgp_gram_assemble)
 }
 
 int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
@@ -801,6 +815,7 @@ int lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* 
   LPGP_CHECK(ctx && mat && rhs && out_host, "lpgp_rhs_to_host: null argument");
   LPGP_CHECK(rhs->ld == mat->pn, "lpgp_rhs_to_host: size mismatch");
   std::vector<double> h((size_t)rhs->ld * rhs->m);
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
   LPGP_HIP(hipMemcpy(h.data(), rhs->v, h.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (const auto& b : mat->blocks)
     for (int64_t i = 0; i < b.n; ++i)

@@ -338,7 +338,23 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
                     const OwnFilter& own) {
-  LPGP_HIP(hipMemcpyAsync(ctx->d_desc, &host_desc, sizeof(DevDesc), hipMemcpyHostToDevice, stream));
+  lpgp_ctx::DescSlot& slot = ctx->desc_ring[ctx->desc_next];
+  ctx->desc_next = (ctx->desc_next + 1) % lpgp_ctx::DESC_RING;
+  if (slot.used) LPGP_HIP(hipEventSynchronize(slot.done));
+  // only the used prefix of the coefficient table travels
+  int ncoef = 0;
+  for (int gi = 0; gi < host_desc.ngroups; ++gi) {
+    const DevGroup& G = host_desc.g[gi];
+    for (int c = 0; c < G.ncls; ++c) {
+      int len = 1;
+      for (int dd = 0; dd < host_desc.d; ++dd) len *= G.deg[dd] + 1;
+      if (G.coef_off[c] + len > ncoef) ncoef = G.coef_off[c] + len;
+    }
+  }
+  const size_t bytes = offsetof(DevDesc, coef) + (size_t)ncoef * sizeof(double);
+  std::memcpy(slot.h, &host_desc, bytes);
+  LPGP_HIP(hipMemcpyAsync(slot.d, slot.h, bytes, hipMemcpyHostToDevice, stream));
+  const DevDesc* d_desc = slot.d;
   AsmArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
@@ -350,14 +366,16 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   double entries = lower_only ? 0.5 * (double)n0 * ((double)n0 + 1.0) : (double)n0 * (double)n1;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
   switch (host_desc.d) {
-    case 1: hipLaunchKernelGGL(assemble_kernel<1>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
-    case 2: hipLaunchKernelGGL(assemble_kernel<2>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
-    case 3: hipLaunchKernelGGL(assemble_kernel<3>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
-    case 4: hipLaunchKernelGGL(assemble_kernel<4>, grid, dim3(256), 0, stream, ctx->d_desc, a); break;
+    case 1: hipLaunchKernelGGL(assemble_kernel<1>, grid, dim3(256), 0, stream, d_desc, a); break;
+    case 2: hipLaunchKernelGGL(assemble_kernel<2>, grid, dim3(256), 0, stream, d_desc, a); break;
+    case 3: hipLaunchKernelGGL(assemble_kernel<3>, grid, dim3(256), 0, stream, d_desc, a); break;
+    case 4: hipLaunchKernelGGL(assemble_kernel<4>, grid, dim3(256), 0, stream, d_desc, a); break;
     default: LPGP_CHECK(false, "assemble: d=%d", host_desc.d);
   }
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
+  LPGP_HIP(hipEventRecord(slot.done, stream));
+  slot.used = true;
   return 0;
 }
 

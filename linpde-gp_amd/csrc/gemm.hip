@@ -164,8 +164,10 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
   return true;
 }
 
-// TRI: lower-triangular output (symmetric rank-k update): a distinct instantiation so that the
-// SYRK launches show up under their own kernel symbol in rocprofv3 --stats.
+// TRI != 0: lower-triangular output (symmetric rank-k update).  TRI = 1 is the rank-nb trailing
+// update of the blocked Cholesky, TRI = 2 the rank-128 update inside a panel: identical code,
+// distinct instantiations, so that each shows up under its own kernel symbol in
+// rocprofv3 --stats and in its own HIP-event profiling slot.
 //
 // One 128x128 tile per workgroup, two workgroups per CU.  (A persistent variant -- 2 workgroups
 // per CU walking the tile list with cross-tile prefetch and a half-tile stagger between the two
@@ -174,7 +176,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 // scratch/stamp_test.hip) show the k-loop at 16.1 cycles per MFMA per SIMD, i.e. the matrix pipe
 // is saturated; what is left is the C prologue (~15k of ~280k cycles per tile at k = 512) and
 // the clock: 2.35 GHz on all-zero operands, 1.97-2.07 GHz on random data.)
-template <bool TA, bool TB, bool TRI>
+template <bool TA, bool TB, int TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const double alpha = g.alpha, beta = g.beta;
 
   int tr, tc;
-  if (!map_tile<TRI>(g, (int)blockIdx.x, tr, tc)) return;
+  if (!map_tile<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
 
   // per-lane byte addresses of the fragment reads (stage 0 of each operand; see frag_lane_*)
   unsigned laneM[4];
@@ -324,7 +326,181 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
       *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
 }
 
-template <bool TA, bool TB, bool TRI>
+// =========================================================================================
+// 64 x 64 tile variant for launches that cannot fill the chip with 128 x 128 tiles: the
+// latency-bound steps of the panel chain (rank-128 solves and updates with 8 ... 100 tiles)
+// and the trailing updates of the last panels.  One 128 x 128 x K tile occupies a CU's four
+// matrix pipes for K/512 * 56 us whatever else is idle; a quarter tile takes a quarter of
+// that and four times as many CUs work.  Same operand images as above with BK = 16:
+//  * M image, 64 indices per k-row: one DMA wave-instruction moves TWO k-rows (lanes 0-31 /
+//    32-63), stored as [k/2][2][64] with 16 doubles of padding per pair (LDMP = 144, so that
+//    consecutive pairs start 32 banks apart).  The four k-slots of an MFMA step read rows
+//    4ks + {0, 2, 1, 3}: slots 0/1 (lanes 0-31) then come from different pairs = different
+//    bank halves.  Both operands use the same slot order, so the contraction is unchanged.
+//  * K image: [idx][16] with the chunk swizzle of the big kernel (8 pieces of 8 rows).
+// Four stages of 16 k in a ring (73.7 KB, two workgroups per CU), three in flight; wave w owns
+// the 64 x 16 column slab w of the tile: acc[t][u] = C[16t + (l&15)][16w + 4u + (l>>4)].
+// =========================================================================================
+constexpr int LDMP = 144;
+constexpr int SOPER = 8 * LDMP;          // doubles per operand per stage (K image uses 1024 of them)
+constexpr int SSTAGES = 4;
+
+template <bool T>
+__device__ __forceinline__ void dma_tile64(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0,
+                                           int lane, int w, double* sdst) {
+  if constexpr (!T) {
+    const unsigned voff = ((unsigned)(lane >> 5) * (unsigned)ld + (unsigned)(lane & 31) * 2u) * 8u;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = qq * 4 + w;                            // k-row pair, wave-uniform
+      const char* ub = reinterpret_cast<const char*>(P + idx0 + (k0 + 2 * q) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + q * LDMP), 16, 0, 0);
+    }
+  } else {
+    const unsigned row8 = (unsigned)(lane >> 3);
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = qq * 4 + w;                            // 8 index rows
+      const unsigned c = ((unsigned)lane & 7u) ^ ((((unsigned)q << 2) + ((unsigned)lane >> 4)) & 7u);
+      const unsigned voff = (c * 2u + row8 * (unsigned)ld) * 8u;
+      const char* ub = reinterpret_cast<const char*>(P + k0 + (idx0 + (int64_t)q * 8) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + q * 128), 16, 0, 0);
+    }
+  }
+}
+
+// fragment addresses (doubles, relative to the operand's stage base); slot j = lane >> 4
+template <bool T>
+__device__ __forceinline__ unsigned frag64_lane_m(int lane, int ks) {
+  const int j = lane >> 4, i = lane & 15;
+  if constexpr (!T) return (unsigned)((j & 1) * LDMP + (j >> 1) * 64 + i);
+  else return (unsigned)(i * 16 + ((((2 * ks) + (j & 1)) ^ (i >> 1)) << 1) + (j >> 1));
+}
+template <bool T>
+__device__ __forceinline__ unsigned frag64_lane_n(int lane, int w) {
+  const int j = lane >> 4, i = lane & 3;
+  if constexpr (!T) return (unsigned)((j & 1) * LDMP + (j >> 1) * 64 + 16 * w + i);
+  else return (unsigned)((16 * w + i) * 16 + ((((j & 1) ^ (i >> 1)) & 1) << 1) + (j >> 1));
+}
+template <bool T> constexpr int frag64_imm_m(int ks, int t) { return T ? t * 256 : 2 * ks * LDMP + 16 * t; }
+template <bool T> constexpr int frag64_imm_n(int ks, int u) { return T ? u * 64 + (((ks ^ u) & 3) << 2) : 2 * ks * LDMP + 4 * u; }
+
+template <bool TA, bool TB, int TRI>
+__global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
+  const int KT = g.k / BK;
+  const double alpha = g.alpha, beta = g.beta;
+  const int mt = g.mt * 2;                          // 64-row tiles
+  const int tr = (int)blockIdx.x % mt, tc = (int)blockIdx.x / mt;
+  if (TRI != 0 && tr < tc) return;                  // (upper quarter of a diagonal 128-tile: never read)
+
+  auto sA = [&](int b) { return smem + (size_t)b * 2 * SOPER; };
+  auto sB = [&](int b) { return smem + (size_t)b * 2 * SOPER + SOPER; };
+  auto issue = [&](int kt) {
+    const int b = kt & (SSTAGES - 1);
+    dma_tile64<TA>(g.A, g.lda, (int64_t)tr * 64, (int64_t)kt * BK, lane, wu, sA(b));
+    dma_tile64<TB>(g.B, g.ldb, (int64_t)tc * 64, (int64_t)kt * BK, lane, wu, sB(b));
+  };
+  // three stages in flight before anything else (each wave: 4 DMA instructions per stage)
+#pragma unroll
+  for (int kt = 0; kt < SSTAGES - 1; ++kt)
+    if (kt < KT) issue(kt);
+
+  unsigned laneM[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) laneM[ks] = lds_base + 8u * frag64_lane_m<TA>(lane, TA ? ks : 0);
+  const unsigned laneN = lds_base + (unsigned)SOPER * 8u + 8u * frag64_lane_n<TB>(lane, wid);
+
+  char* const cub = reinterpret_cast<char*>(g.C + ((int64_t)tc * 64 + wu * 16) * g.ldc + (int64_t)tr * 64);
+  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldc + (unsigned)(lane & 15)) * 8u;
+  double acc[4][4];
+  if (beta != 0.0) {
+    const double sc_ = beta / alpha;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t][u] = sc_ * *reinterpret_cast<const double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // C and the first three stages
+
+  for (int kt = 0; kt < KT; ++kt) {
+    // stage kt has landed once at most the stages issued after it are outstanding
+    const int later = KT - 1 - kt;
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // ... for every wave; and stage kt-1 is consumed
+    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);     // into the buffer stage kt-1 was read from
+    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * 2 * SOPER) * 8u;
+    const unsigned aM0 = laneM[0] + stoff, aM1 = laneM[1] + stoff, aM2 = laneM[2] + stoff, aM3 = laneM[3] + stoff;
+    const unsigned aN = laneN + stoff;
+    double am[2][4], bn[2][4];
+    asm volatile("" ::: "memory");
+    static_for<0, 4>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      am[0][t] = lds_read_async<frag64_imm_m<TA>(0, t)>(aM0);
+    });
+    static_for<0, 4>([&](auto U_) {
+      constexpr int u = decltype(U_)::value;
+      bn[0][u] = lds_read_async<frag64_imm_n<TB>(0, u)>(aN);
+    });
+    static_for<0, 4>([&](auto K_) {
+      constexpr int ks = decltype(K_)::value;
+      if constexpr (ks + 1 < 4) {
+        const unsigned aMk = ks + 1 == 1 ? aM1 : (ks + 1 == 2 ? aM2 : aM3);
+        static_for<0, 4>([&](auto T_) {
+          constexpr int t = decltype(T_)::value;
+          am[(ks + 1) & 1][t] = lds_read_async<frag64_imm_m<TA>(ks + 1, t)>(aMk);
+        });
+        static_for<0, 4>([&](auto U_) {
+          constexpr int u = decltype(U_)::value;
+          bn[(ks + 1) & 1][u] = lds_read_async<frag64_imm_n<TB>(ks + 1, u)>(aN);
+        });
+        LDS_WAIT(8);
+      } else {
+        LDS_WAIT(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[ks & 1][u], am[ks & 1][t], acc[t][u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
+}
+
+template <bool TA, bool TB, int TRI>
+static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
+  const size_t shmem = (size_t)SSTAGES * 2 * SOPER * sizeof(double);      // 73 728 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_f64_kernel<TA, TB, TRI>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  const unsigned blocks = (unsigned)(g.mt * 2) * (unsigned)(g.nt * 2);
+  hipLaunchKernelGGL((gemm64_f64_kernel<TA, TB, TRI>), dim3(blocks), dim3(256), shmem, stream, g);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool TA, bool TB, int TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   static bool attr_set = false;
   size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
@@ -367,18 +543,31 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
   LPGP_CHECK(g.k % BK == 0, "gemm: k=%d not a multiple of %d", g.k, BK);
   LPGP_CHECK(!g.tri || (!ta && !tb), "gemm: the triangular update exists for the NT form only");
   if (prof_kernel >= 0) {
-    if (g.tri) prof_kernel = LPGP_K_SYRK;        // one profiling slot == one kernel symbol
+    if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : LPGP_K_SYRK;    // one profiling slot == one kernel symbol
     const double m = (double)g.mt * BM, n = (double)g.nt * BN, k = (double)g.k;
     // algorithmic flops: a symmetric update counts the lower trapezoid (m >= n) only
     const double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
     prof_begin(ctx, stream, prof_kernel, flops, 0.0);
   }
   int rc;
-  if (g.tri) rc = launch_impl<false, false, true>(ctx, stream, g);
-  else if (!ta && !tb) rc = launch_impl<false, false, false>(ctx, stream, g);
-  else if (!ta && tb) rc = launch_impl<false, true, false>(ctx, stream, g);
-  else if (ta && !tb) rc = launch_impl<true, false, false>(ctx, stream, g);
-  else rc = launch_impl<true, true, false>(ctx, stream, g);
+  // launches with fewer 128 x 128 tiles than CUs go to the 64 x 64-tile kernel (4x the workgroups)
+  const int64_t tiles = g.tri ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
+  // (not for in-place products X <- X * B: with 64-column tiles another workgroup would still be
+  //  reading the columns of X this one overwrites)
+  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C;
+  if (small) {
+    if (g.tri == 2) rc = launch_small<false, false, 2>(ctx, stream, g);
+    else if (g.tri) rc = launch_small<false, false, 1>(ctx, stream, g);
+    else if (!ta && !tb) rc = launch_small<false, false, 0>(ctx, stream, g);
+    else if (!ta && tb) rc = launch_small<false, true, 0>(ctx, stream, g);
+    else if (ta && !tb) rc = launch_small<true, false, 0>(ctx, stream, g);
+    else rc = launch_small<true, true, 0>(ctx, stream, g);
+  } else if (g.tri == 2) rc = launch_impl<false, false, 2>(ctx, stream, g);
+  else if (g.tri) rc = launch_impl<false, false, 1>(ctx, stream, g);
+  else if (!ta && !tb) rc = launch_impl<false, false, 0>(ctx, stream, g);
+  else if (!ta && tb) rc = launch_impl<false, true, 0>(ctx, stream, g);
+  else if (ta && !tb) rc = launch_impl<true, false, 0>(ctx, stream, g);
+  else rc = launch_impl<true, true, 0>(ctx, stream, g);
   if (prof_kernel >= 0) prof_end(ctx, stream);
   return rc;
 }

@@ -81,7 +81,9 @@ struct lpgp_ctx {
   int device = 0;
   int cus = 0;
   hipStream_t s_main = nullptr;    // panel / critical-path stream (high priority)
-  hipStream_t s_upd = nullptr;     // trailing-update stream
+  hipStream_t s_upd = nullptr;     // trailing-update stream (all CUs but `reserve`, default 8)
+  hipStream_t s_upd_narrow = nullptr;  // same with `reserve_narrow` CUs (default 64) left to the panel chain
+  int reserve_narrow = 64;
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};
   int64_t nb = 512;                // panel width of the blocked Cholesky
@@ -89,9 +91,16 @@ struct lpgp_ctx {
   int nb_big_min_tiles = 96;
   int lookahead = 1;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
+  int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   int solo_small = 0;              // small GEMM launches: one workgroup per CU (82 KB LDS request); measured: no gain
   // workspace
-  lpgp::DevDesc* d_desc = nullptr; // device copy of the current descriptor
+  // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,
+  // from there (truly asynchronously) into the slot's device copy; the slot is reused only
+  // after the event recorded behind its kernel has fired -- no stream sync per assembly call
+  static constexpr int DESC_RING = 8;
+  struct DescSlot { lpgp::DevDesc* h = nullptr; lpgp::DevDesc* d = nullptr; hipEvent_t done = nullptr; bool used = false; };
+  DescSlot desc_ring[DESC_RING];
+  int desc_next = 0;
   int* d_info = nullptr;           // potrf info word
   double* d_tmp = nullptr;         // small scratch (vectors)
   int64_t tmp_cap = 0;
@@ -165,8 +174,9 @@ int prof_collect(lpgp_ctx* ctx);
 // C(m x n) = beta*C + alpha*A*B.  All of m, n multiples of TILE, k multiple of 16.
 // ta: A element (i,kk) at A[i + kk*lda] (0) or A[kk + i*lda] (1);
 // tb: B element (kk,j) at B[j + kk*ldb] (0) or B[kk + j*ldb] (1).
-// tri: 0 full; 1 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
-//      with global row tile < global col tile are skipped.
+// tri: 0 full; 1 / 2 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
+//      with global row tile < global col tile are skipped (1: rank-nb trailing update,
+//      2: rank-128 update inside a panel -- same code, own kernel symbol and profiling slot).
 struct GemmArgs {
   const double* A;
   const double* B;

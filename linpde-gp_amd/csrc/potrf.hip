@@ -305,6 +305,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     return (ctx->nb_big > ctx->nb && rem > ctx->nb_big_min_tiles) ? (int)(ctx->nb_big / TILE) : nbt;
   };
   int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
+  hipEvent_t last_upd = nullptr;
   int it = 0;
   for (int p0 = t_done; p0 < T; ++it) {
     const int w0 = width_at(p0);
@@ -321,8 +322,8 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
-                                  p1 - jt - 1, TILE, -1.0, 1.0, 1),
-                               LPGP_K_GEMM));
+                                  p1 - jt - 1, TILE, -1.0, 1.0, 2),
+                               LPGP_K_SYRK_PANEL));
       }
     }
     if (p1 >= T) break;
@@ -337,33 +338,42 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     }
     const int w1 = width_at(p1);
     const int p2 = (p1 + w1 < T) ? p1 + w1 : T;
-    // panel done -> the remainder update may start
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));
     // (a) next panel's columns on sP; they were last written by the previous remainder update
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                          mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
                          LPGP_K_SYRK));
-    // (b) remainder on sU
+    // The remainder update (b) starts only when (a) is COMPLETE: (a) is on the critical path
+    // (the next panel waits for it), (b) is not, and launched together they share the chip by
+    // workgroup count -- measured at panel 20 of c3: (a) took 229 us next to (b) instead of
+    // ~70 us alone.  While the update bounds the pipeline the order costs nothing: the work
+    // of (a) + (b) is the same.
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
+    // (b) remainder on an update stream.  Once its estimated duration (even on the narrow
+    // stream, which leaves a quarter of the CUs to the panel chain) is below that of the next
+    // panel chain, the chain bounds the pipeline and (b) moves to the narrow stream.
     if (p2 < T) {
+      const double rem = (double)(T - p2);
+      const double t_b_us = 0.5 * rem * (rem + 1.0) * (2.0 * TILE * TILE * (double)K / 50e6);   // at 50 TFLOP/s
+      const double t_chain_us = 115.0 * (double)(p2 - p1) + 80.0;
+      const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
+      hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
       const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
-      LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
-      LPGP_TRY(launch_gemm(ctx, sU, 0, 0,
+      LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));       // (and thereby behind the previous remainder update)
+      LPGP_TRY(launch_gemm(ctx, sB, 0, 0,
                            mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
-      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
       have_upd_event = 1;
+      last_upd = ctx->ev_upd[it & 1];
     } else {
       have_upd_event = 0;
     }
     p0 = p1;
   }
-  if (la) {
-    // join: sP must not run ahead of outstanding sU work
-    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
-    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
-  }
+  // join: sP must not run ahead of the last remainder update
+  if (la && last_upd) LPGP_HIP(hipStreamWaitEvent(sP, last_upd, 0));
   int h_info = 0;
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
@@ -475,8 +485,8 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
           if (jt + 1 < p1)
             LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                  mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
-                                    p1 - jt - 1, TILE, -1.0, 1.0, 1),
-                                 LPGP_K_GEMM));
+                                    p1 - jt - 1, TILE, -1.0, 1.0, 2),
+                                 LPGP_K_SYRK_PANEL));
         }
       }
       LPGP_HIP(hipMemcpy2DAsync(pk, (size_t)rows * sizeof(double), panel, (size_t)ld * sizeof(double),
@@ -574,13 +584,13 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
       continue;
     }
     const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                          mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p1 * tb, ldv,
                             p2 - p1, mtl, K, -1.0, 1.0, 0),
                          LPGP_K_GEMM));
+    hipEvent_t evp = ctx->ev_panel[it & 1];        // (b) after (a) is complete, as in potrf_blocked
+    LPGP_HIP(hipEventRecord(evp, sP));
     if (p2 < T) {
       LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
       LPGP_TRY(launch_gemm(ctx, sU, 0, 1,

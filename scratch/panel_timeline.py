@@ -11,7 +11,7 @@ ws = last[0]['s']; we = last[-1]['e']
 print("potrf window ms", (we-ws)/1e6)
 sel=[r for r in rows if r['s']>=ws and r['s']<=we+2000000]
 tiles=[r for r in sel if 'potrf_tile' in r['Kernel_Name']]
-syrk=[r for r in sel if 'Lb0ELb0ELb1E' in r['Kernel_Name'] or 'false, false, true' in r['Kernel_Name']]
+syrk=[r for r in sel if 'false, false, 1>' in r['Kernel_Name']]
 print("panel  chain_us   tiles_us  nsyrk  big_syrk_us big_blocks  syrk_TF   gap_to_next")
 for p in range(33):
     t4 = tiles[4*p:4*p+4]

@@ -1,7 +1,7 @@
 """Turn gpurun_out/r01_* (rocprofv3 output) into the committed files under profiles/."""
 import collections, csv, glob, json, os, shutil
 os.makedirs('profiles', exist_ok=True)
-SYRK = 'gemm_f64_kernel<false, false, true>'
+SYRK = 'gemm_f64_kernel<false, false, 1>'
 st = max(glob.glob('gpurun_out/r01_stats/*/*kernel_stats.csv'), key=os.path.getmtime)
 shutil.copy(st, 'profiles/r01_bench_c3_kernel_stats.csv')
 rows = list(csv.DictReader(open(st)))

@@ -7,6 +7,9 @@ from linpde_gp_amd import _engine, problems
 from linpde_gp_amd.randprocs import covfuncs
 import linpde_gp_amd.randprocs._gaussian_process as G
 ctx = _engine.default_context()
+for kv in os.environ.get("LPGP_OPTS", "").split(","):
+    if "=" in kv:
+        k_, v_ = kv.split("="); ctx.set_option(k_, int(v_)); print("option", k_, v_)
 wl = problems.poisson_2d(128, m_side=64)
 dev = problems.upload(wl)
 prior = problems.build_prior(wl)

@@ -20,11 +20,21 @@ def test_probes(ctx):
     assert tf > 10.0 and gb > 500.0
 
 
+@pytest.fixture(params=["tile128", "tile64"])
+def gemm_kernel(ctx, request):
+    """Both GEMM kernels: launches with at most `small_tiles_max` 128x128 tiles run on the
+    64x64-tile kernel (default 256); 0 forces the 128x128-tile kernel."""
+    ctx.set_option("small_tiles_max", 0 if request.param == "tile128" else 1 << 20)
+    yield request.param
+    ctx.set_option("small_tiles_max", 256)
+
+
+@pytest.mark.parametrize("k", [16, 80, 512])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_variants(ctx, ta, tb):
+def test_gemm_variants(ctx, gemm_kernel, ta, tb, k):
     from linpde_gp_amd import _engine
     rng = np.random.default_rng(100 + 2 * ta + tb)
-    m, n, k = 384, 256, 80
+    m, n = 384, 256
     Am = rng.standard_normal((m, k))      # logical A (m x k)
     Bm = rng.standard_normal((k, n))      # logical B (k x n)
     C0 = rng.standard_normal((m, n))
@@ -37,7 +47,7 @@ def test_gemm_variants(ctx, ta, tb):
     np.testing.assert_allclose(out0, Am @ Bm, rtol=1e-13, atol=1e-12)
 
 
-def test_syrk_lower_only(ctx):
+def test_syrk_lower_only(ctx, gemm_kernel):
     from linpde_gp_amd import _engine
     rng = np.random.default_rng(7)
     n, k = 640, 512
@@ -45,7 +55,8 @@ def test_syrk_lower_only(ctx):
     C0 = rng.standard_normal((n, n))
     out, _ = _engine.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k)
     ref = C0 - P @ P.T
-    tile = np.arange(n) // 128
+    edge = 128 if gemm_kernel == "tile128" else 64
+    tile = np.arange(n) // edge
     lower_tiles = tile[:, None] >= tile[None, :]
     np.testing.assert_allclose(out[lower_tiles], ref[lower_tiles], rtol=1e-12, atol=1e-10)
     # tiles strictly above the diagonal are untouched
