@@ -160,7 +160,9 @@ int  lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
 /* ---- measurement: HIP-event timing of the hot kernels on their own streams ---------- */
 enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing update */, LPGP_K_GEMM = 2,
                       LPGP_K_POTRF_TILE = 3, LPGP_K_TRSM = 4,
-                      LPGP_K_SYRK_PANEL = 5 /* rank-128 triangular update inside a panel */, LPGP_K_COUNT = 6 };
+                      LPGP_K_SYRK_PANEL = 5 /* rank-128 triangular update inside a panel */,
+                      LPGP_K_GEMM_SMALL = 6 /* any product small enough for the 64x64-tile kernel */,
+                      LPGP_K_COUNT = 7 };
 /* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
 int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);

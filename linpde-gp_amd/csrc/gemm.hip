@@ -542,19 +542,21 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
   if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return 0;
   LPGP_CHECK(g.k % BK == 0, "gemm: k=%d not a multiple of %d", g.k, BK);
   LPGP_CHECK(!g.tri || (!ta && !tb), "gemm: the triangular update exists for the NT form only");
+  // launches with fewer 128 x 128 tiles than CUs go to the 64 x 64-tile kernel (4x the workgroups)
+  // (not for in-place products X <- X * B: with 64-column tiles another workgroup would still be
+  //  reading the columns of X this one overwrites)
+  const int64_t tiles = g.tri ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
+  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C;
   if (prof_kernel >= 0) {
-    if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : LPGP_K_SYRK;    // one profiling slot == one kernel symbol
+    // one profiling slot == one kernel symbol (family)
+    if (small) prof_kernel = LPGP_K_GEMM_SMALL;
+    else if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : LPGP_K_SYRK;
     const double m = (double)g.mt * BM, n = (double)g.nt * BN, k = (double)g.k;
     // algorithmic flops: a symmetric update counts the lower trapezoid (m >= n) only
     const double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
     prof_begin(ctx, stream, prof_kernel, flops, 0.0);
   }
   int rc;
-  // launches with fewer 128 x 128 tiles than CUs go to the 64 x 64-tile kernel (4x the workgroups)
-  const int64_t tiles = g.tri ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
-  // (not for in-place products X <- X * B: with 64-column tiles another workgroup would still be
-  //  reading the columns of X this one overwrites)
-  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C;
   if (small) {
     if (g.tri == 2) rc = launch_small<false, false, 2>(ctx, stream, g);
     else if (g.tri) rc = launch_small<false, false, 1>(ctx, stream, g);
