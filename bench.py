@@ -11,14 +11,18 @@ Point sets are resident in HBM before the timed region.  Prints ONE JSON line on
 
 N > 1 (launched by `python -m torch.distributed.run`, env RANK/LOCAL_RANK/WORLD_SIZE/
 MASTER_ADDR/MASTER_PORT): one process per GPU, all ranks factor ONE problem: panels of 512
-columns are owned cyclically by rank and broadcast with RCCL; "scaling":
-"strong".  LPGP_BENCH_REPLICAS=1 runs one independent problem per rank instead ("weak").
+columns are owned cyclically by rank and broadcast with RCCL.  The problem
+grows with N so that the algorithmic flops PER GPU stay those of c3 ("scaling": "weak":
+grid side 128 -> 144 / 162 / 182 at 2 / 4 / 8 GPUs, prediction grid side = half of it; c3
+itself is 36 ms of factorisation, far too small to shard).  LPGP_BENCH_STRONG=1 shards c3
+itself ("strong"); LPGP_BENCH_REPLICAS=1 runs one independent c3 per rank.
 The product path never imports torch; ranks rendezvous over a plain TCP star.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +61,17 @@ def cpu_baseline(problems, n_side):
     }
 
 
+def _weak_sides(world):
+    """Grid side whose algorithmic flops (Workload.algorithmic_work: N^3/3 + 2N^2 + N^2 M + 4NM,
+    N = n^2 + 4n, M = (n/2)^2) are closest to world x those of c3; m_side = n_side / 2."""
+    def flops_of(n, ms):
+        N, M = float(n * n + 4 * n), float(ms * ms)
+        return N**3 / 3.0 + 2.0 * N * N + N * N * M + 4.0 * N * M
+    target = world * flops_of(128, 64)
+    best = min(range(128, 513, 2), key=lambda n: abs(flops_of(n, n // 2) - target))
+    return best, best // 2
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); None if absent."""
@@ -84,17 +99,29 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # a hung collective must not hold the node until the caller's own limit
+    limit = float(os.environ.get("LPGP_BENCH_TIMEOUT", "1500"))
+    watchdog = threading.Timer(limit, lambda: (sys.stderr.write(f"bench.py: no result after {limit:.0f} s, aborting\n"),
+                                               os._exit(3)))
+    watchdog.daemon = True
+    watchdog.start()
+
     import linpde_gp_amd as lp
     from linpde_gp_amd import _dist, _engine, problems
 
     comm = _dist.Comm.from_env()
     ctx = _engine.default_context()          # device = LOCAL_RANK
     replicas = bool(int(os.environ.get("LPGP_BENCH_REPLICAS", "0")))
+    strong = bool(int(os.environ.get("LPGP_BENCH_STRONG", "0")))
     if world > 1 and not replicas:
         ctx.dist_init(comm)                  # RCCL communicator: distributed factorisation of ONE problem
     info = ctx.device_info()
 
-    wl = problems.poisson_2d(n_side=args.n_side, m_side=args.m_side)
+    n_side, m_side = args.n_side, args.m_side
+    weak = world > 1 and not replicas and not strong and (n_side, m_side) == (128, 64)
+    if weak:
+        n_side, m_side = _weak_sides(world)
+    wl = problems.poisson_2d(n_side=n_side, m_side=m_side)
     lp.config.gram_capacity_hint = wl.n_total
     dev = problems.upload(wl)                # point sets resident in HBM before timing
     prior = problems.build_prior(wl)
@@ -156,14 +183,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak" if (replicas and world > 1) else "strong",
+        "scaling": "weak" if ((replicas or weak) and world > 1) else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": wl.name,
-            "n_collocation": args.n_side**2,
-            "n_boundary": 4 * args.n_side,
+            "n_collocation": n_side**2,
+            "n_boundary": 4 * n_side,
             "n_total": wl.n_total,
             "m_predict": int(wl.Xtest.shape[0]),
             "boundary_noise_var": 1e-8,
@@ -171,7 +198,8 @@ def main():
             "multi_gpu": ("single GPU" if world == 1 else
                           "independent replicas (one problem per GPU)" if replicas else
                           f"one problem, panels of 512 columns owned cyclically by {world} ranks (1x{world} grid), "
-                          "RCCL panel broadcast, replicated factor, prediction points sharded"),
+                          "RCCL panel broadcast, replicated factor, prediction points sharded"
+                          + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
             "device": info["name"].strip(),
         },
         "roofline": {

@@ -13,6 +13,7 @@
 //   remainder (second stream): look-ahead of one panel.
 
 #include <climits>
+#include <cstdlib>
 
 #include <rccl/rccl.h>
 
@@ -394,6 +395,23 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
 // panel k.  The only collective is the panel broadcast; message size (T-p0)*128*nb*8 B
 // (c4: up to 272 MB), total received per rank ~ 4 N^2 bytes.
 // ---------------------------------------------------------------------------------------
+// column-major rows x cols block copy (rows a multiple of 128): pack / unpack of a panel.
+// (hipMemcpy2DAsync device-to-device ran at ~0.1 TB/s here: 1.1 ms per panel at N = 34k.)
+__global__ __launch_bounds__(256) void copy2d_kernel(double* __restrict__ dst, int64_t ldd,
+                                                      const double* __restrict__ src, int64_t lds, int64_t rows) {
+  const int64_t c = blockIdx.y;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (r < rows)
+    *reinterpret_cast<double2*>(dst + c * ldd + r) = *reinterpret_cast<const double2*>(src + c * lds + r);
+}
+static int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, dst, ldd,
+                     src, lds, rows);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
 static int ensure_pack(lpgp_ctx* ctx, size_t doubles) {
   if (doubles <= ctx->pack_cap) return 0;
   if (ctx->d_pack) LPGP_HIP(hipFree(ctx->d_pack));
@@ -489,22 +507,24 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
                                  LPGP_K_SYRK_PANEL));
         }
       }
-      LPGP_HIP(hipMemcpy2DAsync(pk, (size_t)rows * sizeof(double), panel, (size_t)ld * sizeof(double),
-                                (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyDeviceToDevice, sP));
+      LPGP_TRY(copy2d(sP, pk, rows, panel, ld, rows, cols));
       LPGP_HIP(hipMemcpyAsync(pk + (size_t)rows * cols, linv0, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
                               hipMemcpyDeviceToDevice, sP));
     }
     LPGP_NCCL(ncclBroadcast(pk, pk, cnt, ncclDouble, own, comm, sP));
-    if (own != me) {
-      LPGP_HIP(hipMemcpy2DAsync(panel, (size_t)ld * sizeof(double), pk, (size_t)rows * sizeof(double),
-                                (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyDeviceToDevice, sP));
+    static const bool selftest = std::getenv("LPGP_DIST_SELFTEST") != nullptr;
+    if (own == me && selftest) {
+      // single-GPU test of the receive path: forget the panel (NaN bytes), then unpack it like a receiver
+      LPGP_HIP(hipMemset2DAsync(panel, (size_t)ld * sizeof(double), 0xFF, (size_t)rows * sizeof(double), (size_t)cols, sP));
+      LPGP_HIP(hipMemsetAsync(linv0, 0xFF, (size_t)(p1 - p0) * TILE * TILE * sizeof(double), sP));
+    }
+    if (own != me || selftest) {
+      LPGP_TRY(copy2d(sP, panel, ld, pk, rows, rows, cols));
       LPGP_HIP(hipMemcpyAsync(linv0, pk + (size_t)rows * cols, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
                               hipMemcpyDeviceToDevice, sP));
     }
     if (p1 >= T) break;
     const int K = cols;
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));
     // (a) look-ahead: the owner of the next panel brings its columns up to date on the panel stream
     const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
     if (owner_of(p1) == me) {
@@ -514,6 +534,9 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
                            mk(P1, ld, P1, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
     }
+    // (b) is released when (a) is complete (see potrf_blocked)
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
     // (b) the other owned panels on the update stream
     LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
     for (int q0 = p2; q0 < T; q0 += nbt) {

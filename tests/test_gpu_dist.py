@@ -20,6 +20,7 @@ import linpde_gp_amd as lp
 from linpde_gp_amd import _dist, _engine, problems
 from oracle import workloads as owl
 os.environ["LPGP_FORCE_RCCL"] = "1"
+os.environ["LPGP_DIST_SELFTEST"] = "1"       # the owner also runs the receive path (panel wiped, then unpacked)
 comm = _dist.Comm(0, 1)
 ctx = _engine.default_context()
 ctx.dist_init(comm)
