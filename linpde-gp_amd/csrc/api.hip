@@ -393,6 +393,9 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
+  } else if (std::strcmp(key, "test_assemble_as") == 0) {      // world * 1000 + rank, 0 = off (tests only)
+    ctx->test_own_world = (int)(value / 1000);
+    ctx->test_own_rank = (int)(value % 1000);
   } else if (std::strcmp(key, "small_tiles_max") == 0) {
     ctx->small_tiles_max = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
@@ -552,6 +555,7 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   // a block append) are needed by every rank
   OwnFilter own;
   own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
+  if (ctx->test_own_world > 1) { own.world = ctx->test_own_world; own.rank = ctx->test_own_rank; }
   rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->cap,
                        Bi.poff, Bj.poff, sym ? 1 : 0, own);
   return rc;       // asynchronous: consumers are ordered behind it on the main stream

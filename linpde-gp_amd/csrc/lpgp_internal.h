@@ -110,6 +110,7 @@ struct lpgp_ctx {
   std::vector<PoolBuf> pool;
   // multi-GPU (one process per GPU): cyclic panel ownership + RCCL panel broadcast
   int rank = 0, world = 1;
+  int test_own_world = 0, test_own_rank = 0;   // tests only: ownership filter of the assembly as if (rank, world)
   void* nccl_comm = nullptr;       // ncclComm_t
   double* d_pack = nullptr;        // packed panel staging for the broadcast
   size_t pack_cap = 0;             // doubles

@@ -39,3 +39,39 @@ def test_world1_rccl_path_matches_oracle():
     out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST1" in out.stdout
+
+
+def test_assembly_ownership_filter():
+    """A rank of a P-rank job assembles only the tile columns of the panels it owns (panel i of
+    512 columns belongs to rank i % P); checked on one GPU by assembling AS rank r of P = 3 into
+    a matrix pre-filled by a full assembly of a different kernel."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd"))
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _engine
+    cf = lp.randprocs.covfuncs
+    ctx = _engine.default_context()
+    rng = np.random.default_rng(5)
+    n = 1700                                            # 4 panels of 512 columns, ragged
+    X = rng.uniform(-1, 1, size=(n, 2))
+    pts = _engine.Points(ctx, X)
+    k_a = cf.TensorProduct(cf.Matern((), nu=2.5), cf.Matern((), nu=2.5))
+    k_b = 3.0 * cf.TensorProduct(cf.Matern((), nu=1.5), cf.Matern((), nu=1.5))
+    Ga, Gb = k_a.matrix(X), k_b.matrix(X)
+    try:
+        for rank in range(3):
+            mat = _engine.GramMatrix(ctx, n)
+            mat.add_block(n)
+            mat.assemble(k_b.lower(), pts, None, 0, 0)             # everything: kernel b
+            ctx.set_option("test_assemble_as", 3 * 1000 + rank)
+            mat.assemble(k_a.lower(), pts, None, 0, 0)             # owned panels: kernel a
+            ctx.set_option("test_assemble_as", 0)
+            G = mat.todense("gram")
+            owner = (np.arange(n) // 512) % 3
+            for j0 in range(0, n, 512):
+                cols = slice(j0, min(j0 + 512, n))
+                want = Ga if owner[j0] == rank else Gb
+                blk = np.tril(G)[:, cols]
+                np.testing.assert_allclose(blk, np.tril(want)[:, cols], rtol=0, atol=1e-12)
+            del mat
+    finally:
+        ctx.set_option("test_assemble_as", 0)
