@@ -262,6 +262,32 @@ def test_iterative_equals_oneshot_and_linop_readout(lp):
     np.testing.assert_allclose(rvL.cov, post.cov(Xt, Ltest=lap), rtol=1e-7, atol=1e-6)
 
 
+def test_condition_normal_on_observations(lp):
+    """Finite-dimensional Gaussian conditioning (`randvars/_normal.py:8-71`) vs its dense NumPy form."""
+    rng = np.random.default_rng(31)
+    n, m = 37, 11
+    B = rng.standard_normal((n, n))
+    prior = lp.randvars.Normal(rng.standard_normal(n), B @ B.T + n * np.eye(n))
+    A = rng.standard_normal((m, n))
+    Cn = rng.standard_normal((m, m))
+    noise = lp.randvars.Normal(rng.standard_normal(m), Cn @ Cn.T + 0.1 * np.eye(m))
+    y = rng.standard_normal(m)
+    for tr, nz in ((A, noise), (A, None), (None, lp.randvars.Normal(np.zeros(n), 0.5 * np.eye(n)))):
+        obs = y if tr is not None else rng.standard_normal(n)
+        post = prior.condition_on_observations(obs, nz, tr)
+        At = np.eye(n) if tr is None else tr
+        S = At @ prior.cov @ At.T + (0 if nz is None else nz.cov)
+        K = np.linalg.solve(S, At @ prior.cov).T
+        ref_mean = prior.mean + K @ (obs - At @ prior.mean - (0 if nz is None else nz.mean))
+        ref_cov = prior.cov - K @ At @ prior.cov
+        np.testing.assert_allclose(post.mean, ref_mean, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(post.cov, ref_cov, rtol=1e-9, atol=1e-9)
+    # one scalar observation through a row vector (`np.ndim(A) == 1` branch of the reference)
+    post = prior.condition_on_observations(np.array(0.3), lp.randvars.Normal(np.zeros(()), np.array(0.01)), A[0])
+    s = A[0] @ prior.cov @ A[0] + 0.01
+    np.testing.assert_allclose(post.mean, prior.mean + prior.cov @ A[0] * (0.3 - A[0] @ prior.mean) / s, rtol=1e-10)
+
+
 def test_potrs_multiple_rhs_and_dense_noise(lp):
     cf = lp.randprocs.covfuncs
     rng = np.random.default_rng(0)
