@@ -157,12 +157,21 @@ int  lpgp_kernel_diag(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, doub
 int  lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                         const lpgp_pts* X0, const lpgp_pts* X1, double* out_host);
 
+/* matrix-free product  out (n0 x nrhs, C-order) = [sum_g (kd[g])(X0, X1)] v   with v (n1 x nrhs,
+ * C-order): every kernel entry is evaluated on the fly, the n0 x n1 matrix is never formed.
+ * Replaces the `_keops_lazy_tensor` hooks (diffops/_matern.py:112-135,231-264,
+ * experiments/cpu.py:214-229) behind `CovarianceFunction.linop(x0, x1) @ v`.               */
+int  lpgp_kernel_matvec(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
+                        const lpgp_pts* X0, const lpgp_pts* X1,
+                        const double* v_host, int64_t nrhs, double* out_host);
+
 /* ---- measurement: HIP-event timing of the hot kernels on their own streams ---------- */
 enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing update */, LPGP_K_GEMM = 2,
                       LPGP_K_POTRF_TILE = 3, LPGP_K_TRSM = 4,
                       LPGP_K_SYRK_PANEL = 5 /* rank-128 triangular update inside a panel */,
                       LPGP_K_GEMM_SMALL = 6 /* any product small enough for the 64x64-tile kernel */,
-                      LPGP_K_COUNT = 7 };
+                      LPGP_K_MATVEC = 7 /* matrix-free kernel product */,
+                      LPGP_K_COUNT = 8 };
 /* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
 int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);

@@ -865,6 +865,51 @@ int lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
 }
 
 // ---- measurement ----------------------------------------------------------------------------
+int lpgp_kernel_matvec(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
+                       const lpgp_pts* X1, const double* v_host, int64_t nrhs, double* out_host) {
+  LPGP_CHECK(ctx && kd && X0 && X1 && v_host && out_host && nrhs >= 1, "lpgp_kernel_matvec: bad argument");
+  LPGP_CHECK(X0->d == X1->d && kd[0].d == X0->d, "lpgp_kernel_matvec: dimension mismatch");
+  const int64_t n0 = X0->n, n1 = X1->n;
+  if (n0 == 0) return 0;
+  if (n1 == 0) {
+    std::memset(out_host, 0, (size_t)(n0 * nrhs) * sizeof(double));
+    return 0;
+  }
+  DevDesc desc;
+  int rc = lower_kdesc(kd, ngroups, &desc);
+  if (rc != 0) return rc;
+  // enough workgroups to fill the chip: row tiles x column splits >= ~4 per CU
+  const int tiles_r = (int)((n0 + 63) / 64), tiles_c = (int)((n1 + 63) / 64);
+  int splits = (4 * ctx->cus + tiles_r - 1) / tiles_r;
+  if (splits > tiles_c) splits = tiles_c;
+  if (splits < 1) splits = 1;
+  const int64_t n0p = X0->n_pad, n1p = X1->n_pad;
+  double *dv = nullptr, *dpart = nullptr, *dout = nullptr;
+  void* p = nullptr;
+  const size_t bv = (size_t)MV_RHS * n1p * sizeof(double), bp = (size_t)splits * MV_RHS * n0p * sizeof(double),
+               bo = (size_t)MV_RHS * n0p * sizeof(double);
+  if (pool_alloc(ctx, &p, bv + bp + bo, nullptr) != 0) return -1;
+  dv = (double*)p;
+  dpart = dv + (size_t)MV_RHS * n1p;
+  dout = dpart + (size_t)splits * MV_RHS * n0p;
+  std::vector<double> hv((size_t)MV_RHS * n1p), ho((size_t)MV_RHS * n0p);
+  for (int64_t r0 = 0; r0 < nrhs && rc == 0; r0 += MV_RHS) {
+    const int nr = (int)((nrhs - r0 < MV_RHS) ? nrhs - r0 : MV_RHS);
+    for (int r = 0; r < nr; ++r)
+      for (int64_t j = 0; j < n1; ++j) hv[(size_t)r * n1p + j] = v_host[j * nrhs + r0 + r];
+    if (hipMemcpyAsync(dv, hv.data(), (size_t)nr * n1p * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) rc = -1;
+    if (rc == 0) rc = launch_matvec(ctx, ctx->s_main, desc, X0->x, n0, n0p, X1->x, n1, n1p, dv, nr, dpart, splits, dout);
+    if (rc == 0 && hipMemcpyAsync(ho.data(), dout, (size_t)nr * n0p * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) rc = -1;
+    if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
+    if (rc == 0)
+      for (int r = 0; r < nr; ++r)
+        for (int64_t i = 0; i < n0; ++i) out_host[i * nrhs + r0 + r] = ho[(size_t)r * n0p + i];
+  }
+  pool_free(ctx, p, bv + bp + bo);
+  if (rc == -1) set_error("lpgp_kernel_matvec: HIP error %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}
+
 int lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask) {
   int rc = prof_collect(ctx);
   ctx->prof_on = mask;

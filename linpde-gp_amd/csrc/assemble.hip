@@ -334,10 +334,9 @@ __global__ void add_dense_lower_kernel(double* a, int64_t ld, int64_t off, int64
   if (i < n && j <= i) a[(off + i) + (off + j) * ld] += b[i * n + j];
 }
 
-int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
-                    int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
-                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
-                    const OwnFilter& own) {
+// Copy a lowered descriptor into the next slot of the context's ring (pinned host -> device,
+// asynchronous); the caller records slot.done behind the kernel that reads it.
+static int stage_desc(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, lpgp_ctx::DescSlot** out) {
   lpgp_ctx::DescSlot& slot = ctx->desc_ring[ctx->desc_next];
   ctx->desc_next = (ctx->desc_next + 1) % lpgp_ctx::DESC_RING;
   if (slot.used) LPGP_HIP(hipEventSynchronize(slot.done));
@@ -354,6 +353,18 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   const size_t bytes = offsetof(DevDesc, coef) + (size_t)ncoef * sizeof(double);
   std::memcpy(slot.h, &host_desc, bytes);
   LPGP_HIP(hipMemcpyAsync(slot.d, slot.h, bytes, hipMemcpyHostToDevice, stream));
+  *out = &slot;
+  return 0;
+}
+
+int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
+                    int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
+                    double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
+                    const OwnFilter& own) {
+  lpgp_ctx::DescSlot* slotp = nullptr;
+  int rc_ = stage_desc(ctx, stream, host_desc, &slotp);
+  if (rc_ != 0) return rc_;
+  lpgp_ctx::DescSlot& slot = *slotp;
   const DevDesc* d_desc = slot.d;
   AsmArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
@@ -376,6 +387,122 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   LPGP_HIP(hipGetLastError());
   LPGP_HIP(hipEventRecord(slot.done, stream));
   slot.used = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Matrix-free product  Y = K(X0, X1) V : every entry is evaluated on the fly and consumed in
+// registers, nothing of the n0 x n1 matrix touches HBM.  This is the slot the reference fills
+// with KeOps lazy tensors (`_keops_lazy_tensor`, diffops/_matern.py:112-135,231-264;
+// experiments/cpu.py:214-229) for iterative solvers beyond dense-memory N.
+// Bound: fp64 VALU (one exp + the Horner polynomial per entry; 2*nrhs flops of "useful" work).
+// A workgroup owns 64 rows and one of `splits` column ranges; lane = row, wave = 16-column
+// slab of each 64-column tile, up to MV_R right-hand sides ride along per evaluation.
+// Partial sums per split go to `part`; mv_reduce_kernel adds them in a fixed order.
+// ---------------------------------------------------------------------------------------
+constexpr int MV_R = MV_RHS;
+
+struct MvArgs {
+  const double* x0;
+  const double* x1;
+  int64_t n0, n1, n0_pad, n1_pad;
+  const double* v;               // device, [r][n1_pad]
+  double* part;                  // device, [split][r][n0_pad]
+  int32_t nr;                    // right-hand sides in this pass (<= MV_R)
+  int32_t tiles_r, tiles_c, splits;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__ desc, MvArgs a) {
+  __shared__ double sx1[D][AT];
+  __shared__ double sv[MV_R][AT];
+  __shared__ double red[3][MV_R][AT];
+  const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)tr * AT + lane;
+  double xr[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  double y[MV_R];
+#pragma unroll
+  for (int r = 0; r < MV_R; ++r) y[r] = 0.0;
+  const int per = (a.tiles_c + a.splits - 1) / a.splits;
+  const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
+  for (int tc = sp * per; tc < tc_end; ++tc) {
+    __syncthreads();                                   // previous tile consumed
+    {
+      const int64_t c = (int64_t)tc * AT + lane;       // wave w stages coordinate / vector row w, w+4, ...
+      for (int j = w; j < D; j += 4) sx1[j][lane] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.n1_pad + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 16 / AE; ++pass) {
+      const int cb = w * 16 + pass * AE;
+      double dx[D][AE], res[AE];
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int e = 0; e < AE; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
+      eval_entries<D>(desc, dx, res);
+#pragma unroll
+      for (int e = 0; e < AE; ++e)
+#pragma unroll
+        for (int r = 0; r < MV_R; ++r) y[r] = fma(res[e], sv[r][cb + e], y[r]);   // columns >= n1 carry v = 0
+    }
+  }
+  __syncthreads();
+  if (w > 0) {
+#pragma unroll
+    for (int r = 0; r < MV_R; ++r) red[w - 1][r][lane] = y[r];
+  }
+  __syncthreads();
+  if (w == 0 && row < a.n0) {
+#pragma unroll
+    for (int r = 0; r < MV_R; ++r)
+      if (r < a.nr) a.part[((int64_t)sp * MV_R + r) * a.n0_pad + row] = ((y[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+  }
+}
+
+__global__ void mv_reduce_kernel(const double* __restrict__ part, double* __restrict__ out, int64_t n0, int64_t n0_pad,
+                                 int splits, int nr) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (i >= n0 || r >= nr) return;
+  double s = 0.0;
+  for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * MV_R + r) * n0_pad + i];
+  out[(int64_t)r * n0_pad + i] = s;
+}
+
+// out[r][n0_pad] = sum_j K(x0_i, x1_j) v[r][j] for r < nr <= MV_R; `part` holds splits*MV_R*n0_pad doubles
+int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
+                  int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
+                  double* part, int splits, double* out) {
+  lpgp_ctx::DescSlot* slot = nullptr;
+  int rc = stage_desc(ctx, stream, host_desc, &slot);
+  if (rc != 0) return rc;
+  MvArgs a;
+  a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
+  a.v = v; a.part = part; a.nr = nr;
+  a.tiles_r = (int)((n0 + AT - 1) / AT);
+  a.tiles_c = (int)((n1 + AT - 1) / AT);
+  a.splits = splits;
+  dim3 grid((unsigned)((int64_t)a.tiles_r * splits));
+  prof_begin(ctx, stream, LPGP_K_MATVEC, 2.0 * (double)n0 * (double)n1 * nr, 0.0);
+  switch (host_desc.d) {
+    case 1: hipLaunchKernelGGL(matvec_kernel<1>, grid, dim3(256), 0, stream, slot->d, a); break;
+    case 2: hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, stream, slot->d, a); break;
+    case 3: hipLaunchKernelGGL(matvec_kernel<3>, grid, dim3(256), 0, stream, slot->d, a); break;
+    case 4: hipLaunchKernelGGL(matvec_kernel<4>, grid, dim3(256), 0, stream, slot->d, a); break;
+    default: LPGP_CHECK(false, "matvec: d=%d", host_desc.d);
+  }
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  LPGP_HIP(hipEventRecord(slot->done, stream));
+  slot->used = true;
+  hipLaunchKernelGGL(mv_reduce_kernel, dim3((unsigned)((n0 + 255) / 256), (unsigned)nr), dim3(256), 0, stream,
+                     (const double*)part, out, n0, n0_pad, splits, nr);
+  LPGP_HIP(hipGetLastError());
   return 0;
 }
 

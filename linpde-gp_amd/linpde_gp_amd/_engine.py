@@ -315,6 +315,18 @@ def kernel_matrix(ctx: Context, kdesc, X0: Points, X1: Points) -> np.ndarray:
     return out
 
 
+def kernel_matvec(ctx: Context, kdesc, X0: Points, X1: Points, V: np.ndarray) -> np.ndarray:
+    """K(X0, X1) @ V without forming K (`lpgp_kernel_matvec`); V of shape (n1,) or (n1, nrhs)."""
+    arr = _lib.make_kdesc_array(kdesc)
+    V = np.asarray(V, dtype=np.double)
+    vec = V.ndim == 1
+    V2 = np.ascontiguousarray(V.reshape(X1.n, -1))
+    out = np.empty((X0.n, V2.shape[1]))
+    check(lib.lpgp_kernel_matvec(ctx._h, arr, len(arr), X0._h, X1._h, as_pd(V2), V2.shape[1], as_pd(out)),
+          "lpgp_kernel_matvec")
+    return out[:, 0] if vec else out
+
+
 def test_gemm(ctx: Context, ta: int, tb: int, lower_only: int, alpha: float, A: np.ndarray, B: np.ndarray,
               beta: float, Cm: np.ndarray, k: int, reps: int = 0):
     """Raw GEMM on column-major (Fortran-ordered) arrays; returns (C, ms_per_rep)."""

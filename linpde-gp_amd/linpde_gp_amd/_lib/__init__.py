@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "liblpgp.so")
 MAXD, MAXT, MAXG = 4, 64, 4
 MATERN_HALFINT, EXPQUAD = 1, 2
 K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small")
+KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec")
 
 
 class Term(C.Structure):
@@ -90,6 +90,7 @@ def _load() -> C.CDLL:
     sig("lpgp_rhs_to_host", C.c_int, vp, vp, vp, pd)
     sig("lpgp_kernel_diag", C.c_int, vp, pk, i32, pd)
     sig("lpgp_kernel_matrix", C.c_int, vp, pk, i32, vp, vp, pd)
+    sig("lpgp_kernel_matvec", C.c_int, vp, pk, i32, vp, vp, pd, i64, pd)
     sig("lpgp_profile_enable", C.c_int, vp, i32)
     sig("lpgp_profile_reset", C.c_int, vp)
     sig("lpgp_profile_get", C.c_int, vp, i32, pd, C.POINTER(i64), pd, pd)
@@ -109,7 +110,7 @@ EXPORTED = [
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
-    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_profile_enable", "lpgp_profile_reset",
+    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_probe_mfma_f64",
     "lpgp_probe_hbm_write",
 ]

@@ -102,6 +102,12 @@ class CovarianceFunction:
             raise ValueError("`matrix` needs inputs of shape (N,) + input_shape")
         return _engine.kernel_matrix(ctx, self.lower(), P0, _engine.Points(ctx, X1))
 
+    def linop(self, x0, x1=None) -> "KernelLinearOperator":
+        """Matrix-free `k(x0, x1)` as a linear operator (probnum `CovarianceFunction.linop`; the
+        reference backs it with KeOps lazy tensors, `_keops_lazy_tensor`): `@` evaluates the
+        kernel on the fly on the device, `todense()` materialises it."""
+        return KernelLinearOperator(self, x0, x0 if x1 is None else x1)
+
     def __call__(self, x0, x1=None) -> np.ndarray:
         """Broadcasting evaluation k(x0, x1); `x1=None` gives the diagonal k(x0, x0)."""
         from ... import _engine
@@ -257,6 +263,66 @@ class SumCovarianceFunction(CovarianceFunction):
 
     def _operator_coeffs(self):
         return self._summands[0]._operator_coeffs()
+
+
+class KernelLinearOperator:
+    """`k(X0, X1)` as a matrix-free operator: products run `lpgp_kernel_matvec` (every entry
+    evaluated on the fly in registers), the point sets stay resident on the device."""
+
+    def __init__(self, covfunc: CovarianceFunction, x0, x1):
+        from ... import _engine
+
+        X0, b0 = covfunc._points(x0)
+        X1, b1 = covfunc._points(x1)
+        if len(b0) != 1 or len(b1) != 1:
+            raise ValueError("`linop` needs inputs of shape (N,) + input_shape")
+        self._ctx = _engine.default_context()
+        self._k = covfunc
+        self._desc = covfunc.lower()
+        self._P0 = _engine.Points(self._ctx, X0)
+        self._P1 = self._P0 if x1 is x0 else _engine.Points(self._ctx, X1)
+        self.shape = (X0.shape[0], X1.shape[0])
+        self.dtype = np.dtype(np.double)
+
+    def __matmul__(self, V):
+        from ... import _engine
+
+        V = np.asarray(V, dtype=np.double)
+        if V.shape[0] != self.shape[1]:
+            raise ValueError(f"shape mismatch: {self.shape} @ {V.shape}")
+        return _engine.kernel_matvec(self._ctx, self._desc, self._P0, self._P1, V)
+
+    matmul = __matmul__
+
+    @property
+    def T(self):
+        return _TransposedKernelOperator(self)
+
+    def todense(self):
+        from ... import _engine
+
+        return _engine.kernel_matrix(self._ctx, self._desc, self._P0, self._P1)
+
+
+class _TransposedKernelOperator:
+    def __init__(self, op: KernelLinearOperator):
+        self._op = op
+        self.shape = op.shape[::-1]
+        # (L0 k L1')(x, x') = (L1 k L0')(x', x) for the symmetric base kernels here: exchange
+        # the operator maps of the two arguments
+        L0, L1 = op._k._operator_coeffs()
+        self._desc = lower_groups(op._k._base_groups(), L1, L0)
+
+    def __matmul__(self, V):
+        from ... import _engine
+
+        V = np.asarray(V, dtype=np.double)
+        if V.shape[0] != self.shape[1]:
+            raise ValueError(f"shape mismatch: {self.shape} @ {V.shape}")
+        return _engine.kernel_matvec(self._op._ctx, self._desc, self._op._P1, self._op._P0, V)
+
+    def todense(self):
+        return self._op.todense().T
 
 
 class Zero(CovarianceFunction):
