@@ -99,6 +99,15 @@ int64_t lpgp_mat_padded_size(const lpgp_mat* mat);    /* internal padded size   
 int  lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                         const lpgp_pts* X0, const lpgp_pts* X1,
                         lpgp_mat* mat, int32_t bi, int32_t bj);
+/* The same block when its point sets are TENSOR GRIDS: rows = grid F0[0] x ... x F0[d-1] and
+ * columns = grid F1[0] x ... x F1[d-1] of 1-D point sets (C order, last factor fastest; F1 ==
+ * NULL for bi == bj).  The block is then a sum of Kronecker products of 1-D kernel matrices:
+ * O(T d n^2) kernel evaluations + an HBM-write-bound expansion instead of N^2 evaluations.
+ * Replaces the Kronecker `linop` of `TensorProduct` / `TensorProduct_LinDiffOp_LinDiffOp`
+ * (covfuncs/_tensor_product.py:64-82, diffops/_tensor_product.py:140-156).                  */
+int  lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
+                             const lpgp_pts* const* F0, const lpgp_pts* const* F1,
+                             lpgp_mat* mat, int32_t bi, int32_t bj);
 /* diagonal of block bi += v_host[i] (v_host may be NULL) + scalar                       */
 int  lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar);
 /* diagonal block bi += B_host (n_bi x n_bi, C-order, symmetric)                          */

@@ -561,6 +561,42 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   return rc;       // asynchronous: consumers are ordered behind it on the main stream
 }
 
+int lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* const* F0,
+                            const lpgp_pts* const* F1, lpgp_mat* mat, int32_t bi, int32_t bj) {
+  LPGP_CHECK(ctx && kd && F0 && mat, "lpgp_gram_assemble_grid: null argument");
+  LPGP_CHECK(ngroups >= 1 && ngroups <= LPGP_MAXG, "lpgp_gram_assemble_grid: bad ngroups %d", ngroups);
+  LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size() && bj >= 0 && bj <= bi, "lpgp_gram_assemble_grid: bad block (%d,%d)", bi, bj);
+  const lpgp_block& Bi = mat->blocks[bi];
+  const lpgp_block& Bj = mat->blocks[bj];
+  LPGP_CHECK(Bi.poff >= mat->pn_fact, "lpgp_gram_assemble_grid: block %d is already factored", bi);
+  const bool sym = (F1 == nullptr);
+  LPGP_CHECK(sym == (bi == bj), "lpgp_gram_assemble_grid: F1 must be NULL exactly for diagonal blocks");
+  const int D = kd[0].d;
+  LPGP_CHECK(D >= 1 && D <= LPGP_MAXD, "lpgp_gram_assemble_grid: d=%d", D);
+  const double *f0[LPGP_MAXD], *f1[LPGP_MAXD];
+  int64_t n0d[LPGP_MAXD], n1d[LPGP_MAXD], n0 = 1, n1 = 1;
+  for (int d = 0; d < D; ++d) {
+    const lpgp_pts* a = F0[d];
+    const lpgp_pts* b = sym ? F0[d] : F1[d];
+    LPGP_CHECK(a && b && a->d == 1 && b->d == 1 && a->n >= 1 && b->n >= 1, "lpgp_gram_assemble_grid: factor %d must be a 1-D point set", d);
+    f0[d] = a->x; f1[d] = b->x;
+    n0d[d] = a->n; n1d[d] = b->n;
+    n0 *= a->n; n1 *= b->n;
+  }
+  LPGP_CHECK(n0 == Bi.n && n1 == Bj.n, "lpgp_gram_assemble_grid: grids have %lld x %lld points, block (%d,%d) is %lld x %lld",
+             (long long)n0, (long long)n1, bi, bj, (long long)Bi.n, (long long)Bj.n);
+  const size_t wd = kron_work_doubles(D, n0d, n1d);
+  void* work = nullptr;
+  if (pool_alloc(ctx, &work, wd * sizeof(double), nullptr) != 0) return -1;
+  OwnFilter own;
+  own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
+  if (ctx->test_own_world > 1) { own.world = ctx->test_own_world; own.rank = ctx->test_own_rank; }
+  int rc = launch_assemble_kron(ctx, ctx->s_main, kd, ngroups, f0, n0d, f1, n1d, (double*)work, wd, mat->a, mat->cap,
+                                Bi.poff, Bj.poff, sym ? 1 : 0, own);
+  pool_free(ctx, work, wd * sizeof(double));       // reuse is ordered behind this launch on the main stream
+  return rc;
+}
+
 int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar) {
   LPGP_CHECK(ctx && mat && bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_mat_add_diag: bad argument");
   const lpgp_block& B = mat->blocks[bi];

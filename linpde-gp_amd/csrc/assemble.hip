@@ -506,6 +506,214 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Tensor-grid ("Kronecker") assembly.  Every kernel this library evaluates is a product over
+// input dimensions, so on point sets that are tensor grids (rows = grid of factors F0[0..D),
+// columns = grid of F1[0..D), C order) a block is a sum of Kronecker products of 1-D matrices:
+//   G[(i_0..i_{D-1}), (j_0..j_{D-1})] = sum_t c_t prod_d M_{u(t,d)}[i_d, j_d],
+//   M_u = [d^{n0} d'^{n1} k_d](F0[d], F1[d])   (each distinct (d, n0, n1) of a group once).
+// This is the structure the reference exposes as `TensorProduct.linop` /
+// `TensorProduct_LinDiffOp_LinDiffOp.linop` (covfuncs/_tensor_product.py:64-82,
+// diffops/_tensor_product.py:140-156).  The 1-D matrices come from assemble_kernel<1>
+// (O(T d n^2) kernel evaluations instead of O(N^2)); kron_expand_kernel then writes the block
+// with a handful of cached loads and multiplies per entry: no exp, no polynomial.
+// ---------------------------------------------------------------------------------------
+constexpr int KR_MAXT = 48;      // terms over all groups
+constexpr int KR_MAXU = 16;      // distinct 1-D matrices per dimension
+
+struct KronArgs {
+  int32_t nterms;
+  int32_t nuniq[LPGP_MAXD];
+  int32_t n0d[LPGP_MAXD], n1d[LPGP_MAXD];     // grid extents per dimension (rows / columns)
+  int32_t ldu[LPGP_MAXD];                     // leading dimension of the 1-D matrices of dimension d
+  const double* u[LPGP_MAXD];                 // dimension d: nuniq[d] matrices, n1d[d] * ldu[d] doubles apart
+  double coef[KR_MAXT];
+  uint8_t which[KR_MAXT][LPGP_MAXD];          // term t uses matrix which[t][d] of dimension d
+  int64_t n0, n1;
+  double* out;
+  int64_t ld, row_off, col_off;
+  int32_t lower_only, tiles_r, tiles_c;
+  int32_t own_world, own_rank;
+  int64_t own_from, own_width;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
+  const int tr = blockIdx.x % a.tiles_r, tc = blockIdx.x / a.tiles_r;
+  const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
+  if (a.lower_only && c0 > r0 + AT - 1) return;
+  if (a.own_world > 1) {
+    const int64_t gc = a.col_off + c0;
+    if (gc >= a.own_from && (int)(((gc - a.own_from) / a.own_width) % a.own_world) != a.own_rank) return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t row = r0 + lane;
+  // row multi-index (C order: last dimension fastest) as offsets into the 1-D matrices
+  int roff[D];
+  {
+    unsigned rem = (unsigned)(row < a.n0 ? row : a.n0 - 1);
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      const unsigned q = rem / (unsigned)a.n0d[d];
+      roff[d] = (int)(rem - q * (unsigned)a.n0d[d]);
+      rem = q;
+    }
+  }
+  // column multi-index of the first column of this wave's 16-column slab; advanced incrementally
+  // (a division per entry would cost more than the entry)
+  const int64_t cfirst = c0 + w * 16;
+  int j[D];
+  {
+    unsigned rem = (unsigned)(cfirst < a.n1 ? cfirst : 0);
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      const unsigned q = rem / (unsigned)a.n1d[d];
+      j[d] = (int)(rem - q * (unsigned)a.n1d[d]);
+      rem = q;
+    }
+  }
+  const double* ufast = a.u[D - 1] + roff[D - 1];
+  const int64_t sfast = (int64_t)a.n1d[D - 1] * a.ldu[D - 1];
+  const int nu = a.nuniq[D - 1];
+  double q[KR_MAXU];             // weight of each fast-dimension matrix for the current slow column index
+  bool fresh = true;
+  for (int e = 0; e < 16; ++e) {
+    const int64_t c = cfirst + e;
+    if (c >= a.n1) break;
+    if (fresh) {
+      // q[u] = sum over the terms that use fast matrix u of  coef * prod_{d < D-1} M[i_d, j_d]
+#pragma unroll
+      for (int u = 0; u < KR_MAXU; ++u) q[u] = 0.0;
+      for (int t = 0; t < a.nterms; ++t) {
+        double p = a.coef[t];
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+          p *= a.u[d][(int64_t)a.which[t][d] * a.n1d[d] * a.ldu[d] + (int64_t)j[d] * a.ldu[d] + roff[d]];
+        const int uu = a.which[t][D - 1];
+#pragma unroll
+        for (int u = 0; u < KR_MAXU; ++u) q[u] += (uu == u) ? p : 0.0;
+      }
+      fresh = false;
+    }
+    const double* col = ufast + (int64_t)j[D - 1] * a.ldu[D - 1];
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < KR_MAXU; ++u)
+      if (u < nu) acc = fma(q[u], col[u * sfast], acc);
+    if (row < a.n0) a.out[(a.row_off + row) + (a.col_off + c) * a.ld] = acc;
+    // next column: increment the multi-index; a carry out of the fastest dimension changes q
+    if (++j[D - 1] == a.n1d[D - 1]) {
+      j[D - 1] = 0;
+      fresh = true;
+#pragma unroll
+      for (int d = D - 2; d >= 0; --d) {
+        if (++j[d] < a.n1d[d]) break;
+        j[d] = 0;
+      }
+    }
+  }
+}
+
+// F0[d] / F1[d]: device coordinate arrays of the grid factors (n0d[d] / n1d[d] points); work:
+// device scratch of at least kron_work_doubles(...) doubles.
+int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
+                         const double* const* F0, const int64_t* n0d, const double* const* F1, const int64_t* n1d,
+                         double* work, size_t work_doubles, double* out, int64_t ld, int64_t row_off,
+                         int64_t col_off, int lower_only, const OwnFilter& own) {
+  const int D = kd[0].d;
+  KronArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n0 = 1; a.n1 = 1;
+  size_t woff = 0;
+  size_t dim_off[LPGP_MAXD];
+  for (int d = 0; d < D; ++d) {
+    a.n0d[d] = (int32_t)n0d[d];
+    a.n1d[d] = (int32_t)n1d[d];
+    a.ldu[d] = (int32_t)round_up(n0d[d], 2);
+    a.n0 *= n0d[d];
+    a.n1 *= n1d[d];
+    dim_off[d] = woff;
+    woff += (size_t)KR_MAXU * a.ldu[d] * n1d[d];
+  }
+  LPGP_CHECK(woff <= work_doubles, "kron assembly: scratch too small");
+  LPGP_CHECK(a.n0 < (int64_t)1 << 31 && a.n1 < (int64_t)1 << 31, "kron assembly: grid too large");
+  // distinct 1-D matrices: key (group, n0, n1) per dimension
+  struct Key { int g, n0, n1; };
+  std::vector<Key> keys[LPGP_MAXD];
+  for (int g = 0; g < ngroups; ++g) {
+    const lpgp_kdesc& K = kd[g];
+    LPGP_CHECK(K.d == D, "kron assembly: group %d has d=%d != %d", g, K.d, D);
+    for (int t = 0; t < K.nterms; ++t) {
+      LPGP_CHECK(a.nterms < KR_MAXT, "kron assembly: more than %d terms", KR_MAXT);
+      const int ti = a.nterms++;
+      a.coef[ti] = K.scale * K.terms[t].coef;
+      for (int d = 0; d < D; ++d) {
+        const int n0 = K.terms[t].n0[d], n1 = K.terms[t].n1[d];
+        int found = -1;
+        for (size_t q = 0; q < keys[d].size(); ++q)
+          if (keys[d][q].g == g && keys[d][q].n0 == n0 && keys[d][q].n1 == n1) found = (int)q;
+        if (found < 0) {
+          LPGP_CHECK((int)keys[d].size() < KR_MAXU, "kron assembly: more than %d distinct 1-D factors", KR_MAXU);
+          keys[d].push_back({g, n0, n1});
+          found = (int)keys[d].size() - 1;
+        }
+        a.which[ti][d] = (uint8_t)found;
+      }
+    }
+  }
+  // evaluate the 1-D matrices with the ordinary assembly kernel (D = 1, scale 1, one term)
+  OwnFilter none;
+  for (int d = 0; d < D; ++d) {
+    a.nuniq[d] = (int32_t)keys[d].size();
+    a.u[d] = work + dim_off[d];
+    for (size_t q = 0; q < keys[d].size(); ++q) {
+      const lpgp_kdesc& K = kd[keys[d][q].g];
+      lpgp_kdesc k1;
+      std::memset(&k1, 0, sizeof(k1));
+      k1.d = 1;
+      k1.family[0] = K.family[d];
+      k1.p[0] = K.p[d];
+      k1.lengthscale[0] = K.lengthscale[d];
+      k1.scale = 1.0;
+      k1.nterms = 1;
+      k1.terms[0].coef = 1.0;
+      k1.terms[0].n0[0] = keys[d][q].n0;
+      k1.terms[0].n1[0] = keys[d][q].n1;
+      DevDesc dd;
+      int rc = lower_kdesc(&k1, 1, &dd);
+      if (rc != 0) return rc;
+      double* dst = work + dim_off[d] + q * (size_t)a.ldu[d] * n1d[d];
+      rc = launch_assemble(ctx, stream, dd, F0[d], n0d[d], n0d[d], F1[d], n1d[d], n1d[d], dst, a.ldu[d], 0, 0, 0, none);
+      if (rc != 0) return rc;
+    }
+  }
+  a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
+  a.own_world = own.world; a.own_rank = own.rank; a.own_from = own.from; a.own_width = own.width;
+  a.tiles_r = (int)((a.n0 + AT - 1) / AT);
+  a.tiles_c = (int)((a.n1 + AT - 1) / AT);
+  if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
+  dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
+  const double entries = lower_only ? 0.5 * (double)a.n0 * ((double)a.n0 + 1.0) : (double)a.n0 * (double)a.n1;
+  prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+  switch (D) {
+    case 1: hipLaunchKernelGGL(kron_expand_kernel<1>, grid, dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(kron_expand_kernel<2>, grid, dim3(256), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(kron_expand_kernel<3>, grid, dim3(256), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(kron_expand_kernel<4>, grid, dim3(256), 0, stream, a); break;
+    default: LPGP_CHECK(false, "kron assembly: d=%d", D);
+  }
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d) {
+  size_t w = 0;
+  for (int d = 0; d < D; ++d) w += (size_t)KR_MAXU * (size_t)round_up(n0d[d], 2) * (size_t)n1d[d];
+  return w;
+}
+
 int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ld, off, n, v, scalar);

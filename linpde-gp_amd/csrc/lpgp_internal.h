@@ -216,6 +216,11 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
                     const OwnFilter& own = OwnFilter());
+int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
+                         const double* const* F0, const int64_t* n0d, const double* const* F1, const int64_t* n1d,
+                         double* work, size_t work_doubles, double* out, int64_t ld, int64_t row_off,
+                         int64_t col_off, int lower_only, const OwnFilter& own);
+size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d);
 constexpr int MV_RHS = 4;         // right-hand sides per pass of the matrix-free product (== MV_R in assemble.hip)
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,

@@ -10,7 +10,7 @@ import threading
 
 import numpy as np
 
-from . import _lib
+from . import _lib, config
 from ._lib import check, as_pd, lib
 
 
@@ -130,11 +130,29 @@ class Points:
         h = C.c_void_p()
         check(lib.lpgp_pts_create(ctx._h, as_pd(X), self.n, self.d, C.byref(h)), "lpgp_pts_create")
         self._h = h
+        # 1-D factor point sets if the points are a tensor grid (C order): enables the Kronecker
+        # assembly `lpgp_gram_assemble_grid`
+        self.grid_factors: "tuple[Points, ...] | None" = None
 
     def __del__(self):  # pragma: no cover
         if getattr(self, "_h", None) and self.ctx._h:
             lib.lpgp_pts_destroy(self._h)
             self._h = None
+
+
+def _grid_factor_points(ctx: "Context", X_original, X_flat: np.ndarray):
+    """Factor point sets of `X_original` if it is a `TensorProductGrid` (carries `.factors`) whose
+    points, flattened in C order, are exactly `X_flat` (a sliced or reordered view is not)."""
+    factors = getattr(X_original, "factors", None)
+    if not config.use_grid_assembly or factors is None or len(factors) != X_flat.shape[1] or len(factors) < 2:
+        return None
+    factors = [np.ascontiguousarray(f, dtype=np.double).reshape(-1) for f in factors]
+    if int(np.prod([f.size for f in factors])) != X_flat.shape[0]:
+        return None
+    mesh = np.stack(np.meshgrid(*factors, indexing="ij"), axis=-1).reshape(-1, len(factors))
+    if not np.array_equal(mesh, X_flat):
+        return None
+    return tuple(Points(ctx, f[:, None]) for f in factors)
 
 
 class DeviceArray(np.ndarray):
@@ -150,7 +168,8 @@ class DeviceArray(np.ndarray):
 
 def to_device(X, input_shape=None, ctx: Context | None = None) -> DeviceArray:
     """Upload a point array of shape batch + input_shape once; returns an ndarray subclass
-    that carries the device handle."""
+    that carries the device handle (and, for a `TensorProductGrid`, its factor point sets)."""
+    X_in = X
     X = np.ascontiguousarray(np.asarray(X, dtype=np.double))
     if input_shape is None:
         d = X.shape[-1] if X.ndim >= 2 else 1
@@ -159,6 +178,7 @@ def to_device(X, input_shape=None, ctx: Context | None = None) -> DeviceArray:
     ctx = ctx or default_context()
     out = X.view(DeviceArray)
     out._lpgp_points = Points(ctx, X.reshape(-1, d))
+    out._lpgp_points.grid_factors = _grid_factor_points(ctx, X_in, X.reshape(-1, d))
     return out
 
 
@@ -166,7 +186,9 @@ def as_points(ctx: Context, X_original, X_flat: np.ndarray) -> Points:
     h = getattr(X_original, "_lpgp_points", None)
     if h is not None and h.ctx is ctx and h.n == X_flat.shape[0] and h.d == X_flat.shape[1]:
         return h
-    return Points(ctx, X_flat)
+    pts = Points(ctx, X_flat)
+    pts.grid_factors = _grid_factor_points(ctx, X_original, X_flat)
+    return pts
 
 
 class GramMatrix:
@@ -201,6 +223,13 @@ class GramMatrix:
 
     def assemble(self, kdesc, X0: Points, X1: Points | None, bi: int, bj: int):
         arr = _lib.make_kdesc_array(kdesc)
+        if X0.grid_factors is not None and (X1 is None or X1.grid_factors is not None):
+            # both point sets are tensor grids: sum of Kronecker products of 1-D kernel matrices
+            F0 = (C.c_void_p * len(X0.grid_factors))(*[f._h for f in X0.grid_factors])
+            F1 = None if X1 is None else (C.c_void_p * len(X1.grid_factors))(*[f._h for f in X1.grid_factors])
+            check(lib.lpgp_gram_assemble_grid(self.ctx._h, arr, len(arr), F0, F1, self._h, bi, bj),
+                  "lpgp_gram_assemble_grid")
+            return
         check(lib.lpgp_gram_assemble(self.ctx._h, arr, len(arr), X0._h, X1._h if X1 is not None else None,
                                      self._h, bi, bj), "lpgp_gram_assemble")
 

@@ -90,6 +90,7 @@ def _load() -> C.CDLL:
     sig("lpgp_rhs_to_host", C.c_int, vp, vp, vp, pd)
     sig("lpgp_kernel_diag", C.c_int, vp, pk, i32, pd)
     sig("lpgp_kernel_matrix", C.c_int, vp, pk, i32, vp, vp, pd)
+    sig("lpgp_gram_assemble_grid", C.c_int, vp, pk, i32, C.POINTER(vp), C.POINTER(vp), vp, i32, i32)
     sig("lpgp_kernel_matvec", C.c_int, vp, pk, i32, vp, vp, pd, i64, pd)
     sig("lpgp_profile_enable", C.c_int, vp, i32)
     sig("lpgp_profile_reset", C.c_int, vp)
@@ -110,7 +111,7 @@ EXPORTED = [
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
-    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_profile_enable", "lpgp_profile_reset",
+    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_probe_mfma_f64",
     "lpgp_probe_hbm_write",
 ]

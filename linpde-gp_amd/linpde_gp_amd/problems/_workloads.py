@@ -20,6 +20,17 @@ class Observation:
     Y: np.ndarray                 # (n,)
     op: dict                      # {multi_index: coeff} of the differential operator (identity = values)
     noise_var: float | None = None
+    grid: tuple | None = None     # factors if X is their tensor grid (`Box.uniform_grid`, `domains/_box.py:81-114`)
+
+    def X_as_given(self):
+        """X the way the reference's builders hand it over: a `TensorProductGrid` (shape
+        factors + (d,)) for grid observations, else the flat (n, d) array; Y shaped alike."""
+        if self.grid is None:
+            return self.X, self.Y
+        from ..domains import TensorProductGrid
+
+        Xg = TensorProductGrid(*self.grid)
+        return Xg, self.Y.reshape(Xg.shape[:-1])
 
 
 @dataclass
@@ -64,7 +75,7 @@ def poisson_2d(n_side: int = 128, n_bdry: int | None = None, m_side: int = 64,
     ident = {(0, 0): 1.0}
     lap = {(2, 0): -1.0, (0, 2): -1.0}                       # L = -Laplacian
     obs = [Observation(X, np.zeros(n_bdry), ident, noise_var) for X in edges]
-    obs.append(Observation(Xp, np.full(Xp.shape[0], 2.0), lap, None))
+    obs.append(Observation(Xp, np.full(Xp.shape[0], 2.0), lap, None, grid=(g, g)))
     t = np.linspace(-1.0 + 1.0 / m_side, 1.0 - 1.0 / m_side, m_side)
     Xt = np.stack(np.meshgrid(t, t, indexing="ij"), axis=-1).reshape(-1, 2)
     kernel = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
@@ -94,12 +105,12 @@ def heat_1d(nt: int = 512, nx: int = 64, alpha: float = 0.1, m_side: int = 64) -
     tg = np.linspace(0.0, 5.0, nt)
     xg = np.linspace(-1.0, 1.0, nx)
     Xp = np.stack(np.meshgrid(tg, xg, indexing="ij"), axis=-1).reshape(-1, 2)
-    pde = Observation(Xp, np.zeros(Xp.shape[0]), heat, None)
+    pde = Observation(Xp, np.zeros(Xp.shape[0]), heat, None, grid=(tg, xg))
     ti = np.linspace(0.2, 4.8, 16)
     xi = np.linspace(-0.9, 0.9, 16)
     Xi = np.stack(np.meshgrid(ti, xi, indexing="ij"), axis=-1).reshape(-1, 2)
     sol = np.exp(-alpha * (np.pi / 2.0) ** 2 * Xi[:, 0]) * np.sin(np.pi * (Xi[:, 1] + 1.0) / 2.0)
-    interior = Observation(Xi, sol, ident, 1e-4)
+    interior = Observation(Xi, sol, ident, 1e-4, grid=(ti, xi))
     tt = np.linspace(0.05, 4.95, m_side)
     xt = np.linspace(-0.95, 0.95, m_side)
     Xt = np.stack(np.meshgrid(tt, xt, indexing="ij"), axis=-1).reshape(-1, 2)
@@ -153,10 +164,12 @@ def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var
     prior = build_prior(wl) if prior is None else prior
     u = prior
     for i, o in enumerate(wl.observations):
-        X = o.X if device_arrays is None else device_arrays["obs"][i]
+        X, Y = o.X_as_given()
+        if device_arrays is not None:
+            X = device_arrays["obs"][i]
         n = o.X.shape[0]
-        b = None if o.noise_var is None else randvars.Normal(np.zeros(n), np.full(n, o.noise_var))
-        u = u.condition_on_observations(o.Y, X=X, L=operator_of(o.op, wl.d), b=b)
+        b = None if o.noise_var is None else randvars.Normal(np.zeros(Y.shape), np.full(n, o.noise_var))
+        u = u.condition_on_observations(Y, X=X, L=operator_of(o.op, wl.d), b=b)
     Xt = wl.Xtest if device_arrays is None else device_arrays["test"]
     if want_var:
         mean, var = u.predict(Xt)
@@ -169,4 +182,4 @@ def upload(wl: Workload):
     """Make every point set of the workload resident in HBM (outside any timed region)."""
     from .._engine import to_device
 
-    return {"obs": [to_device(o.X) for o in wl.observations], "test": to_device(wl.Xtest)}
+    return {"obs": [to_device(o.X_as_given()[0]) for o in wl.observations], "test": to_device(wl.Xtest)}

@@ -16,8 +16,8 @@ for nb in (512, 256, 1024):
     t0 = time.perf_counter()
     for i, o in enumerate(wl.observations):
         n = o.X.shape[0]
-        b = None if o.noise_var is None else randvars.Normal(np.zeros(n), np.full(n, o.noise_var))
-        u = u.condition_on_observations(o.Y, X=dev["obs"][i], L=problems.operator_of(o.op, 2), b=b)
+        b = None if o.noise_var is None else randvars.Normal(np.zeros(o.X_as_given()[1].shape), np.full(n, o.noise_var))
+        u = u.condition_on_observations(o.X_as_given()[1], X=dev["obs"][i], L=problems.operator_of(o.op, 2), b=b)
         ctx.sync(); ts.append(time.perf_counter() - t0); t0 = time.perf_counter()
     m = u.predict(dev["test"], return_var=False); ctx.sync(); tm = time.perf_counter() - t0; t0 = time.perf_counter()
     m, v = u.predict(dev["test"]); ctx.sync(); tv = time.perf_counter() - t0

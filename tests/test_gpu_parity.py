@@ -262,6 +262,47 @@ def test_iterative_equals_oneshot_and_linop_readout(lp):
     np.testing.assert_allclose(rvL.cov, post.cov(Xt, Ltest=lap), rtol=1e-7, atol=1e-6)
 
 
+def test_tensor_grid_assembly_matches_generic(lp):
+    """Observations on a `TensorProductGrid` are assembled as sums of Kronecker products of 1-D
+    kernel matrices (`lpgp_gram_assemble_grid`; the reference's Kronecker `linop`,
+    covfuncs/_tensor_product.py:64-82, diffops/_tensor_product.py:140-156): same Gram matrix
+    and posterior as the per-entry path, ragged grid (37 x 23), heat operator x value
+    observations on a second grid, sum kernel."""
+    from linpde_gp_amd import config, domains
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    k = (1.5 * cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
+         + 0.3 * cf.TensorProduct(cf.ExpQuad((), lengthscales=1.1), cf.Matern((), nu=3.5, lengthscales=0.9)))
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), k)
+    Xg = domains.TensorProductGrid(np.linspace(0.0, 5.0, 37), np.linspace(-1.0, 1.0, 23))
+    Xv = domains.TensorProductGrid(np.linspace(0.3, 4.7, 9), np.linspace(-0.8, 0.8, 11))
+    rng = np.random.default_rng(3)
+    Yg, Yv = rng.standard_normal(Xg.shape[:-1]), rng.standard_normal(Xv.shape[:-1])
+    Xe = rng.uniform(-1, 1, size=(50, 2)) * np.array([2.5, 1.0]) + np.array([2.5, 0.0])
+    Ye = rng.standard_normal(50)
+    Xt = rng.uniform(0.0, 1.0, size=(40, 2))
+    res = {}
+    for flag in (True, False):
+        config.use_grid_assembly = flag
+        try:
+            u = prior.condition_on_observations(Yv, X=Xv, b=lp.randvars.Normal(np.zeros(Yv.shape), np.full(Yv.size, 1e-4)))
+            u = u.condition_on_observations(Ye, X=Xe, b=lp.randvars.Normal(np.zeros(50), 1e-3))     # not a grid
+            u = u.condition_on_observations(Yg, X=Xg, L=diffops.HeatOperator((2,), alpha=0.1),
+                                            b=lp.randvars.Normal(np.zeros(Yg.shape), np.full(Yg.size, 1e-6)))
+            res[flag] = (u.gram.todense(), *u.predict(Xt))
+        finally:
+            config.use_grid_assembly = True
+    G1, m1, v1 = res[True]
+    G0, m0, v0 = res[False]
+    np.testing.assert_allclose(G1, G0, rtol=0, atol=1e-12 * np.abs(G0).max())
+    assert _rel(m1, m0) < 1e-8 and _rel(v1, v0) < 1e-8
+    # a sliced grid no longer is the grid of its factors: silently takes the generic path
+    Xs = Xg[::2]
+    u = prior.condition_on_observations(Yg[::2], X=Xs, L=diffops.HeatOperator((2,), alpha=0.1),
+                                        b=lp.randvars.Normal(np.zeros(Yg[::2].shape), np.full(Yg[::2].size, 1e-6)))
+    assert np.all(np.isfinite(u.predict(Xt)[0]))
+
+
 def test_condition_normal_on_observations(lp):
     """Finite-dimensional Gaussian conditioning (`randvars/_normal.py:8-71`) vs its dense NumPy form."""
     rng = np.random.default_rng(31)
