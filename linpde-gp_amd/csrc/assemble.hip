@@ -537,7 +537,9 @@ struct KronArgs {
   int64_t own_from, own_width;
 };
 
-template <int D>
+// NU: compile-time bound on the number of distinct fast-dimension matrices (2, 4, 8 or 16), so
+// that their weights q[] live in registers and the 8 x NU loads of a pass are issued together.
+template <int D, int NU>
 __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
   const int tr = blockIdx.x % a.tiles_r, tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
@@ -573,18 +575,23 @@ __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
       rem = q;
     }
   }
-  const double* ufast = a.u[D - 1] + roff[D - 1];
-  const int64_t sfast = (int64_t)a.n1d[D - 1] * a.ldu[D - 1];
+  const int nfast = a.n1d[D - 1], ldf = a.ldu[D - 1];
   const int nu = a.nuniq[D - 1];
-  double q[KR_MAXU];             // weight of each fast-dimension matrix for the current slow column index
+  const int64_t sfast = (int64_t)nfast * ldf;
+  // fast-dimension matrices beyond nu alias the last one and get weight 0
+  const double* ufast[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) ufast[u] = a.u[D - 1] + (int64_t)(u < nu ? u : nu - 1) * sfast + roff[D - 1];
+  double* const outp = a.out + (a.row_off + row) + a.col_off * a.ld;
+  const bool row_ok = row < a.n0;
+  double q[NU];                  // weight of each fast-dimension matrix for the current slow column index
   bool fresh = true;
-  for (int e = 0; e < 16; ++e) {
-    const int64_t c = cfirst + e;
-    if (c >= a.n1) break;
+  int e = 0;
+  while (e < 16 && cfirst + e < a.n1) {
     if (fresh) {
       // q[u] = sum over the terms that use fast matrix u of  coef * prod_{d < D-1} M[i_d, j_d]
 #pragma unroll
-      for (int u = 0; u < KR_MAXU; ++u) q[u] = 0.0;
+      for (int u = 0; u < NU; ++u) q[u] = 0.0;
       for (int t = 0; t < a.nterms; ++t) {
         double p = a.coef[t];
 #pragma unroll
@@ -592,18 +599,41 @@ __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
           p *= a.u[d][(int64_t)a.which[t][d] * a.n1d[d] * a.ldu[d] + (int64_t)j[d] * a.ldu[d] + roff[d]];
         const int uu = a.which[t][D - 1];
 #pragma unroll
-        for (int u = 0; u < KR_MAXU; ++u) q[u] += (uu == u) ? p : 0.0;
+        for (int u = 0; u < NU; ++u) q[u] += (uu == u) ? p : 0.0;
       }
       fresh = false;
     }
-    const double* col = ufast + (int64_t)j[D - 1] * a.ldu[D - 1];
-    double acc = 0.0;
+    // columns until the fastest index wraps (at most 8 per pass)
+    int seg = nfast - j[D - 1];
+    if (seg > 16 - e) seg = 16 - e;
+    if ((int64_t)seg > a.n1 - (cfirst + e)) seg = (int)(a.n1 - (cfirst + e));
+    if (seg >= 8) {
+      seg = 8;
+      double acc[8];
 #pragma unroll
-    for (int u = 0; u < KR_MAXU; ++u)
-      if (u < nu) acc = fma(q[u], col[u * sfast], acc);
-    if (row < a.n0) a.out[(a.row_off + row) + (a.col_off + c) * a.ld] = acc;
-    // next column: increment the multi-index; a carry out of the fastest dimension changes q
-    if (++j[D - 1] == a.n1d[D - 1]) {
+      for (int x = 0; x < 8; ++x) acc[x] = 0.0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const double* col = ufast[u] + (int64_t)j[D - 1] * ldf;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[x] = fma(q[u], col[x * ldf], acc[x]);
+      }
+      if (row_ok) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) outp[(cfirst + e + x) * a.ld] = acc[x];
+      }
+    } else {
+      for (int x = 0; x < seg; ++x) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc = fma(q[u], ufast[u][(int64_t)(j[D - 1] + x) * ldf], acc);
+        if (row_ok) outp[(cfirst + e + x) * a.ld] = acc;
+      }
+    }
+    e += seg;
+    // advance the multi-index; a carry out of the fastest dimension changes q
+    j[D - 1] += seg;
+    if (j[D - 1] == nfast) {
       j[D - 1] = 0;
       fresh = true;
 #pragma unroll
@@ -613,6 +643,90 @@ __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
       }
     }
   }
+}
+
+// Two-dimensional grids, NU <= 8: the roles are turned around.  A workgroup keeps a 64 x 32
+// sub-block of every FAST-dimension matrix in registers (lane = fast row index, wave = 8 fast
+// columns) and walks over KR_PAIRS pairs (i_s, j_s) of SLOW indices; per pair the weights q[u]
+// come from a few wave-uniform loads of the slow-dimension matrices and every output entry costs
+// NU fused multiply-adds and its store -- no vector loads in the loop, so the kernel runs at the
+// rate of the stores (measured with scratch/store_probe.hip: this store pattern alone reaches
+// 5.9 TB/s, the per-entry evaluation 2.9 TB/s).
+constexpr int KR_PAIRS = 16;
+template <int NU>
+__global__ __launch_bounds__(256) void kron2_kernel(KronArgs a, int ftr, int ftc) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int b = blockIdx.x;
+  const int tr = b % ftr; b /= ftr;
+  const int tcf = b % ftc;
+  const int chunk = b / ftc;
+  const int n0s = a.n0d[0], n1s = a.n1d[0], n0f = a.n0d[1], n1f = a.n1d[1];
+  const int ifast = tr * 64 + lane;                    // fast row index of this lane
+  const int jf0 = tcf * 32 + w * 8;                    // first fast column of this wave
+  const int nu = a.nuniq[1];
+  const int64_t sfast = (int64_t)n1f * a.ldu[1];
+  const bool row_ok = ifast < n0f;
+  double vals[NU][8];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int jf = jf0 + x;
+      vals[u][x] = (u < nu && row_ok && jf < n1f) ? a.u[1][(int64_t)u * sfast + (int64_t)jf * a.ldu[1] + ifast] : 0.0;
+    }
+  const int64_t sslow = (int64_t)n1s * a.ldu[0];
+  const int64_t npairs = (int64_t)n0s * n1s;
+  int64_t p = (int64_t)chunk * KR_PAIRS;
+  int is = (int)(p % n0s), js = (int)(p / n0s);
+  for (int it = 0; it < KR_PAIRS && p < npairs; ++it, ++p) {
+    const int64_t rtile = (int64_t)is * n0f + tr * 64;            // first global row / column of the
+    const int64_t ctile = (int64_t)js * n1f + tcf * 32;           // 64 x 32 tile of this pair
+    const bool skip = a.lower_only && ctile > rtile + 63;
+    // distributed factorisation: columns of panels owned by other ranks are not written (a tile of
+    // this kernel is not aligned to the panel width, so the owner is decided per column)
+    unsigned mine = 0xffu;
+    if (!skip && a.own_world > 1) {
+      mine = 0;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int64_t gc = a.col_off + (int64_t)js * n1f + jf0 + x;
+        if (gc < a.own_from || (int)(((gc - a.own_from) / a.own_width) % a.own_world) == a.own_rank) mine |= 1u << x;
+      }
+    }
+    if (!skip && mine != 0) {
+      double q[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) q[u] = 0.0;
+      for (int t = 0; t < a.nterms; ++t) {
+        const double pv = a.coef[t] * a.u[0][(int64_t)a.which[t][0] * sslow + (int64_t)js * a.ldu[0] + is];
+        const int uu = a.which[t][1];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) q[u] += (uu == u) ? pv : 0.0;
+      }
+      double* outp = a.out + (a.row_off + (int64_t)is * n0f + ifast) + (a.col_off + (int64_t)js * n1f + jf0) * a.ld;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc = fma(q[u], vals[u][x], acc);
+        if (row_ok && jf0 + x < n1f && ((mine >> x) & 1u)) outp[(int64_t)x * a.ld] = acc;
+      }
+    }
+    if (++is == n0s) {
+      is = 0;
+      ++js;
+    }
+  }
+}
+
+template <int D>
+static void launch_kron_nu(dim3 grid, hipStream_t stream, const KronArgs& a) {
+  const int nu = a.nuniq[D - 1];
+  if (nu <= 2) hipLaunchKernelGGL((kron_expand_kernel<D, 2>), grid, dim3(256), 0, stream, a);
+  else if (nu <= 4) hipLaunchKernelGGL((kron_expand_kernel<D, 4>), grid, dim3(256), 0, stream, a);
+  else if (nu <= 8) hipLaunchKernelGGL((kron_expand_kernel<D, 8>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((kron_expand_kernel<D, KR_MAXU>), grid, dim3(256), 0, stream, a);
 }
 
 // F0[d] / F1[d]: device coordinate arrays of the grid factors (n0d[d] / n1d[d] points); work:
@@ -696,11 +810,18 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
   dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
   const double entries = lower_only ? 0.5 * (double)a.n0 * ((double)a.n0 + 1.0) : (double)a.n0 * (double)a.n1;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+  if (D == 2 && a.nuniq[1] <= 8 && a.n0d[1] >= 32 && a.n1d[1] >= 16) {
+    const int ftr = (a.n0d[1] + 63) / 64, ftc = (a.n1d[1] + 31) / 32;
+    const int64_t chunks = ((int64_t)a.n0d[0] * a.n1d[0] + KR_PAIRS - 1) / KR_PAIRS;
+    dim3 g2((unsigned)((int64_t)ftr * ftc * chunks));
+    if (a.nuniq[1] <= 4) hipLaunchKernelGGL(kron2_kernel<4>, g2, dim3(256), 0, stream, a, ftr, ftc);
+    else hipLaunchKernelGGL(kron2_kernel<8>, g2, dim3(256), 0, stream, a, ftr, ftc);
+  } else
   switch (D) {
-    case 1: hipLaunchKernelGGL(kron_expand_kernel<1>, grid, dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(kron_expand_kernel<2>, grid, dim3(256), 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(kron_expand_kernel<3>, grid, dim3(256), 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(kron_expand_kernel<4>, grid, dim3(256), 0, stream, a); break;
+    case 1: launch_kron_nu<1>(grid, stream, a); break;
+    case 2: launch_kron_nu<2>(grid, stream, a); break;
+    case 3: launch_kron_nu<3>(grid, stream, a); break;
+    case 4: launch_kron_nu<4>(grid, stream, a); break;
     default: LPGP_CHECK(false, "kron assembly: d=%d", D);
   }
   prof_end(ctx, stream);

@@ -53,7 +53,17 @@ def test_assembly_ownership_filter():
     rng = np.random.default_rng(5)
     n = 1700                                            # 4 panels of 512 columns, ragged
     X = rng.uniform(-1, 1, size=(n, 2))
-    pts = _engine.Points(ctx, X)
+    _check_ownership(lp, _engine, ctx, X, _engine.Points(ctx, X))
+    # the same through the tensor-grid (Kronecker) assembly: 34 x 50 grid
+    from linpde_gp_amd import domains
+    Xg = _engine.to_device(domains.TensorProductGrid(np.linspace(-1, 1, 34), np.linspace(-1, 1, 50)))
+    assert Xg._lpgp_points.grid_factors is not None
+    _check_ownership(lp, _engine, ctx, np.asarray(Xg).reshape(-1, 2), Xg._lpgp_points)
+
+
+def _check_ownership(lp, _engine, ctx, X, pts):
+    cf = lp.randprocs.covfuncs
+    n = X.shape[0]
     k_a = cf.TensorProduct(cf.Matern((), nu=2.5), cf.Matern((), nu=2.5))
     k_b = 3.0 * cf.TensorProduct(cf.Matern((), nu=1.5), cf.Matern((), nu=1.5))
     Ga, Gb = k_a.matrix(X), k_b.matrix(X)

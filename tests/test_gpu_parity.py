@@ -266,17 +266,25 @@ def test_tensor_grid_assembly_matches_generic(lp):
     """Observations on a `TensorProductGrid` are assembled as sums of Kronecker products of 1-D
     kernel matrices (`lpgp_gram_assemble_grid`; the reference's Kronecker `linop`,
     covfuncs/_tensor_product.py:64-82, diffops/_tensor_product.py:140-156): same Gram matrix
-    and posterior as the per-entry path, ragged grid (37 x 23), heat operator x value
-    observations on a second grid, sum kernel."""
+    and posterior as the per-entry path; ragged grids, heat operator x value observations on a
+    second grid, sum kernel.  Sizes (37 x 70, 9 x 40) take the register-resident 2-D kernel with
+    partial tiles, (21 x 23, 5 x 11) the general expansion kernel."""
     from linpde_gp_amd import config, domains
     from linpde_gp_amd.linfuncops import diffops
     cf = lp.randprocs.covfuncs
     k = (1.5 * cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
          + 0.3 * cf.TensorProduct(cf.ExpQuad((), lengthscales=1.1), cf.Matern((), nu=3.5, lengthscales=0.9)))
     prior = lp.GaussianProcess(lp.functions.Zero((2,)), k)
-    Xg = domains.TensorProductGrid(np.linspace(0.0, 5.0, 37), np.linspace(-1.0, 1.0, 23))
-    Xv = domains.TensorProductGrid(np.linspace(0.3, 4.7, 9), np.linspace(-0.8, 0.8, 11))
     rng = np.random.default_rng(3)
+    for (ng, nv) in (((37, 70), (9, 40)), ((21, 23), (5, 11))):
+        _grid_case(lp, prior, rng, ng, nv)
+
+
+def _grid_case(lp, prior, rng, ng, nv):
+    from linpde_gp_amd import config, domains
+    from linpde_gp_amd.linfuncops import diffops
+    Xg = domains.TensorProductGrid(np.linspace(0.0, 5.0, ng[0]), np.linspace(-1.0, 1.0, ng[1]))
+    Xv = domains.TensorProductGrid(np.linspace(0.3, 4.7, nv[0]), np.linspace(-0.8, 0.8, nv[1]))
     Yg, Yv = rng.standard_normal(Xg.shape[:-1]), rng.standard_normal(Xv.shape[:-1])
     Xe = rng.uniform(-1, 1, size=(50, 2)) * np.array([2.5, 1.0]) + np.array([2.5, 0.0])
     Ye = rng.standard_normal(50)
@@ -295,7 +303,8 @@ def test_tensor_grid_assembly_matches_generic(lp):
     G1, m1, v1 = res[True]
     G0, m0, v0 = res[False]
     np.testing.assert_allclose(G1, G0, rtol=0, atol=1e-12 * np.abs(G0).max())
-    assert _rel(m1, m0) < 1e-8 and _rel(v1, v0) < 1e-8
+    # (the two Gram matrices differ by rounding, ~1e-13; the posterior amplifies that by cond(G))
+    assert _rel(m1, m0) < 1e-6 and _rel(v1, v0) < 1e-6
     # a sliced grid no longer is the grid of its factors: silently takes the generic path
     Xs = Xg[::2]
     u = prior.condition_on_observations(Yg[::2], X=Xs, L=diffops.HeatOperator((2,), alpha=0.1),
