@@ -226,7 +226,8 @@ def main():
     }
     if asm["ms"] > 0:
         out["roofline_assembly"] = {
-            "kernel": "assemble_kernel<2>", "bound": "hbm",
+            "kernel": "kron2_kernel<4> (tensor-grid PDE block) + assemble_kernel<2> (boundary and cross blocks, cross-covariance)",
+            "bound": "hbm",
             "achieved": asm["bytes"] / (asm["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": asm["bytes"] / (asm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "note": "lower triangle only for diagonal blocks: 4 N(N+1) bytes",
