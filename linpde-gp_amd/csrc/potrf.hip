@@ -73,9 +73,62 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   __syncthreads();
   TSTAMP(0);
 
+  // ---- block products, shared by the phases below -------------------------------------------
+  // trailing update of step jb:  A_ib,kb -= X_ib X_kb^T   (X = column block jb below the diagonal)
+  auto update_pair = [&](int jb, int ib, int kb) {
+    const int j0 = jb * 16;
+    double acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];          //  X_ib[r=r16][k]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)                                             // -X_kb[c=4q+l3][k]
+        acc[q] = MFMA4(-s[(j0 + 4 * ks + g) * TL + kb * 16 + 4 * q + l3], bop, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
+  };
+  // block (i, j), i > j, of the inverse:  X_ij = -Linv_i (L_ij Linv_j + sum_{j<k<i} L_ik X_kj);
+  // X_ij is kept transposed in the strict upper triangle: X_ij[r][c] at s[(i16+r)*TL + j16+c]
+  auto inverse_block = [&](int i, int j) {
+    double S[4] = {0.0, 0.0, 0.0, 0.0};                  // S[q]: (m = 4q + g, c = r16)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double bop = sD[j * 256 + r16 * 16 + 4 * ks + g];                 // Linv_j[t][c=r16]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)                                             // L_ij[m=4q+l3][t]
+        S[q] = MFMA4(s[(j * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
+    }
+    for (int k = j + 1; k < i; ++k) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double bop = s[(k * 16 + 4 * ks + g) * TL + j * 16 + r16];      // X_kj[t][c=r16]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                           // L_ik[m=4q+l3][t]
+          S[q] = MFMA4(s[(k * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
+      }
+    }
+    double X[4] = {0.0, 0.0, 0.0, 0.0};                  // X[u]: (r = 4u + g, c = r16)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                         // contraction index m = 4q + g: S[q] is the m-side operand
+#pragma unroll
+      for (int u = 0; u < 4; ++u)                         // -Linv_i[r=4u+l3][m=4q+g]
+        X[u] = MFMA4(-sD[i * 256 + (4 * q + g) * 16 + 4 * u + l3], S[q], X[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[(i * 16 + 4 * u + g) * TL + j * 16 + r16] = X[u];
+  };
+
+  // Pipeline over the eight 16-wide block columns.  The diagonal block (factor + inverse, a serial
+  // pivot chain on ONE wave, ~60 % of the kernel when everything waits for it) overlaps with the
+  // work that is not on the critical path: while wave 0 factors diagonal block jb, waves 1-3 finish
+  // the trailing update of step jb-1 (all block columns except jb, which phase C1 did) and row
+  // jb-1 of the tile inverse.
   for (int jb = 0; jb < 8; ++jb) {
     const int j0 = jb * 16;
-    // ---- (a) diagonal 16x16 block: factor + invert, wave 0, one matrix row per lane ----
+    // ---- (D) diagonal 16x16 block: factor + invert, wave 0, one matrix row per lane ----
     if (wid == 0) {
       double row[16];
       const int i = r16;
@@ -122,10 +175,24 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
           sD[jb * 256 + c * 16 + k] = x[k];
         }
       }
+    } else if (jb >= 1) {
+      // ---- background of step jb (waves 1-3) ----
+      const int wi = wid - 1;
+      // rest of the trailing update of step jb-1: block columns kb >= jb+1
+      const int cnt = 7 - jb;
+      const int npairs = cnt * (cnt + 1) / 2;
+      for (int pidx = wi; pidx < npairs; pidx += 3) {
+        int u = 0;
+        while ((u + 1) * (u + 2) / 2 <= pidx) ++u;
+        const int v = pidx - u * (u + 1) / 2;
+        update_pair(jb - 1, jb + 1 + u, jb + 1 + v);
+      }
+      // row jb-1 of the inverse (its diagonal inverse and all rows above it are complete)
+      for (int j = wi; j < jb - 1; j += 3) inverse_block(jb - 1, j);
     }
     __syncthreads();
     TSTAMP(1);
-    // ---- (b) panel below: X_ib = A_ib * Linv^T  (in place) ----
+    // ---- (B) panel below: X_ib = A_ib * Linv^T  (in place) ----
     for (int ib = jb + 1 + wid; ib < 8; ib += 4) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -140,65 +207,16 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     }
     __syncthreads();
     TSTAMP(2);
-    // ---- (c) trailing update inside the tile: A_ib,kb -= X_ib X_kb^T, jb < kb <= ib ----
-    const int cnt = 7 - jb;
-    const int npairs = cnt * (cnt + 1) / 2;
-    for (int pidx = wid; pidx < npairs; pidx += 4) {
-      int u = 0;
-      while ((u + 1) * (u + 2) / 2 <= pidx) ++u;
-      const int v = pidx - u * (u + 1) / 2;
-      const int ib = jb + 1 + u, kb = jb + 1 + v;
-      double acc[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double bop = s[(j0 + 4 * ks + g) * TL + ib * 16 + r16];          //  X_ib[r=r16][k]
-#pragma unroll
-        for (int q = 0; q < 4; ++q)                                             // -X_kb[c=4q+l3][k]
-          acc[q] = MFMA4(-s[(j0 + 4 * ks + g) * TL + kb * 16 + 4 * q + l3], bop, acc[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[(kb * 16 + 4 * q + g) * TL + ib * 16 + r16] = acc[q];
-    }
+    // ---- (C1) the part of the trailing update the next diagonal block and panel wait for:
+    //      block column jb+1 ----
+    if (jb + 1 < 8)
+      for (int ib = jb + 1 + wid; ib < 8; ib += 4) update_pair(jb, ib, jb + 1);
     __syncthreads();
     TSTAMP(3);
   }
-
-  // ---- inverse of the whole tile by block forward substitution; X_ij (i>j) is kept
-  //      transposed in the strict upper triangle: X_ij[r][c] at s[(i16+r)*TL + j16+c] ----
-  for (int dlt = 1; dlt < 8; ++dlt) {
-    for (int j = wid; j + dlt < 8; j += 4) {
-      const int i = j + dlt;
-      double S[4] = {0.0, 0.0, 0.0, 0.0};                  // S[q]: (m = 4q + g, c = r16)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double bop = sD[j * 256 + r16 * 16 + 4 * ks + g];                 // Linv_j[t][c=r16]
-#pragma unroll
-        for (int q = 0; q < 4; ++q)                                             // L_ij[m=4q+l3][t]
-          S[q] = MFMA4(s[(j * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
-      }
-      for (int k = j + 1; k < i; ++k) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double bop = s[(k * 16 + 4 * ks + g) * TL + j * 16 + r16];      // X_kj[t][c=r16]
-#pragma unroll
-          for (int q = 0; q < 4; ++q)                                           // L_ik[m=4q+l3][t]
-            S[q] = MFMA4(s[(k * 16 + 4 * ks + g) * TL + i * 16 + 4 * q + l3], bop, S[q]);
-        }
-      }
-      double X[4] = {0.0, 0.0, 0.0, 0.0};                  // X[u]: (r = 4u + g, c = r16)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {                         // contraction index m = 4q + g: S[q] is the m-side operand
-#pragma unroll
-        for (int u = 0; u < 4; ++u)                         // -Linv_i[r=4u+l3][m=4q+g]
-          X[u] = MFMA4(-sD[i * 256 + (4 * q + g) * 16 + 4 * u + l3], S[q], X[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s[(i * 16 + 4 * u + g) * TL + j * 16 + r16] = X[u];
-    }
-    __syncthreads();
-  }
+  // ---- last row of the inverse (needs the last diagonal inverse) ----
+  for (int j = wid; j < 7; j += 4) inverse_block(7, j);
+  __syncthreads();
 
   TSTAMP(4);
   // ---- write back L (zeros above the diagonal) and Linv ----
