@@ -121,6 +121,33 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     for (int u = 0; u < 4; ++u) s[(i * 16 + 4 * u + g) * TL + j * 16 + r16] = X[u];
   };
 
+  // ---- write-out helpers: a finished part of the result leaves for HBM as soon as it is final,
+  //      from the waves that are not on the critical path ----
+  // block column cb of L (16 columns, zeros above the diagonal); wave slot wi of nw
+  auto store_l_columns = [&](int cb, int wi, int nw) {
+    for (int c = cb * 16 + wi; c < cb * 16 + 16; c += nw) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + 64 * h;
+        a[(int64_t)c * lda + r] = (r >= c) ? s[c * TL + r] : 0.0;
+      }
+    }
+  };
+  // block row i of Linv (16 rows x 128 columns): blocks left of the diagonal from the transposed
+  // copies in the upper triangle (a strided, bank-conflicting LDS read -- harmless off the
+  // critical path), the diagonal block from sD, zeros to the right; 4 columns x 16 rows per store
+  auto store_linv_row = [&](int i, int wi, int nw) {
+    const int rl = lane & 15, cl = lane >> 4;
+    for (int c4 = wi; c4 < 32; c4 += nw) {
+      const int c = c4 * 4 + cl, r = i * 16 + rl;
+      double v;
+      if (c < i * 16) v = s[r * TL + c];
+      else if (c < i * 16 + 16) v = sD[i * 256 + (c & 15) * 16 + rl];
+      else v = 0.0;
+      linv[c * TILE + r] = v;
+    }
+  };
+
   // Pipeline over the eight 16-wide block columns.  The diagonal block (factor + inverse, a serial
   // pivot chain on ONE wave, ~60 % of the kernel when everything waits for it) overlaps with the
   // work that is not on the critical path: while wave 0 factors diagonal block jb, waves 1-3 finish
@@ -189,6 +216,9 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       }
       // row jb-1 of the inverse (its diagonal inverse and all rows above it are complete)
       for (int j = wi; j < jb - 1; j += 3) inverse_block(jb - 1, j);
+      // results that are final: block column jb-1 of L, block row jb-2 of Linv
+      store_l_columns(jb - 1, wi, 3);
+      if (jb >= 2) store_linv_row(jb - 2, wi, 3);
     }
     __syncthreads();
     TSTAMP(1);
@@ -219,19 +249,10 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   __syncthreads();
 
   TSTAMP(4);
-  // ---- write back L (zeros above the diagonal) and Linv ----
-  for (int c = wid; c < TILE; c += 4) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + 64 * h;
-      a[(int64_t)c * lda + r] = (r >= c) ? s[c * TL + r] : 0.0;
-      double xv;
-      if (r < c) xv = 0.0;
-      else if ((r >> 4) == (c >> 4)) xv = sD[(c >> 4) * 256 + (c & 15) * 16 + (r & 15)];
-      else xv = s[r * TL + c];
-      linv[c * TILE + r] = xv;
-    }
-  }
+  // ---- what is left to write: the last block column of L, the last two block rows of Linv ----
+  store_l_columns(7, wid, 4);
+  store_linv_row(6, wid, 4);
+  store_linv_row(7, wid, 4);
 #ifdef LPGP_TILE_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSTAMP(5);
