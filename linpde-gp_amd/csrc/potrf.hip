@@ -156,18 +156,21 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
   for (int jb = 0; jb < 8; ++jb) {
     const int j0 = jb * 16;
     // ---- (D) diagonal 16x16 block: factor + invert, wave 0, one matrix row per lane ----
-    if (wid == 0) {
+    if (wu == 0) {
       double row[16];
       const int i = r16;
 #pragma unroll
       for (int k = 0; k < 16; ++k) row[k] = s[(j0 + k) * TL + j0 + i];
       int bad = 0;
-      // Factorisation and inversion share one pivot loop: column c of X = L^{-1} (lane c) needs
-      // row j of L, which is final right after pivot step j, so the two recurrences are
-      // interleaved and overlap in the instruction stream (the pivot chain
-      // readlane -> rsq -> scale -> readlane is latency bound).
+      // Factorisation and inversion share one pivot loop AND their broadcasts: lane c builds
+      // column c of X = L^{-1} right-looking, x[k] -= L[k][j] x[j] as soon as x[j] is final, with
+      // the very L[k][j] that the rank-1 update of the factor broadcasts at that moment.  (Forming
+      // x[j] from all earlier L[j][k] at step j instead doubles the v_readlane count and keeps
+      // 240 broadcast SGPRs alive: the compiler spilled 254 of them through v_writelane.)
       double x[16];
       const int c = r16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = (j == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double piv = bcast_lane(row[j], j);
@@ -183,15 +186,16 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
         l = fma(0.5 * inv, res, l);
         inv = fma(inv, -0.5 * inv * inv * res, inv);       // keep inv consistent with the refined l
         row[j] = (i == j) ? l : row[j] * inv;
-        // x[j] = (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]   (row j of L is final now)
-        double acc = (j == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < j; ++k) acc = fma(-bcast_lane(row[k], j), x[k], acc);
-        x[j] = (j >= c) ? acc * inv : 0.0;
+        x[j] = (j >= c) ? x[j] * inv : 0.0;                // (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
-          const double lkj = bcast_lane(row[j], k);
+          const double lkj = bcast_lane(row[j], k);        // L[k][j]
           row[k] = fma(-row[j], lkj, row[k]);
+          x[k] = fma(-lkj, x[j], x[k]);
+          // pin the update here: left alone, the compiler sinks all updates of x[k] down to pivot
+          // step k (their first use) and parks the broadcast L[k][j] in VGPR lanes until then
+          // (264 v_writelane / v_readlane spill pairs, twice the instruction count of this loop)
+          asm volatile("" : "+v"(x[k]));
         }
       }
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
@@ -202,28 +206,40 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
           sD[jb * 256 + c * 16 + k] = x[k];
         }
       }
+#ifdef LPGP_TILE_STAMP
+      { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); ts_[6] += tC_ - tA_; }
+#endif
     } else if (jb >= 1) {
       // ---- background of step jb (waves 1-3) ----
-      const int wi = wid - 1;
-      // rest of the trailing update of step jb-1: block columns kb >= jb+1
-      const int cnt = 7 - jb;
-      const int npairs = cnt * (cnt + 1) / 2;
-      for (int pidx = wi; pidx < npairs; pidx += 3) {
-        int u = 0;
-        while ((u + 1) * (u + 2) / 2 <= pidx) ++u;
-        const int v = pidx - u * (u + 1) / 2;
-        update_pair(jb - 1, jb + 1 + u, jb + 1 + v);
+      const int wi = wu - 1;
+#ifdef LPGP_TILE_STAMP
+      unsigned long long tBg_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tBg_) :: "memory");
+#endif
+      // results that are final leave first (block column jb-1 of L, block row jb-2 of Linv): the
+      // barrier at the end of the phase waits for outstanding stores, so they go out before the
+      // arithmetic, not after it
+      store_l_columns(jb - 1, wi, 3);
+      if (jb >= 2) store_linv_row(jb - 2, wi, 3);
+      // rest of the trailing update of step jb-1: block columns kb >= jb+1, dealt round-robin
+      // (wave-uniform loop control: wi comes from the scalar wave index)
+      {
+        int turn = 0;
+        for (int kb = jb + 1; kb < 8; ++kb)
+          for (int ib = kb; ib < 8; ++ib) {
+            if (turn == wi) update_pair(jb - 1, ib, kb);
+            turn = (turn == 2) ? 0 : turn + 1;
+          }
       }
       // row jb-1 of the inverse (its diagonal inverse and all rows above it are complete)
       for (int j = wi; j < jb - 1; j += 3) inverse_block(jb - 1, j);
-      // results that are final: block column jb-1 of L, block row jb-2 of Linv
-      store_l_columns(jb - 1, wi, 3);
-      if (jb >= 2) store_linv_row(jb - 2, wi, 3);
+#ifdef LPGP_TILE_STAMP
+      if (tid == 64) { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); g_stamps[8 + jb] = tC_ - tBg_; }
+#endif
     }
     __syncthreads();
     TSTAMP(1);
     // ---- (B) panel below: X_ib = A_ib * Linv^T  (in place) ----
-    for (int ib = jb + 1 + wid; ib < 8; ib += 4) {
+    for (int ib = jb + 1 + wu; ib < 8; ib += 4) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -240,23 +256,23 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     // ---- (C1) the part of the trailing update the next diagonal block and panel wait for:
     //      block column jb+1 ----
     if (jb + 1 < 8)
-      for (int ib = jb + 1 + wid; ib < 8; ib += 4) update_pair(jb, ib, jb + 1);
+      for (int ib = jb + 1 + wu; ib < 8; ib += 4) update_pair(jb, ib, jb + 1);
     __syncthreads();
     TSTAMP(3);
   }
   // ---- last row of the inverse (needs the last diagonal inverse) ----
-  for (int j = wid; j < 7; j += 4) inverse_block(7, j);
+  for (int j = wu; j < 7; j += 4) inverse_block(7, j);
   __syncthreads();
 
   TSTAMP(4);
   // ---- what is left to write: the last block column of L, the last two block rows of Linv ----
-  store_l_columns(7, wid, 4);
-  store_linv_row(6, wid, 4);
-  store_linv_row(7, wid, 4);
+  store_l_columns(7, wu, 4);
+  store_linv_row(6, wu, 4);
+  store_linv_row(7, wu, 4);
 #ifdef LPGP_TILE_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSTAMP(5);
-  if (tid == 0) for (int i = 0; i < 6; ++i) g_stamps[i] = ts_[i];
+  if (tid == 0) for (int i = 0; i < 7; ++i) g_stamps[i] = ts_[i];
 #endif
 }
 

@@ -27,8 +27,9 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[16];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
-    printf("tile kernel %.1f us; cycles: load %llu, diag %llu, panel %llu, trailing %llu, inverse %llu, writeback %llu (total %llu)\n",
-           ms * 1e3, h[0], h[1], h[2], h[3], h[4], h[5], h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
+    printf("tile kernel %.1f us; cycles: load %llu, diag %llu, panel %llu, trailing %llu, inverse %llu, writeback %llu (total %llu); wave-0 diagonal work alone %llu\n",
+           ms * 1e3, h[0], h[1], h[2], h[3], h[4], h[5], h[0] + h[1] + h[2] + h[3] + h[4] + h[5], h[6]);
+    printf("  background of wave 1 per step:"); for (int j = 1; j < 8; ++j) printf(" %llu", h[8 + j]); printf("\n");
   }
   return 0;
 }
