@@ -26,6 +26,7 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int TL = 136;                       // LDS leading dimension of the 128x128 tile (col-major)
 constexpr int TILE_LDS_DOUBLES = TILE * TL + 8 * 256;
+constexpr int TILE_WAVES = 8;                 // wave 0: diagonal blocks (the serial chain); the others: everything off it
 
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -49,7 +50,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // n = 4q + (lane>>4)); per 4-deep k-step it takes ONE "m-side" fragment
 // (lane -> M[m = lane&15][k = lane>>4]) and four replicated "n-side" fragments
 // (lane -> N[n = 4q + (lane&3)][k = lane>>4]).
-__global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
+__global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
                                                           double* __restrict__ linv, int* __restrict__ info,
                                                           int info_base) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
 #define TSTAMP(i) do { } while (0)
 #endif
   // ---- load tile: one 1-KiB LDS-DMA piece per column ----
-  for (int c = wu; c < TILE; c += 4)
+  for (int c = wu; c < TILE; c += TILE_WAVES)
     __builtin_amdgcn_global_load_lds((gptr_t)(a + (int64_t)c * lda + 2 * lane), (lptr_t)(s + c * TL), 16, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
 
   // Pipeline over the eight 16-wide block columns.  The diagonal block (factor + inverse, a serial
   // pivot chain on ONE wave, ~60 % of the kernel when everything waits for it) overlaps with the
-  // work that is not on the critical path: while wave 0 factors diagonal block jb, waves 1-3 finish
+  // work that is not on the critical path: while wave 0 factors diagonal block jb, the other waves finish
   // the trailing update of step jb-1 (all block columns except jb, which phase C1 did) and row
   // jb-1 of the tile inverse.
   for (int jb = 0; jb < 8; ++jb) {
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); ts_[6] += tC_ - tA_; }
 #endif
     } else if (jb >= 1) {
-      // ---- background of step jb (waves 1-3) ----
+      // ---- background of step jb (waves 1 .. TILE_WAVES-1) ----
       const int wi = wu - 1;
 #ifdef LPGP_TILE_STAMP
       unsigned long long tBg_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tBg_) :: "memory");
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
       // results that are final leave first (block column jb-1 of L, block row jb-2 of Linv): the
       // barrier at the end of the phase waits for outstanding stores, so they go out before the
       // arithmetic, not after it
-      store_l_columns(jb - 1, wi, 3);
-      if (jb >= 2) store_linv_row(jb - 2, wi, 3);
+      store_l_columns(jb - 1, wi, TILE_WAVES - 1);
+      if (jb >= 2) store_linv_row(jb - 2, wi, TILE_WAVES - 1);
       // rest of the trailing update of step jb-1: block columns kb >= jb+1, dealt round-robin
       // (wave-uniform loop control: wi comes from the scalar wave index)
       {
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
         for (int kb = jb + 1; kb < 8; ++kb)
           for (int ib = kb; ib < 8; ++ib) {
             if (turn == wi) update_pair(jb - 1, ib, kb);
-            turn = (turn == 2) ? 0 : turn + 1;
+            turn = (turn == TILE_WAVES - 2) ? 0 : turn + 1;
           }
       }
       // row jb-1 of the inverse (its diagonal inverse and all rows above it are complete)
-      for (int j = wi; j < jb - 1; j += 3) inverse_block(jb - 1, j);
+      for (int j = wi; j < jb - 1; j += TILE_WAVES - 1) inverse_block(jb - 1, j);
 #ifdef LPGP_TILE_STAMP
       if (tid == 64) { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); g_stamps[8 + jb] = tC_ - tBg_; }
 #endif
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     __syncthreads();
     TSTAMP(1);
     // ---- (B) panel below: X_ib = A_ib * Linv^T  (in place) ----
-    for (int ib = jb + 1 + wu; ib < 8; ib += 4) {
+    for (int ib = jb + 1 + wu; ib < 8; ib += TILE_WAVES) {
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -256,19 +257,19 @@ __global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ a,
     // ---- (C1) the part of the trailing update the next diagonal block and panel wait for:
     //      block column jb+1 ----
     if (jb + 1 < 8)
-      for (int ib = jb + 1 + wu; ib < 8; ib += 4) update_pair(jb, ib, jb + 1);
+      for (int ib = jb + 1 + wu; ib < 8; ib += TILE_WAVES) update_pair(jb, ib, jb + 1);
     __syncthreads();
     TSTAMP(3);
   }
   // ---- last row of the inverse (needs the last diagonal inverse) ----
-  for (int j = wu; j < 7; j += 4) inverse_block(7, j);
+  for (int j = wu; j < 7; j += TILE_WAVES) inverse_block(7, j);
   __syncthreads();
 
   TSTAMP(4);
   // ---- what is left to write: the last block column of L, the last two block rows of Linv ----
-  store_l_columns(7, wu, 4);
-  store_linv_row(6, wu, 4);
-  store_linv_row(7, wu, 4);
+  store_l_columns(7, wu, TILE_WAVES);
+  store_linv_row(6, wu, TILE_WAVES);
+  store_linv_row(7, wu, TILE_WAVES);
 #ifdef LPGP_TILE_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSTAMP(5);
@@ -286,7 +287,7 @@ int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda,
     attr_set = true;
   }
   prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
-  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), shmem, stream, a, lda, linv, d_info, info_base);
+  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;
