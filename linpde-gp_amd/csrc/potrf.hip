@@ -193,10 +193,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           const double lkj = bcast_lane(row[j], k);        // L[k][j]
           row[k] = fma(-row[j], lkj, row[k]);
           x[k] = fma(-lkj, x[j], x[k]);
-          // pin the update here: left alone, the compiler sinks all updates of x[k] down to pivot
-          // step k (their first use) and parks the broadcast L[k][j] in VGPR lanes until then
-          // (264 v_writelane / v_readlane spill pairs, twice the instruction count of this loop)
-          asm volatile("" : "+v"(x[k]));
+          // pin both updates here: left alone, the compiler sinks all updates of x[k] and row[k]
+          // down to pivot step k (their first use) and either parks the broadcast L[k][j] in VGPR
+          // lanes until then (264 v_writelane / v_readlane spill pairs) or broadcasts it twice.
+          // (Tried and measured equal or slower: one instruction stream for both recurrences with
+          // factor rows on lanes 0-15 and inverse columns on lanes 16-31; s_setprio for this wave;
+          // keeping its SIMD free of background waves.  ~450 cycles per pivot step remain.)
+          asm volatile("" : "+v"(x[k]), "+v"(row[k]));
         }
       }
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
