@@ -203,7 +203,7 @@ def main():
             "device": info["name"].strip(),
         },
         "roofline": {
-            "kernel": "gemm_f64_kernel<false,false,1> (SYRK: rank-512 trailing update of the blocked Cholesky, both look-ahead halves)",
+            "kernel": "gemm_f64_kernel<false,false,1> (SYRK: rank-512 trailing update of the blocked Cholesky, remainder half of the look-ahead split, ~90 % of the factorisation flops)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -180,7 +180,8 @@ enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing u
                       LPGP_K_SYRK_PANEL = 5 /* rank-128 triangular update inside a panel */,
                       LPGP_K_GEMM_SMALL = 6 /* any product small enough for the 64x64-tile kernel */,
                       LPGP_K_MATVEC = 7 /* matrix-free kernel product */,
-                      LPGP_K_COUNT = 8 };
+                      LPGP_K_SYRK_AHEAD = 8 /* look-ahead half of the trailing update (next panel's columns) */,
+                      LPGP_K_COUNT = 9 };
 /* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
 int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);

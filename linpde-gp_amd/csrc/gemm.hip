@@ -165,7 +165,9 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 }
 
 // TRI != 0: lower-triangular output (symmetric rank-k update).  TRI = 1 is the rank-nb trailing
-// update of the blocked Cholesky, TRI = 2 the rank-128 update inside a panel: identical code,
+// update of the blocked Cholesky (the remainder half of the look-ahead split: the bulk of the
+// flops), TRI = 3 its look-ahead half (the next panel's columns, on the panel stream, possibly
+// underneath the remainder), TRI = 2 the rank-128 update inside a panel: identical code,
 // distinct instantiations, so that each shows up under its own kernel symbol in
 // rocprofv3 --stats and in its own HIP-event profiling slot.
 //
@@ -550,7 +552,7 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
   if (prof_kernel >= 0) {
     // one profiling slot == one kernel symbol (family)
     if (small) prof_kernel = LPGP_K_GEMM_SMALL;
-    else if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : LPGP_K_SYRK;
+    else if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : (g.tri == 3 ? LPGP_K_SYRK_AHEAD : LPGP_K_SYRK);
     const double m = (double)g.mt * BM, n = (double)g.nt * BN, k = (double)g.k;
     // algorithmic flops: a symmetric update counts the lower trapezoid (m >= n) only
     const double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
@@ -565,6 +567,7 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
     else if (ta && !tb) rc = launch_small<true, false, 0>(ctx, stream, g);
     else rc = launch_small<true, true, 0>(ctx, stream, g);
   } else if (g.tri == 2) rc = launch_impl<false, false, 2>(ctx, stream, g);
+  else if (g.tri == 3) rc = launch_impl<false, false, 3>(ctx, stream, g);
   else if (g.tri) rc = launch_impl<false, false, 1>(ctx, stream, g);
   else if (!ta && !tb) rc = launch_impl<false, false, 0>(ctx, stream, g);
   else if (!ta && tb) rc = launch_impl<false, true, 0>(ctx, stream, g);

@@ -175,9 +175,10 @@ int prof_collect(lpgp_ctx* ctx);
 // C(m x n) = beta*C + alpha*A*B.  All of m, n multiples of TILE, k multiple of 16.
 // ta: A element (i,kk) at A[i + kk*lda] (0) or A[kk + i*lda] (1);
 // tb: B element (kk,j) at B[j + kk*ldb] (0) or B[kk + j*ldb] (1).
-// tri: 0 full; 1 / 2 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
-//      with global row tile < global col tile are skipped (1: rank-nb trailing update,
-//      2: rank-128 update inside a panel -- same code, own kernel symbol and profiling slot).
+// tri: 0 full; 1 / 2 / 3 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
+//      with global row tile < global col tile are skipped (1: rank-nb trailing update, remainder
+//      half; 3: its look-ahead half; 2: rank-128 update inside a panel -- same code, own kernel
+//      symbol and profiling slot each).
 struct GemmArgs {
   const double* A;
   const double* B;

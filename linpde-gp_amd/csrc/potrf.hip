@@ -398,29 +398,34 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     }
     const int w1 = width_at(p1);
     const int p2 = (p1 + w1 < T) ? p1 + w1 : T;
+    // Estimated duration of the remainder update (b) at 50 TFLOP/s against that of the next panel
+    // chain: decides who bounds the pipeline from here on.
+    const double rem = (double)(T - p2);
+    const double t_b_us = 0.5 * rem * (rem + 1.0) * (2.0 * TILE * TILE * (double)K / 50e6);
+    const double t_chain_us = 115.0 * (double)(p2 - p1) + 80.0;
+    const bool chain_bound = t_b_us < t_chain_us;
+    // While the CHAIN bounds it, (b) starts only when (a) is COMPLETE: (a) is on the critical
+    // path (the next panel waits for it), (b) is not, and launched together they share the chip by
+    // workgroup count -- measured at panel 20 of c3: (a) took 229 us next to (b) instead of
+    // ~70 us alone.  While the UPDATE bounds it, (b) is released with the panel and (a) runs
+    // underneath it (alone it would leave part of the chip idle).
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     // (a) next panel's columns on sP; they were last written by the previous remainder update
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
-                         LPGP_K_SYRK));
-    // The remainder update (b) starts only when (a) is COMPLETE: (a) is on the critical path
-    // (the next panel waits for it), (b) is not, and launched together they share the chip by
-    // workgroup count -- measured at panel 20 of c3: (a) took 229 us next to (b) instead of
-    // ~70 us alone.  While the update bounds the pipeline the order costs nothing: the work
-    // of (a) + (b) is the same.
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));
-    // (b) remainder on an update stream.  Once its estimated duration (even on the narrow
-    // stream, which leaves a quarter of the CUs to the panel chain) is below that of the next
-    // panel chain, the chain bounds the pipeline and (b) moves to the narrow stream.
+                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 3),
+                         LPGP_K_SYRK_AHEAD));
+    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    // (b) remainder on an update stream.  Once its estimated duration even on the narrow stream
+    // (which leaves a quarter of the CUs to the panel chain) is below that of the chain, it moves
+    // there.
     if (p2 < T) {
-      const double rem = (double)(T - p2);
-      const double t_b_us = 0.5 * rem * (rem + 1.0) * (2.0 * TILE * TILE * (double)K / 50e6);   // at 50 TFLOP/s
-      const double t_chain_us = 115.0 * (double)(p2 - p1) + 80.0;
       const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
       hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
+      if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
       const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
-      LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));       // (and thereby behind the previous remainder update)
+      LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
       LPGP_TRY(launch_gemm(ctx, sB, 0, 0,
                            mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
@@ -666,13 +671,19 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
       continue;
     }
     const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
+    // (b) is released after (a) only while the panel chain bounds the pipeline (see potrf_blocked);
+    // while the update does, (a) -- here only (p2-p1) x mtl tiles, too few to fill the chip alone
+    // (measured: 62 us at 35 TFLOP/s per panel) -- runs underneath (b)
+    const double t_b_us = (double)(T - p2) * mtl * (2.0 * TILE * TILE * (double)K / 50e6);
+    const bool chain_bound = t_b_us < 115.0 * (double)(p2 - p1) + 80.0;
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                          mk(a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p1 * tb, ldv,
                             p2 - p1, mtl, K, -1.0, 1.0, 0),
                          LPGP_K_GEMM));
-    hipEvent_t evp = ctx->ev_panel[it & 1];        // (b) after (a) is complete, as in potrf_blocked
-    LPGP_HIP(hipEventRecord(evp, sP));
+    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     if (p2 < T) {
       LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
       LPGP_TRY(launch_gemm(ctx, sU, 0, 1,

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "liblpgp.so")
 MAXD, MAXT, MAXG = 4, 64, 4
 MATERN_HALFINT, EXPQUAD = 1, 2
 K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec")
+KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec", "syrk_lookahead")
 
 
 class Term(C.Structure):
