@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--n-side", type=int, default=128, help="collocation grid side (c3: 128)")
     ap.add_argument("--m-side", type=int, default=64, help="prediction grid side (c3: 64)")
     ap.add_argument("--cpu-side", type=int, default=72, help="grid side of the bounded CPU-baseline sample")
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson1d", "heat1d"],
+                    help="poisson2d = c3/c4 (the metric's workload), poisson1d = c2 (N=8192), heat1d = c5 (N=32768 + IC/BC/noisy interior)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare with the CPU oracle at full size")
     args = ap.parse_args()
@@ -121,7 +123,12 @@ def main():
     weak = world > 1 and not replicas and not strong and (n_side, m_side) == (128, 64)
     if weak:
         n_side, m_side = _weak_sides(world)
-    wl = problems.poisson_2d(n_side=n_side, m_side=m_side)
+    if args.workload == "poisson1d":
+        wl = problems.poisson_1d()            # c2
+    elif args.workload == "heat1d":
+        wl = problems.heat_1d()               # c5
+    else:
+        wl = problems.poisson_2d(n_side=n_side, m_side=m_side)
     lp.config.gram_capacity_hint = wl.n_total
     dev = problems.upload(wl)                # point sets resident in HBM before timing
     prior = problems.build_prior(wl)
@@ -189,8 +196,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": wl.name,
-            "n_collocation": n_side**2,
-            "n_boundary": 4 * n_side,
+            "n_collocation": int(wl.observations[-1].X.shape[0]) if args.workload == "poisson1d" else
+                             int(max(o.X.shape[0] for o in wl.observations)),
+            "n_other_observations": int(wl.n_total - max(o.X.shape[0] for o in wl.observations)),
             "n_total": wl.n_total,
             "m_predict": int(wl.Xtest.shape[0]),
             "boundary_noise_var": 1e-8,
@@ -232,7 +240,9 @@ def main():
             "frac": asm["bytes"] / (asm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "note": "lower triangle only for diagonal blocks: 4 N(N+1) bytes",
         }
-    if not args.no_cpu and world == 1:
+    if args.workload != "poisson2d":
+        out["metric"] = f"condition+predict fp64 GFLOP/s (algorithmic), {wl.name}"
+    if not args.no_cpu and world == 1 and args.workload == "poisson2d":
         out["cpu_baseline"] = cpu_baseline(problems, args.cpu_side)
     if args.check:
         from oracle import workloads as owl
@@ -240,6 +250,9 @@ def main():
         out["parity"] = {
             "mean_rel_err": float(np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))),
             "var_rel_err": float(np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))),
+            # var = k(x,x) - ||v||^2 cancels against the prior variance: its rounding floor is eps * k(x,x)
+            "var_abs_err_over_prior_var": float(np.max(np.abs(var - ref["var"])) / sum(sc for sc, _ in wl.kernel)),
+            "var_max": float(np.max(ref["var"])),
             "cpu_seconds_full": ref["seconds"],
         }
     print(json.dumps(out))
