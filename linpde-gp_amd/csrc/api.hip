@@ -400,8 +400,6 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->small_tiles_max = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
-  } else if (std::strcmp(key, "solo_small") == 0) {
-    ctx->solo_small = value != 0;
   } else if (std::strcmp(key, "nb_big") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_big must be a multiple of %d (0 disables)", TILE);
     ctx->nb_big = value;
@@ -839,7 +837,7 @@ int lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host) {
   GemmArgs g;
   g.A = A->v; g.B = B->v; g.C = dc; g.lda = A->ld; g.ldb = B->ld; g.ldc = ma;
   g.mt = (int)(ma / TILE); g.nt = (int)(mb / TILE); g.k = (int)A->ld; g.alpha = 1.0; g.beta = 0.0;
-  g.tri = 0; g.row_tile0 = g.col_tile0 = 0; g.ktrim = 0;
+  g.tri = 0;
   int rc = launch_gemm(ctx, ctx->s_main, 1, 1, g, LPGP_K_GEMM);
   std::vector<double> h((size_t)ma * mb);
   if (rc == 0 && hipMemcpyAsync(h.data(), dc, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) rc = -1;
@@ -987,7 +985,7 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
   GemmArgs g;
   g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.mt = (int)(m / TILE); g.nt = (int)(n / TILE); g.k = (int)k; g.alpha = alpha; g.beta = beta;
-  g.tri = lower_only; g.row_tile0 = g.col_tile0 = 0; g.ktrim = 0;
+  g.tri = lower_only;
   int rc = launch_gemm(ctx, ctx->s_main, ta, tb, g, -1);
   if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
   if (rc == 0) LPGP_HIP(hipMemcpy(C, dC, (size_t)ldc * n * sizeof(double), hipMemcpyDeviceToHost));

@@ -505,20 +505,11 @@ static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
 template <bool TA, bool TB, int TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   static bool attr_set = false;
-  size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
-  // 82 KB: more than half of the 160 KB, so two such workgroups never share a CU, yet one of
-  // them still fits beside a 73.7 KB workgroup of a concurrent large update.
-  const size_t shmem_solo = 82 * 1024;
+  const size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
   if (!attr_set) {
     LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_solo));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set = true;
-  }
-  // Small launches (the latency-bound panel steps): the dispatcher packs two workgroups per CU
-  // and leaves other CUs idle; each workgroup then gets half of the matrix pipe.  Spread them.
-  {
-    const int64_t tiles = TRI ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
-    if (ctx->solo_small && tiles <= ctx->cus) shmem = shmem_solo;
   }
   GemmArgs ga = g;
   int nsuper = 0, SS = 64;

@@ -92,7 +92,6 @@ struct lpgp_ctx {
   int lookahead = 1;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
-  int solo_small = 0;              // small GEMM launches: one workgroup per CU (82 KB LDS request); measured: no gain
   // workspace
   // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,
   // from there (truly asynchronously) into the slot's device copy; the slot is reused only
@@ -175,8 +174,8 @@ int prof_collect(lpgp_ctx* ctx);
 // C(m x n) = beta*C + alpha*A*B.  All of m, n multiples of TILE, k multiple of 16.
 // ta: A element (i,kk) at A[i + kk*lda] (0) or A[kk + i*lda] (1);
 // tb: B element (kk,j) at B[j + kk*ldb] (0) or B[kk + j*ldb] (1).
-// tri: 0 full; 1 / 2 / 3 lower-only with global tile coordinates (row_tile0, col_tile0): tiles
-//      with global row tile < global col tile are skipped (1: rank-nb trailing update, remainder
+// tri: 0 full; 1 / 2 / 3 lower-only (C(0,0) is a diagonal tile): tiles with row tile < column
+//      tile are skipped (1: rank-nb trailing update, remainder
 //      half; 3: its look-ahead half; 2: rank-128 update inside a panel -- same code, own kernel
 //      symbol and profiling slot each).
 struct GemmArgs {
@@ -188,8 +187,6 @@ struct GemmArgs {
   int32_t k;
   double alpha, beta;
   int32_t tri;
-  int32_t row_tile0, col_tile0;    // global tile index of C(0,0) (for tri)
-  int32_t ktrim;                   // 1: B (or A) lower-triangular in (n,k): skip k > n-range (invL products)
   int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm)
   unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
 };

@@ -304,7 +304,7 @@ static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.mt = mt; g.nt = nt; g.k = k; g.alpha = alpha; g.beta = beta;
-  g.tri = tri; g.row_tile0 = 0; g.col_tile0 = 0; g.ktrim = 0;
+  g.tri = tri;
   return g;
 }
 

@@ -22,7 +22,7 @@ int main() {
   for (int rep = 0; rep < 2; ++rep)
   for (Case c : {Case{16, 16, 8192}, Case{32, 32, 4096}, Case{64, 64, 512}, Case{32, 16, 512}}) {
     GemmArgs g; g.A = A; g.B = B; g.C = C; g.lda = m; g.ldb = n; g.ldc = m; g.mt = c.mt; g.nt = c.nt; g.k = c.k;
-    g.alpha = -1; g.beta = 1; g.tri = 0; g.row_tile0 = g.col_tile0 = 0; g.ktrim = 0;
+    g.alpha = -1; g.beta = 1; g.tri = 0;
     int nv = 64 * 64 * 2;
     hipMalloc(&st, (size_t)nv * 64); hipMemset(st, 0, (size_t)nv * 64); g.stamps = st;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
