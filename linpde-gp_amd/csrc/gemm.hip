@@ -177,7 +177,11 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 // one workgroup's prologue with its neighbour's k-loop.  In-kernel stamps (-DLPGP_STAMP,
 // scratch/stamp_test.hip) show the k-loop at 16.1 cycles per MFMA per SIMD, i.e. the matrix pipe
 // is saturated; what is left is the C prologue (~15k of ~280k cycles per tile at k = 512) and
-// the clock: 2.35 GHz on all-zero operands, 1.97-2.07 GHz on random data.)
+// the clock: 2.35 GHz on all-zero operands, 1.97-2.07 GHz on random data.  Folding C into the
+// first nine k-stages instead (accumulators from zero, 8 C values per lane loaded per stage and
+// added one stage later, so that the MFMAs start as soon as the first operand stage lands) was
+// built and measured: no gain either (51 vs 52 TFLOP/s at k = 512) -- the co-resident workgroup
+// does hide the prologue.)
 template <bool TA, bool TB, int TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
