@@ -38,38 +38,69 @@ def _recv(sock):
 
 
 class Comm:
+    NPORTS = 8
+
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29601):
         self.rank, self.world = rank, world
         self._peers = []
         self._sock = None
         if world == 1:
             return
+        # Rendezvous: rank 0 listens on the first free port of [port, port + NPORTS); a client walks
+        # the same list until a connection answers the handshake (so a foreign listener on one of
+        # the ports, or a socket of a previous run still in TIME_WAIT, does not break the job).
+        ports = [port + i for i in range(self.NPORTS)]
+        magic = ("lpgp-comm", world)
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
-            srv.listen(world)
+            srv = None
+            for prt in ports:
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    cand.bind((addr, prt))
+                    cand.listen(world)
+                    srv = cand
+                    break
+                except OSError:
+                    cand.close()
+            if srv is None:
+                raise OSError(f"no free control-plane port in {ports[0]}..{ports[-1]} on {addr}")
+            srv.settimeout(300.0)
             peers = {}
             while len(peers) < world - 1:
                 c, _ = srv.accept()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r = _recv(c)
-                peers[r] = c
+                try:
+                    c.settimeout(10.0)
+                    hello = _recv(c)
+                    if not (isinstance(hello, tuple) and len(hello) == 2 and hello[0] == magic):
+                        raise ConnectionError("not a peer")
+                    _send(c, magic)
+                    c.settimeout(None)
+                    peers[int(hello[1])] = c
+                except (OSError, ConnectionError, pickle.UnpicklingError, EOFError):
+                    c.close()
             self._peers = [peers[r] for r in range(1, world)]
             srv.close()
         else:
-            deadline = time.time() + 120.0
-            while True:
+            deadline = time.time() + 300.0
+            s, i = None, 0
+            while s is None:
+                prt = ports[i % len(ports)]
+                i += 1
                 try:
-                    s = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
+                    cand = socket.create_connection((addr, prt), timeout=5.0)
+                    cand.settimeout(10.0)
+                    _send(cand, (magic, rank))
+                    if _recv(cand) != magic:
+                        raise ConnectionError("not rank 0")
+                    s = cand
+                except (OSError, ConnectionError, pickle.UnpicklingError, EOFError):
                     if time.time() > deadline:
                         raise
-                    time.sleep(0.1)
+                    time.sleep(0.05)
             s.settimeout(None)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(s, rank)
             self._sock = s
 
     @classmethod

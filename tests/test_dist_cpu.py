@@ -55,6 +55,53 @@ def test_comm_world2_matches_gloo():
         assert mx == 11.0 == gl and uid == b"\x01\x02" and ag == [0, 2]
 
 
+def _plain_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd"))
+    from linpde_gp_amd import _dist
+    comm = _dist.Comm(rank, world, "127.0.0.1", port)
+    q.put((rank, comm.allgather(rank + 5)))
+    comm.close()
+
+
+def test_comm_survives_a_foreign_listener_on_its_port():
+    """The control-plane port (MASTER_PORT + 1) may be taken: rank 0 moves to the next free port
+    and the clients find it by handshake."""
+    port = _free_port()
+    squatter = socket.socket()
+    squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(4)                         # accepts connections, never answers the handshake
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_plain_worker, args=(r, 3, port, q)) for r in range(3)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res == [(0, [5, 6, 7]), (1, [5, 6, 7]), (2, [5, 6, 7])]
+    finally:
+        squatter.close()
+
+
+def test_bench_weak_scaling_sizes():
+    """bench.py grows the grid with the number of GPUs so that the algorithmic flops per GPU stay
+    those of c3."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    def flops(n, m):
+        N, M = float(n * n + 4 * n), float(m * m)
+        return N**3 / 3 + 2 * N * N + N * N * M + 4 * N * M
+    assert bench._weak_sides(1) == (128, 64)
+    for w in (2, 4, 8):
+        n, m = bench._weak_sides(w)
+        assert m == n // 2 and abs(flops(n, m) / (w * flops(128, 64)) - 1.0) < 0.06
+
+
 # ---- model of the distributed factorisation (csrc/potrf.hip: potrf_blocked_dist) ------------
 def _model_potrf_dist(A, t_done, T, nbt, tile, rank, world, bcast):
     """NumPy mirror of potrf_blocked_dist, step for step: cyclic panel ownership, owner factors
