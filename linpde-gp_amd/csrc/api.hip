@@ -317,6 +317,10 @@ int lpgp_init(int device, lpgp_ctx** out) {
   // quarter of the chip: with only 8 reserved CUs the chain's TRSM / in-panel update wait for
   // update workgroups to retire (measured at panel 20 of c3: 92 + 154 us instead of 21 + 15).
   masked_stream(ctx->reserve_narrow, &ctx->s_upd_narrow);
+  // (a CU mask costs more than its CUs: a 16384^2 x 512 SYRK runs at 53.5 TFLOP/s unmasked, 49.4
+  //  with 8 CUs removed (tile-count quantisation on 496 instead of 512 slots), 44.3 with 64
+  //  removed; LPGP_TEST_GEMM_STREAM + scratch/gemm_sweep.py.  Only the factorisation needs it.)
+  LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd_all, hipStreamNonBlocking, lo));
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
@@ -368,6 +372,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipStreamDestroy(ctx->s_main);
   (void)hipStreamDestroy(ctx->s_upd);
   if (ctx->s_upd_narrow) (void)hipStreamDestroy(ctx->s_upd_narrow);
+  (void)hipStreamDestroy(ctx->s_upd_all);
   delete ctx;
   return 0;
 }
@@ -972,6 +977,8 @@ int lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* laun
 int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, int64_t m, int64_t n, int64_t k,
                    double alpha, const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
                    double* C, int64_t ldc, int32_t reps, double* ms_per_rep) {
+  hipStream_t ts = ctx->s_main;
+  if (const char* e = std::getenv("LPGP_TEST_GEMM_STREAM")) { const int v = std::atoi(e); ts = v == 1 ? ctx->s_upd : (v == 2 && ctx->s_upd_narrow ? ctx->s_upd_narrow : ctx->s_main); }
   LPGP_CHECK(m % TILE == 0 && n % TILE == 0 && k % 16 == 0, "lpgp_test_gemm: m,n multiples of 128 and k of 16 required");
   const int64_t a_elems = ta ? lda * m : lda * k;
   const int64_t b_elems = tb ? ldb * n : ldb * k;
@@ -986,16 +993,16 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
   g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.mt = (int)(m / TILE); g.nt = (int)(n / TILE); g.k = (int)k; g.alpha = alpha; g.beta = beta;
   g.tri = lower_only;
-  int rc = launch_gemm(ctx, ctx->s_main, ta, tb, g, -1);
-  if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;
+  int rc = launch_gemm(ctx, ts, ta, tb, g, -1);
+  if (rc == 0 && hipStreamSynchronize(ts) != hipSuccess) rc = -1;
   if (rc == 0) LPGP_HIP(hipMemcpy(C, dC, (size_t)ldc * n * sizeof(double), hipMemcpyDeviceToHost));
   if (rc == 0 && reps > 0 && ms_per_rep) {
     hipEvent_t e0, e1;
     LPGP_HIP(hipEventCreate(&e0));
     LPGP_HIP(hipEventCreate(&e1));
-    LPGP_HIP(hipEventRecord(e0, ctx->s_main));
-    for (int r = 0; r < reps && rc == 0; ++r) rc = launch_gemm(ctx, ctx->s_main, ta, tb, g, -1);
-    LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+    LPGP_HIP(hipEventRecord(e0, ts));
+    for (int r = 0; r < reps && rc == 0; ++r) rc = launch_gemm(ctx, ts, ta, tb, g, -1);
+    LPGP_HIP(hipEventRecord(e1, ts));
     LPGP_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));

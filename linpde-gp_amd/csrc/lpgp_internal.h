@@ -83,6 +83,7 @@ struct lpgp_ctx {
   hipStream_t s_main = nullptr;    // panel / critical-path stream (high priority)
   hipStream_t s_upd = nullptr;     // trailing-update stream (all CUs but `reserve`, default 8)
   hipStream_t s_upd_narrow = nullptr;  // same with `reserve_narrow` CUs (default 64) left to the panel chain
+  hipStream_t s_upd_all = nullptr;     // unmasked update stream: the blocked solves have no whole-CU kernel to protect
   int reserve_narrow = 64;
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};

@@ -644,7 +644,7 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   const int nbt = (int)(ctx->nb / TILE);
   const double* a = mat->a;
   const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
-  hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd : ctx->s_main;
+  hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
   bool have_upd_event = false;
   int it = 0;
   for (int p0 = 0; p0 < T; p0 += nbt, ++it) {
