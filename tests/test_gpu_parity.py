@@ -29,6 +29,68 @@ def _sobol_like(rng, n, d, lo=-3.0, hi=3.0):
     return rng.uniform(lo, hi, size=(n, d))
 
 
+# ---- the reference's own tensor-product kernel cases (cases_tensor_product.py:10-186), on its own
+#      inputs: 128 Sobol points in [-3, 3]^2, seed 109134809 + d (test_diffops.py:15-20) ----------
+def _ref_tensor_product_cases():
+    def unit(rng):
+        v = rng.standard_normal(size=(2,))
+        return v / np.sqrt(np.sum(v**2))
+    cases = []
+    rng = np.random.default_rng(390852098); d = unit(rng)
+    cases.append(("ID x DD", 1.5, 1.5, None, ("dd", d)))
+    cases.append(("DD x ID", 1.5, 1.5, ("dd", d), None))
+    rng = np.random.default_rng(390852098); d0 = unit(rng); d1 = unit(rng)
+    cases.append(("DD x DD", 1.5, 1.5, ("dd", d0), ("dd", d1)))
+    rng = np.random.default_rng(67835487); w = 2.0 * rng.standard_normal(size=(2,))
+    cases.append(("ID x WL", 2.5, 2.5, None, ("wl", w)))
+    rng = np.random.default_rng(89012645); w = 2.0 * rng.standard_normal(size=(2,))
+    cases.append(("WL x ID", 2.5, 2.5, ("wl", w), None))
+    rng = np.random.default_rng(89012645); w0 = 2.0 * rng.standard_normal(size=(2,)); w1 = 2.0 * rng.standard_normal(size=(2,))
+    cases.append(("WL x WL", 2.5, 2.5, ("wl", w0), ("wl", w1)))
+    rng = np.random.default_rng(390852098); d = unit(rng); w = 2.0 * rng.standard_normal(size=(2,))
+    cases.append(("DD x WL", 3.5, 3.5, ("dd", d), ("wl", w)))
+    cases.append(("WL x DD", 2.5, 2.5, ("wl", w), ("dd", d)))
+    cases.append(("ID x heat", 1.5, 2.5, None, ("heat", 0.1)))
+    cases.append(("heat x heat", 1.5, 2.5, ("heat", 0.2), ("heat", 0.1)))
+    return cases
+
+
+@pytest.mark.parametrize("name,nu0,nu1,L0,L1", _ref_tensor_product_cases(), ids=lambda v: v if isinstance(v, str) else None)
+def test_reference_tensor_product_cases(lp, name, nu0, nu1, L0, L1):
+    import scipy.stats
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    X = scipy.stats.qmc.scale(scipy.stats.qmc.Sobol(2, seed=109134809 + 2).random_base2(7), -3.0, 3.0)
+
+    def host_op(spec):
+        if spec is None:
+            return None
+        kind, par = spec
+        return {"dd": lambda: diffops.DirectionalDerivative(par), "wl": lambda: diffops.WeightedLaplacian(par),
+                "heat": lambda: diffops.HeatOperator((2,), alpha=par)}[kind]()
+
+    def coeffs(spec):
+        if spec is None:
+            return ocf.identity(2)
+        kind, par = spec
+        if kind == "dd":
+            return {(1, 0): float(par[0]), (0, 1): float(par[1])}
+        if kind == "wl":
+            return {(2, 0): float(par[0]), (0, 2): float(par[1])}
+        return {(1, 0): 1.0, (0, 2): -float(par)}          # d/dt - alpha d^2/dx^2
+
+    k = cf.TensorProduct(cf.Matern((), nu=nu0), cf.Matern((), nu=nu1))
+    kk = k
+    if L1 is not None:
+        kk = host_op(L1)(kk, argnum=1)
+    if L0 is not None:
+        kk = host_op(L0)(kk, argnum=0)
+    got = kk.matrix(X, X)
+    ref = ocf.LkL([(1.0, [("matern", nu0, 1.0), ("matern", nu1, 1.0)])], coeffs(L0), coeffs(L1), X, X)
+    # the reference's own bar is atol 1e-14 + rtol 1e-7 against JAX autodiff (test_diffops.py:42)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+
+
 # ---- (1) kernel blocks -------------------------------------------------------------------
 MATERN_CASES = [(nu, a, b) for nu in (1.5, 2.5, 3.5, 4.5) for a in range(3) for b in range(3)
                 if a + b <= 2 * int(nu - 0.5)]
