@@ -115,8 +115,24 @@ def main():
     ctx = _engine.default_context()          # device = LOCAL_RANK
     replicas = bool(int(os.environ.get("LPGP_BENCH_REPLICAS", "0")))
     strong = bool(int(os.environ.get("LPGP_BENCH_STRONG", "0")))
+    dist_note = None
     if world > 1 and not replicas:
-        ctx.dist_init(comm)                  # RCCL communicator: distributed factorisation of ONE problem
+        # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be
+        # created (on every rank alike), the run degrades to independent replicas and says so.
+        try:
+            ctx.dist_init(comm)
+            ok, err = True, ""
+        except Exception as exc:            # noqa: BLE001 (reported in the JSON line)
+            ok, err = False, f"{type(exc).__name__}: {exc}"
+        oks = comm.allgather((ok, err))
+        if not all(o for o, _ in oks):
+            if any(o for o, _ in oks):
+                raise SystemExit("RCCL communicator creation failed on some ranks only: "
+                                 + "; ".join(e for o, e in oks if not o))
+            replicas = True
+            dist_note = "RCCL communicator creation failed (" + oks[0][1][:200] + "): independent replicas instead"
+            if rank == 0:
+                sys.stderr.write("bench.py: " + dist_note + "\n")
     info = ctx.device_info()
 
     n_side, m_side = args.n_side, args.m_side
@@ -204,7 +220,7 @@ def main():
             "boundary_noise_var": 1e-8,
             "algorithmic_flops_per_step": flops,
             "multi_gpu": ("single GPU" if world == 1 else
-                          "independent replicas (one problem per GPU)" if replicas else
+                          (dist_note or "independent replicas (one problem per GPU)") if replicas else
                           f"one problem, panels of 512 columns owned cyclically by {world} ranks (1x{world} grid), "
                           "RCCL panel broadcast, replicated factor, prediction points sharded"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
