@@ -76,9 +76,10 @@ def _check_ownership(lp, _engine, ctx, X, pts):
             mat.assemble(k_a.lower(), pts, None, 0, 0)             # owned panels: kernel a
             ctx.set_option("test_assemble_as", 0)
             G = mat.todense("gram")
-            owner = (np.arange(n) // 512) % 3
-            for j0 in range(0, n, 512):
-                cols = slice(j0, min(j0 + 512, n))
+            nb = int(os.environ.get("LPGP_NB", "512"))          # panel width of the factorisation
+            owner = (np.arange(n) // nb) % 3
+            for j0 in range(0, n, nb):
+                cols = slice(j0, min(j0 + nb, n))
                 want = Ga if owner[j0] == rank else Gb
                 blk = np.tril(G)[:, cols]
                 np.testing.assert_allclose(blk, np.tril(want)[:, cols], rtol=0, atol=1e-12)
