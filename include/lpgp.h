@@ -22,7 +22,14 @@ extern "C" {
 #define LPGP_MAXT 64     /* terms of the expansion  sum_t c_t prod_d d^{n0} d'^{n1} k_d */
 #define LPGP_MAXG 4      /* summands of a sum kernel                              */
 
-enum lpgp_family { LPGP_MATERN_HALFINT = 1, LPGP_EXPQUAD = 2 };
+/* LPGP_MATERN_ISO: ISOTROPIC half-integer Matern over all d input dimensions,
+ * k(x,x') = kappa_nu(|| sqrt(2 nu) (x - x') / lengthscale ||)  (probnum `Matern` with
+ * input_shape (d,)); every dimension of the descriptor then carries this family and the same p.
+ * It is not a product over dimensions: closed forms exist for at most ONE derivative per
+ * argument (sum of the orders of n0 <= 1, of n1 <= 1), i.e. identity and directional derivatives:
+ * `HalfIntegerMatern_Identity_DirectionalDerivative` (diffops/_matern.py:17-86) and
+ * `HalfIntegerMatern_DirectionalDerivative_DirectionalDerivative` (:138-203).                */
+enum lpgp_family { LPGP_MATERN_HALFINT = 1, LPGP_EXPQUAD = 2, LPGP_MATERN_ISO = 3 };
 
 typedef struct lpgp_ctx lpgp_ctx;   /* one per process / per GPU                          */
 typedef struct lpgp_pts lpgp_pts;   /* device-resident point set (n x d)                  */

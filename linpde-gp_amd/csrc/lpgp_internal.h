@@ -51,6 +51,13 @@ struct DevGroup {
   int32_t ncls;
   int32_t parity[MAXCLS];          // bit d set => factor sign(x_d - x'_d)
   int32_t coef_off[MAXCLS];        // offset into coef[]
+  // isotropic Matern group (LPGP_MATERN_ISO): with u = a .* (x - x'), s = |u|,
+  //   entry = scale * exp(-s) * [ Q0(s) + (w . u) Q1(s) + (u^T B u) Q2(s) ],
+  // Q0, Q1, Q2 of degree deg[0] at coef_off[0..2] (ncls = 3; parity[0] = 0 so that the constant
+  // coefficient of Q0 is the diagonal value, as for the product form)
+  int32_t iso, has_lin, has_quad;
+  double w[LPGP_MAXD];
+  double B[LPGP_MAXD * LPGP_MAXD];
 };
 
 struct DevDesc {

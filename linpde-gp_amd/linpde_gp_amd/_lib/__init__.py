@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblpgp.so")
 
 MAXD, MAXT, MAXG = 4, 64, 4
-MATERN_HALFINT, EXPQUAD = 1, 2
+MATERN_HALFINT, EXPQUAD, MATERN_ISO = 1, 2, 3
 K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec", "syrk_lookahead")
 

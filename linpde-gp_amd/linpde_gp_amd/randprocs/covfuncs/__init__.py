@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..._lib import EXPQUAD, MATERN_HALFINT, MAXD, MAXG, MAXT
+from ..._lib import EXPQUAD, MATERN_HALFINT, MATERN_ISO, MAXD, MAXG, MAXT
 
 
 def _as_shape(shape):
@@ -139,23 +139,33 @@ class CovarianceFunction:
 
 
 class Matern(CovarianceFunction):
-    """Half-integer Matérn, k = kappa_nu(sqrt(2 nu) |x - x'| / lengthscale)."""
+    """Half-integer Matérn, k = kappa_nu(|| sqrt(2 nu) (x - x') / lengthscales ||) (probnum `Matern`).
+
+    input_shape () or (1,): univariate, every differential operator with a closed form
+    (`UnivariateHalfIntegerMatern_*`, `diffops/_matern.py:267-611`).  input_shape (d,), d > 1: the
+    ISOTROPIC kernel (scalar or per-dimension lengthscales); closed forms exist for identity and
+    directional derivatives on either argument (`HalfIntegerMatern_Identity_DirectionalDerivative`,
+    `HalfIntegerMatern_DirectionalDerivative_DirectionalDerivative`, `_matern.py:17-264`), anything
+    of higher order raises NotImplementedError (the reference falls back to JAX autodiff there)."""
 
     def __init__(self, input_shape=(), nu=1.5, lengthscales=1.0):
         super().__init__(input_shape)
-        if self.input_size > 1:
-            raise NotImplementedError(
-                "multivariate isotropic Matérn kernels are not on the MI355X path; use "
-                "`TensorProduct` of univariate factors (as the PDE experiments of the reference do)")
         self._nu = float(nu)
         p = self._nu - 0.5
         if p < 0 or abs(p - round(p)) > 1e-12:
             raise NotImplementedError("only half-integer nu has a closed form (`matern.p is None` otherwise)")
         self._p = int(round(p))
-        ls = np.asarray(lengthscales, dtype=np.double)
-        if ls.size != 1 or not (ls > 0).all():
-            raise ValueError("`lengthscales` must be one positive number")
-        self._lengthscales = float(ls.reshape(()))
+        d = max(self.input_size, 1)
+        if d > MAXD:
+            raise NotImplementedError(f"at most {MAXD} input dimensions are supported")
+        try:
+            ls = np.broadcast_to(np.asarray(lengthscales, dtype=np.double), (d,)).copy()
+        except ValueError:
+            raise ValueError(f"`lengthscales` must be a scalar or have shape ({d},)") from None
+        if not (ls > 0).all():
+            raise ValueError("`lengthscales` must be positive")
+        self._ls = ls
+        self._lengthscales = float(ls[0]) if d == 1 else ls
 
     @property
     def nu(self):
@@ -170,7 +180,9 @@ class Matern(CovarianceFunction):
         return self._lengthscales
 
     def _base_groups(self):
-        return [(1.0, [(MATERN_HALFINT, self._p, self._lengthscales)])]
+        if self.input_size > 1:
+            return [(1.0, [(MATERN_ISO, self._p, float(l)) for l in self._ls])]
+        return [(1.0, [(MATERN_HALFINT, self._p, float(self._ls[0]))])]
 
 
 class ExpQuad(CovarianceFunction):
@@ -406,6 +418,18 @@ def lower_groups(base_groups, L0: dict, L1: dict):
         for c, a, b in term_list:
             if len(a) != d or len(b) != d:
                 raise ValueError("operator and kernel dimensions do not match")
+            if factors[0][0] == MATERN_ISO:
+                p = factors[0][1]
+                if (sum(a) > 1 or sum(b) > 1) and c != 0.0:
+                    raise NotImplementedError(
+                        "the isotropic multivariate Matérn kernel has closed forms for identity and "
+                        "directional derivatives only (no JAX autodiff fallback on the MI355X path); "
+                        "use a `TensorProduct` prior for higher-order operators")
+                if sum(a) + sum(b) > p and c != 0.0:
+                    raise ValueError(
+                        f"a multivariate Matérn-{p}+1/2 kernel does not admit {sum(a) + sum(b)} "
+                        "derivative(s) in closed form (not enough differentiability)")
+                continue
             for j, (fam, p, _) in enumerate(factors):
                 if fam == MATERN_HALFINT and a[j] + b[j] > 2 * p:
                     raise ValueError(

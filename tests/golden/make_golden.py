@@ -13,7 +13,12 @@ by independent high-precision evaluation, not by the oracle under test:
   (analytic solution sin(pi x)), solved in 50-digit mpmath (mpmath.cholesky_solve) from
   the mpmath kernel blocks.
 
-Run:  python tests/golden/make_golden.py      (about a minute)
+* `matern_iso_blocks.npz`: the ISOTROPIC 3-D Matern (nu = 5/2, 7/2; per-dimension lengthscales)
+  with identity / directional derivatives on either argument, again SymPy derivatives of the
+  base kernel in 50-digit mpmath (the reference's cases `cases_matern.py:19-89` with its seeds
+  for the directions).
+
+Run:  python tests/golden/make_golden.py      (about a minute; `... iso` writes the last file only)
 """
 import os
 import sys
@@ -74,11 +79,48 @@ def block(factors, scale, L0, L1, X0, X1):
     return out
 
 
+def make_iso():
+    from math import factorial
+    d = 3
+    rng = np.random.default_rng(20240613)
+    X0 = rng.uniform(-3, 3, size=(7, d))
+    X1 = rng.uniform(-3, 3, size=(6, d))
+    ls = [sp.Rational(7, 10), sp.Rational(1), sp.Rational(13, 10)]
+    dir_a1 = 2.0 * np.random.default_rng(390852098).standard_normal(size=(d,))      # cases_matern.py:25-27
+    dir_a0 = 2.0 * np.random.default_rng(4158976).standard_normal(size=(d,))        # :44-46
+    r2 = np.random.default_rng(413598)                                              # :68-71
+    dir0, dir1 = r2.standard_normal(size=(d,)), r2.standard_normal(size=(d,))
+    out = {"X0": X0, "X1": X1, "lengthscales": np.array([float(v) for v in ls]),
+           "dir_arg1": dir_a1, "dir_arg0": dir_a0, "dir0": dir0, "dir1": dir1}
+    xs = sp.symbols(f"x0:{d}", real=True)
+    ys = sp.symbols(f"y0:{d}", real=True)
+
+    def dd(expr, v, vars_):
+        return sum(sp.Float(float(vj), 60) * sp.diff(expr, xj) for vj, xj in zip(v, vars_))
+
+    for nu2 in (5, 7):
+        p = (nu2 - 1) // 2
+        c = [sp.Rational(factorial(p), factorial(2 * p)) * sp.Rational(factorial(2 * p - k), factorial(p - k) * factorial(k)) * 2**k
+             for k in range(p + 1)]
+        s_ = sp.sqrt(sum((sp.sqrt(nu2) * (xi - yi) / l) ** 2 for xi, yi, l in zip(xs, ys, ls)))
+        k = sum(ck * s_**i for i, ck in enumerate(c)) * sp.exp(-s_)
+        exprs = {"k": k, "k_dd": dd(k, dir_a1, ys), "dd_k": dd(k, dir_a0, xs), "dd_k_dd": dd(dd(k, dir0, xs), dir1, ys)}
+        for name, e in exprs.items():
+            f = sp.lambdify((*xs, *ys), e, "mpmath")
+            out[f"matern{nu2}2_{name}"] = np.array(
+                [[float(f(*[mpmath.mpf(float(v)) for v in (*a, *b)])) for b in X1] for a in X0])
+    np.savez(os.path.join(HERE, "matern_iso_blocks.npz"), **out)
+    print("wrote matern_iso_blocks.npz")
+
+
 def to_np(M):
     return np.array([[float(M[i, j]) for j in range(M.cols)] for i in range(M.rows)])
 
 
 def main():
+    if sys.argv[1:] == ["iso"]:
+        return make_iso()
+    make_iso()
     rng = np.random.default_rng(20240612)
     out = {}
     # ---- 1-D factors, off-grid points (x != y everywhere) ----

@@ -98,8 +98,17 @@ def test_lowering_errors():
         diffops.Laplacian((3,))(k, argnum=0)
     with pytest.raises(NotImplementedError):  # no closed form for non-half-integer nu
         cf.Matern((), nu=2.2)
-    with pytest.raises(NotImplementedError):  # multivariate isotropic Matern: not on this path
-        cf.Matern((2,), nu=2.5)
+    # multivariate isotropic Matern: identity and directional derivatives only
+    kiso = cf.Matern((2,), nu=2.5, lengthscales=[0.5, 2.0])
+    dd = diffops.DirectionalDerivative(np.array([1.0, -2.0]))
+    g, = dd(dd(kiso, argnum=1), argnum=0).lower()
+    assert g["family"] == [lp._lib.MATERN_ISO] * 2 and g["p"] == [2, 2] and g["lengthscale"] == [0.5, 2.0]
+    assert sorted((c, a, b) for c, a, b in g["terms"]) == sorted(
+        [(1.0, (1, 0), (1, 0)), (-2.0, (1, 0), (0, 1)), (-2.0, (0, 1), (1, 0)), (4.0, (0, 1), (0, 1))])
+    with pytest.raises(NotImplementedError):  # the reference falls back to JAX autodiff here
+        lap(kiso, argnum=0).lower()
+    with pytest.raises(ValueError):           # not enough differentiability (cases_matern.py:64-65)
+        dd(dd(cf.Matern((2,), nu=1.5), argnum=1), argnum=0).lower()
     with pytest.raises(ValueError):
         cf.TensorProduct(cf.Matern((1,), nu=2.5))
     with pytest.raises(ValueError):

@@ -128,3 +128,72 @@ def test_tensor_product_expquad_equals_multivariate():
     got = covfuncs.LkL(kernel, covfuncs.identity(3), covfuncs.identity(3), X)
     D = (X[:, None, :] - X[None, :, :]) / ls
     np.testing.assert_allclose(got, np.exp(-0.5 * np.sum(D * D, axis=-1)), rtol=1e-13)
+
+
+# ---- isotropic multivariate Matérn with directional derivatives -------------------------------
+# the reference's cases `cases_matern.py:19-89` (input_shape (3,), its seeds for the directions)
+# checked the way `test_diffops.py:30-42` does (closed form vs derivative of the base kernel)
+def _sympy_matern_iso(p, a, d):
+    xs = sp.symbols(f"x0:{d}", real=True)
+    ys = sp.symbols(f"y0:{d}", real=True)
+    s = sp.sqrt(sum((a * (xi - yi)) ** 2 for xi, yi in zip(xs, ys)))
+    c = polynomials.matern_half_integer_coefficients(p)
+    k = sum(sp.Rational(ck.numerator, ck.denominator) * s**i for i, ck in enumerate(c)) * sp.exp(-s)
+    return xs, ys, k
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_matern_iso_vs_sympy(p):
+    d = 3
+    nu = p + 0.5
+    a_exact = sp.sqrt(2 * sp.Rational(2 * p + 1, 2))          # lengthscale 1, as in the reference's cases
+    xs, ys, k = _sympy_matern_iso(p, a_exact, d)
+    X0 = np.random.default_rng(109134809 + d).uniform(-3, 3, size=(12, d))
+    X1 = np.random.default_rng(1 + d).uniform(-3, 3, size=(9, d))
+    dir_a1 = 2.0 * np.random.default_rng(390852098).standard_normal(size=(d,))     # cases_matern.py:25-27
+    dir_a0 = 2.0 * np.random.default_rng(4158976).standard_normal(size=(d,))       # :44-46
+    rng = np.random.default_rng(413598)                                            # :68-71
+    dir0, dir1 = rng.standard_normal(size=(d,)), rng.standard_normal(size=(d,))
+    ident = covfuncs.identity(d)
+
+    def dd(v):
+        return {tuple(int(i == j) for i in range(d)): float(v[j]) for j in range(d)}
+
+    def sym_apply(expr, v, vars_):
+        return sum(sp.Float(float(vj), 60) * sp.diff(expr, xj) for vj, xj in zip(v, vars_))
+
+    cases = [("id x dd", ident, dd(dir_a1), sym_apply(k, dir_a1, ys)),
+             ("dd x id", dd(dir_a0), ident, sym_apply(k, dir_a0, xs))]
+    if p >= 2:
+        cases.append(("dd x dd", dd(dir0), dd(dir1), sym_apply(sym_apply(k, dir0, xs), dir1, ys)))
+        # identity + direction on both sides (what a Robin-type functional gives)
+        L0 = {**dd(dir0), (0,) * d: 0.7}
+        L1 = {**dd(dir1), (0,) * d: -1.3}
+        e0 = sp.Float(0.7, 60) * k + sym_apply(k, dir0, xs)
+        cases.append(("robin", L0, L1, sp.Float(-1.3, 60) * e0 + sym_apply(e0, dir1, ys)))
+    kernel = [(1.0, [("matern_iso", nu, np.ones(d))])]
+    for name, L0, L1, expr in cases:
+        got = covfuncs.LkL(kernel, L0, L1, X0, X1)
+        f = sp.lambdify((*xs, *ys), expr, "mpmath")
+        ref = np.array([[float(f(*[mpmath.mpf(float(v)) for v in (*x, *y)])) for y in X1] for x in X0])
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13, err_msg=f"p={p} {name}")
+
+
+def test_matern_iso_diagonal_and_lengthscales():
+    # x1 is None branches (`_matern.py:65-69,186-191`) == limit of the dense block; ARD lengthscales
+    d, nu = 3, 2.5
+    ls = np.array([0.6, 1.1, 2.0])
+    kernel = [(1.7, [("matern_iso", nu, ls)])]
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, size=(7, d))
+    v0, v1 = rng.standard_normal(d), rng.standard_normal(d)
+    L0 = {tuple(int(i == j) for i in range(d)): float(v0[j]) for j in range(d)}
+    L1 = {tuple(int(i == j) for i in range(d)): float(v1[j]) for j in range(d)}
+    for A, B in [(covfuncs.identity(d), covfuncs.identity(d)), (L0, covfuncs.identity(d)), (L0, L1)]:
+        dense = covfuncs.LkL(kernel, A, B, X, X)
+        np.testing.assert_allclose(covfuncs.k_diag(kernel, A, B, X), np.diag(dense), rtol=1e-13, atol=1e-15)
+    # d = 1 isotropic == the univariate factor
+    X1 = rng.uniform(-1, 1, size=(9, 1))
+    got = covfuncs.LkL([(1.0, [("matern_iso", nu, np.array([0.8]))])], {(1,): 1.0}, {(1,): 1.0}, X1, X1)
+    ref = covfuncs.LkL([(1.0, [("matern", nu, 0.8)])], {(1,): 1.0}, {(1,): 1.0}, X1, X1)
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-14)
