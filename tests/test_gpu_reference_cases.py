@@ -1,0 +1,111 @@
+"""The reference's own kernel-derivative cases, case by case, on its own inputs.
+
+`tests/linpde_gp/randprocs/kernels/linfuncops/diffops/cases/cases_expquad.py:15-148` (8 operator
+pairs x input shapes (), (1,), (3,)) and `cases_matern.py:18-203` (the univariate rows; the (3,)
+rows are in test_gpu_matern_iso.py; the tensor-product cases in test_gpu_parity.py), evaluated
+like `test_diffops.py:14-42`: 128 Sobol points in [-3, 3]^d, seed 109134809 + d, the in-file seeds
+for directions and weights; `L0kL1(Xs[:, None], Xs[None, :])` against an independent evaluation
+(there: JAX autodiff, atol 1e-14; here: the SymPy-pinned oracle, 1e-12 of the block maximum), plus
+the `linop` product the reference checks against KeOps (`test_diffops.py:58-72`).
+"""
+import numpy as np
+import pytest
+import scipy.stats
+
+from oracle import covfuncs as ocf
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = ((), (1,), (3,))
+
+
+def _X(shape):
+    d = int(np.prod(shape, dtype=int))
+    xs = scipy.stats.qmc.scale(scipy.stats.qmc.Sobol(d, seed=109134809 + d).random_base2(7), -3.0, 3.0)
+    return xs.reshape((-1,) + shape)
+
+
+def _op(kind, par):
+    from linpde_gp_amd.linfuncops import diffops
+    if kind is None:
+        return None
+    if kind == "dd":
+        return diffops.DirectionalDerivative(par)
+    if kind == "wl":
+        return diffops.WeightedLaplacian(par)
+    return float(par) * diffops.Derivative(1)            # cases_matern.py:199-200
+
+
+def _coeffs(kind, par, d):
+    if kind is None:
+        return ocf.identity(d)
+    v = np.asarray(par, dtype=float).reshape(-1)
+    order = 2 if kind == "wl" else 1
+    return {tuple(order * int(i == j) for i in range(d)): float(v[j]) for j in range(d)}
+
+
+def _expquad_cases():
+    out = []
+    for shape in SHAPES:
+        def draw(seed, n, scale=2.0):
+            rng = np.random.default_rng(seed)
+            return [scale * rng.standard_normal(size=shape) for _ in range(n)]
+        d, = draw(390852098, 1); out.append(("id-dd", shape, None, ("dd", d)))
+        d, = draw(4158976, 1); out.append(("dd-id", shape, ("dd", d), None))
+        d0, d1 = draw(52469753628, 2, 1.0); out.append(("dd-dd", shape, ("dd", d0), ("dd", d1)))
+        w, = draw(524390, 1); out.append(("id-wl", shape, None, ("wl", w)))
+        w, = draw(2309823372, 1); out.append(("wl-id", shape, ("wl", w), None))
+        w0, w1 = draw(235890, 2); out.append(("wl-wl", shape, ("wl", w0), ("wl", w1)))
+        d, w = draw(4158976, 2); out.append(("dd-wl", shape, ("dd", d), ("wl", w)))
+        d, w = draw(4158976, 2); out.append(("wl-dd", shape, ("wl", w), ("dd", d)))
+    return out
+
+
+def _matern_cases():
+    out = []
+    for shape in ((), (1,)):
+        for nu in (1.5, 2.5, 3.5, 4.5):
+            def draw(seed, n, scale=2.0):
+                rng = np.random.default_rng(seed)
+                return [scale * rng.standard_normal(size=shape) for _ in range(n)]
+            d, = draw(390852098, 1); out.append(("id-dd", shape, nu, None, ("dd", d)))
+            d, = draw(4158976, 1); out.append(("dd-id", shape, nu, ("dd", d), None))
+            d0, d1 = draw(413598, 2, 1.0); out.append(("dd-dd", shape, nu, ("dd", d0), ("dd", d1)))
+            if shape == ():
+                out.append(("deriv-deriv", shape, nu, ("deriv", d0), ("deriv", d1)))
+            if shape == () and nu >= 2.5:
+                w, = draw(5468907, 1); out.append(("id-wl", shape, nu, None, ("wl", w)))
+                w, = draw(87905642, 1); out.append(("wl-id", shape, nu, ("wl", w), None))
+                w0, w1 = draw(257834, 2); out.append(("wl-wl", shape, nu, ("wl", w0), ("wl", w1)))
+                d, w = draw(4158976, 2); out.append(("dd-wl", shape, nu, ("dd", d), ("wl", w)))
+                d, w = draw(654890, 2); out.append(("wl-dd", shape, nu, ("wl", w), ("dd", d)))
+    return out
+
+
+def _check(k, okern, shape, L0, L1):
+    d = max(int(np.prod(shape, dtype=int)), 1)
+    Xs = _X(shape)
+    kk = k
+    if L1 is not None:
+        kk = _op(*L1)(kk, argnum=1)
+    if L0 is not None:
+        kk = _op(*L0)(kk, argnum=0)
+    Xf = Xs.reshape(-1, d)
+    ref = ocf.LkL(okern, _coeffs(*(L0 or (None, None)), d), _coeffs(*(L1 or (None, None)), d), Xf, Xf)
+    got = kk(Xs[:, None], Xs[None, :])
+    assert got.shape == (128, 128)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(kk.linop(Xs, Xs) @ np.eye(128), ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,shape,L0,L1", _expquad_cases(), ids=lambda v: str(v) if isinstance(v, (str, tuple)) and not isinstance(v[0:1], tuple) else None)
+def test_reference_expquad_cases(name, shape, L0, L1):
+    import linpde_gp_amd as lp
+    d = max(int(np.prod(shape, dtype=int)), 1)
+    _check(lp.randprocs.covfuncs.ExpQuad(shape), [(1.0, [("expquad", 1.0)] * d)], shape, L0, L1)
+
+
+@pytest.mark.parametrize("name,shape,nu,L0,L1", _matern_cases(), ids=lambda v: str(v) if isinstance(v, (str, float)) else None)
+def test_reference_matern_univariate_cases(name, shape, nu, L0, L1):
+    import linpde_gp_amd as lp
+    _check(lp.randprocs.covfuncs.Matern(shape, nu=nu), [(1.0, [("matern", nu, 1.0)])], shape, L0, L1)
