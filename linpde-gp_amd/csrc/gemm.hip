@@ -16,6 +16,7 @@
 // super-tile at a time (its 16 operand panels stay in that XCD's L2).
 
 #include "lpgp_internal.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace lpgp {
@@ -164,6 +165,57 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
   return true;
 }
 
+// Dense enumeration: list index -> tile.  Bands of 8 tile rows; inside a band column-major over
+// the valid columns (c < nt, and c <= r for the triangular shapes), so that 64 consecutive
+// indices are one 8 x 8 block of tiles (8 row panels + 8 column panels in the XCD's L2).  XCD x
+// (blocks with v & 7 == x) walks the contiguous range [x * chunk, (x + 1) * chunk) of the list:
+// every XCD gets the same number of tiles whatever the shape.  (The super-tile dealing of map_tile
+// hands a triangular super-tile on the diagonal -- 36 tiles -- to an XCD with 64 slots; measured
+// on SYRK n x n x 512: n = 16384 51.2 -> 51.9, 12288 48.1 -> 49.9, 6144 49.2 -> 51.0 TFLOP/s,
+// rectangular shapes unchanged; scratch/dense_ab.py.)
+constexpr int BAND = 8;
+template <bool TRI>
+__device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr, int& tc) {
+  const int xcd = v & 7, q = v >> 3;
+  const int idx = xcd * g.chunk + q;
+  if (idx >= g.ntiles) return false;
+  int b, j;
+  if (!TRI) {
+    const int per = BAND * g.nt;
+    b = idx / per;
+    j = idx - b * per;
+  } else {
+    int lo = 0, hi = g.nbands;                       // band_prefix[lo] <= idx < band_prefix[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (g.band_prefix[mid] <= idx) lo = mid; else hi = mid;
+    }
+    b = lo;
+    j = idx - g.band_prefix[b];
+  }
+  const int r0 = b * BAND;
+  const int R = (g.mt - r0 < BAND) ? g.mt - r0 : BAND;
+  int r, c;
+  if (!TRI) {
+    c = j / R;
+    r = r0 + (j - c * R);
+  } else {
+    const int cfull = (r0 + 1 < g.nt) ? r0 + 1 : g.nt;       // columns c <= r0: all R rows valid
+    if (j < cfull * R) {
+      c = j / R;
+      r = r0 + (j - c * R);
+    } else {
+      int jj = j - cfull * R, t = 0;
+      while (jj >= R - 1 - t) { jj -= R - 1 - t; ++t; }      // column r0+1+t has rows r0+1+t .. r0+R-1
+      c = r0 + 1 + t;
+      r = c + jj;
+    }
+  }
+  tr = __builtin_amdgcn_readfirstlane(r);
+  tc = __builtin_amdgcn_readfirstlane(c);
+  return true;
+}
+
 // TRI != 0: lower-triangular output (symmetric rank-k update).  TRI = 1 is the rank-nb trailing
 // update of the blocked Cholesky (the remainder half of the look-ahead split: the bulk of the
 // flops), TRI = 3 its look-ahead half (the next panel's columns, on the panel stream, possibly
@@ -195,8 +247,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int wum = wu & 1, wun = wu >> 1;
   const double alpha = g.alpha, beta = g.beta;
 
+#ifdef LPGP_STAMP
+  const unsigned long long st_rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
   int tr, tc;
-  if (!map_tile<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
+  if (g.dense) {
+    if (!map_tile_dense<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
+  } else {
+    if (!map_tile<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
+  }
 
   // per-lane byte addresses of the fragment reads (stage 0 of each operand; see frag_lane_*)
   unsigned laneM[4];
@@ -322,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     o[5] = __builtin_amdgcn_s_memtime() - st_tile0;       // whole k loop, core clocks
     o[6] = __builtin_amdgcn_s_memrealtime() - st_real0;   // same in 100 MHz ticks
   }
+  const unsigned long long st_rt_kend = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // ---- epilogue: lane holds C[m = 16t + (l&15)][n = 4u + (l>>4)] in acc[t][u]; stores only ----
@@ -330,6 +390,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
+#ifdef LPGP_STAMP
+  if (g.timeline != nullptr && tid == 0) {
+    // workgroup life cycle in 100 MHz ticks + where it ran (scratch/timeline.hip):
+    // [start, k-loop begin, k-loop end, stores issued, hw id, xcc]
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = g.timeline + (size_t)blockIdx.x * 8;
+    o[0] = st_rt_start; o[1] = st_real0; o[2] = st_rt_kend; o[3] = __builtin_amdgcn_s_memrealtime();
+    o[4] = hw; o[5] = xcc & 0xf;
+  }
+#endif
 }
 
 // =========================================================================================
@@ -516,6 +588,28 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     attr_set = true;
   }
   GemmArgs ga = g;
+  if (ctx->dense_tiles && (g.mt + BAND - 1) / BAND <= GemmArgs::MAXB) {
+    ga.dense = 1;
+    ga.nbands = (g.mt + BAND - 1) / BAND;
+    if (TRI) {
+      LPGP_CHECK(g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
+      int acc = 0;
+      for (int b = 0; b < ga.nbands; ++b) {
+        ga.band_prefix[b] = acc;
+        const int r0 = b * BAND, R = std::min(BAND, g.mt - r0);
+        acc += std::min(r0 + 1, g.nt) * R;
+        for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t) acc += R - 1 - t;
+      }
+      ga.band_prefix[ga.nbands] = acc;
+      ga.ntiles = acc;
+    } else {
+      ga.ntiles = g.mt * g.nt;
+    }
+    ga.chunk = (ga.ntiles + 7) / 8;
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)(8 * ga.chunk)), dim3(256), shmem, stream, ga);
+    LPGP_HIP(hipGetLastError());
+    return 0;
+  }
   int nsuper = 0, SS = 64;
   for (int sh = 3; sh >= 0; --sh) {
     const int S = 1 << sh;

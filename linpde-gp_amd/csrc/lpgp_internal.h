@@ -99,6 +99,7 @@ struct lpgp_ctx {
   int nb_big_min_tiles = 96;
   int lookahead = 1;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
+  int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
   // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,
@@ -195,8 +196,14 @@ struct GemmArgs {
   int32_t k;
   double alpha, beta;
   int32_t tri;
-  int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm)
+  int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm; legacy mapping)
+  // dense tile enumeration (set by launch_gemm; map_tile_dense in gemm.hip)
+  int32_t dense = 0;
+  int32_t ntiles = 0, chunk = 0, nbands = 0;
+  static constexpr int MAXB = 192; // bands of 8 tile rows: 1536 tile rows = 196 608 matrix rows (> 288 GB of fp64)
+  int32_t band_prefix[MAXB + 1];   // triangular shapes only: tiles before band b
   unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
+  unsigned long long* timeline = nullptr; // diagnostic builds: per-workgroup life cycle + hardware id
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
 
