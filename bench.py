@@ -120,7 +120,9 @@ def main():
         # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be
         # created (on every rank alike), the run degrades to independent replicas and says so.
         try:
-            ctx.dist_init(comm)
+            # LPGP_DIST_TRANSPORT=host: bring-up on a box whose ranks share one GPU (panels staged
+            # through the host; never a benchmark configuration)
+            ctx.dist_init(comm, transport=os.environ.get("LPGP_DIST_TRANSPORT", "rccl"))
             ok, err = True, ""
         except Exception as exc:            # noqa: BLE001 (reported in the JSON line)
             ok, err = False, f"{type(exc).__name__}: {exc}"
@@ -222,7 +224,9 @@ def main():
             "multi_gpu": ("single GPU" if world == 1 else
                           (dist_note or "independent replicas (one problem per GPU)") if replicas else
                           f"one problem, panels of 512 columns owned cyclically by {world} ranks (1x{world} grid), "
-                          "RCCL panel broadcast, replicated factor, prediction points sharded"
+                          + ("HOST-STAGED panel broadcast (bring-up transport, not a benchmark configuration)"
+                             if os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host" else "RCCL panel broadcast")
+                          + ", replicated factor, prediction points sharded"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
             "device": info["name"].strip(),
         },

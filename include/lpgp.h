@@ -81,6 +81,14 @@ int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
 int  lpgp_dist_unique_id(char* out128);
 int  lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128);
 int  lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world);
+/* Bring-up / test transport: the same distributed factorisation with every panel staged through
+ * the host and handed to a caller-supplied exchange (op 0: broadcast `bytes` bytes of buf from
+ * rank `root`; op 1: element-wise max all-reduce of one int32 in buf; return 0 on success) instead
+ * of RCCL.  Ranks may then share ONE GPU (RCCL refuses that), which is how tests/test_gpu_dist.py
+ * runs 2- and 3-rank jobs on the single-GPU box.  All arithmetic still runs on the device; it is
+ * not a data path of the product (bench.py never selects it).                               */
+typedef int (*lpgp_host_exchange_fn)(void* user, int32_t op, void* buf, int64_t bytes, int32_t root);
+int  lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user);
 
 /* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) ----- */
 int  lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out);

@@ -434,7 +434,7 @@ int lpgp_dist_unique_id(char* out128) {
 
 int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128) {
   LPGP_CHECK(ctx && uid128 && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init: bad argument");
-  LPGP_CHECK(ctx->nccl_comm == nullptr, "lpgp_dist_init: already initialised");
+  LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init: already initialised");
   LPGP_HIP(hipSetDevice(ctx->device));
   ncclUniqueId id;
   std::memcpy(&id, uid128, 128);
@@ -442,6 +442,16 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
   ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
   LPGP_CHECK(r == ncclSuccess, "ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r));
   ctx->nccl_comm = comm;
+  ctx->rank = rank;
+  ctx->world = world;
+  return 0;
+}
+
+int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user) {
+  LPGP_CHECK(ctx && fn && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init_host: bad argument");
+  LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init_host: already initialised");
+  ctx->host_xfer = fn;
+  ctx->host_xfer_user = user;
   ctx->rank = rank;
   ctx->world = world;
   return 0;
@@ -663,7 +673,7 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   if (info) *info = 0;
   if (mat->pn_fact == mat->pn) return 0;
   int32_t h = 0;
-  int rc = (ctx->nccl_comm != nullptr)
+  int rc = ctx->distributed()
                ? potrf_blocked_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
                : potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
   if (rc != 0) return rc;

@@ -120,6 +120,9 @@ struct lpgp_ctx {
   int rank = 0, world = 1;
   int test_own_world = 0, test_own_rank = 0;   // tests only: ownership filter of the assembly as if (rank, world)
   void* nccl_comm = nullptr;       // ncclComm_t
+  lpgp_host_exchange_fn host_xfer = nullptr;   // test transport (lpgp_dist_init_host): panels staged through the host
+  void* host_xfer_user = nullptr;
+  bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr; }
   double* d_pack = nullptr;        // packed panel staging for the broadcast
   size_t pack_cap = 0;             // doubles
   // profiling

@@ -506,6 +506,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
   hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
   LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
   auto owner_of = [&](int p0) { return ((p0 - t_done) / nbt) % P; };
+  std::vector<double> host_stage;                  // test transport only
 
   // ---- phase A (append): every rank pushes the new rows through the factored columns
   //      (replicated: n_new * n_old^2 flops), but updates only the new columns it owns ----
@@ -575,7 +576,20 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
       LPGP_HIP(hipMemcpyAsync(pk + (size_t)rows * cols, linv0, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
                               hipMemcpyDeviceToDevice, sP));
     }
-    LPGP_NCCL(ncclBroadcast(pk, pk, cnt, ncclDouble, own, comm, sP));
+    if (ctx->host_xfer) {
+      // test transport: D2H on the owner, the caller's exchange, H2D on the receivers
+      if (host_stage.size() < cnt) host_stage.resize(cnt);
+      if (own == me) LPGP_HIP(hipMemcpyAsync(host_stage.data(), pk, cnt * sizeof(double), hipMemcpyDeviceToHost, sP));
+      LPGP_HIP(hipStreamSynchronize(sP));
+      LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 0, host_stage.data(), (int64_t)(cnt * sizeof(double)), own) == 0,
+                 "host exchange: broadcast of panel %d failed", it);
+      if (own != me) {
+        LPGP_HIP(hipMemcpyAsync(pk, host_stage.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sP));
+        LPGP_HIP(hipStreamSynchronize(sP));          // host_stage is reused by the next panel
+      }
+    } else {
+      LPGP_NCCL(ncclBroadcast(pk, pk, cnt, ncclDouble, own, comm, sP));
+    }
     static const bool selftest = std::getenv("LPGP_DIST_SELFTEST") != nullptr;
     if (own == me && selftest) {
       // single-GPU test of the receive path: forget the panel (NaN bytes), then unpack it like a receiver
@@ -622,7 +636,9 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
   // a failed pivot is detected by the panel's owner only: agree on it (max over ranks)
-  {
+  if (ctx->host_xfer) {
+    LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, &h_info, (int64_t)sizeof(int), 0) == 0, "host exchange: all-reduce failed");
+  } else {
     int* d = ctx->d_info;
     LPGP_HIP(hipMemcpyAsync(d, &h_info, sizeof(int), hipMemcpyHostToDevice, sP));
     LPGP_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMax, comm, sP));

@@ -129,6 +129,20 @@ class Comm:
             return obj
         return _recv(self._sock)
 
+    def bcast_from(self, obj, root: int):
+        """Broadcast from an arbitrary rank over the star: the root hands its object to rank 0,
+        which forwards it to everybody (the root included)."""
+        if self.world == 1 or root == 0:
+            return self.bcast(obj)
+        if self.rank == 0:
+            obj = _recv(self._peers[root - 1])
+            for p in self._peers:
+                _send(p, obj)
+            return obj
+        if self.rank == root:
+            _send(self._sock, obj)
+        return _recv(self._sock)
+
     def allgather(self, obj):
         return self.bcast(self.gather(obj))
 

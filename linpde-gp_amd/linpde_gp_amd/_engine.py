@@ -26,13 +26,36 @@ class Context:
         self.device = int(device)
         self.rank, self.world, self.comm = 0, 1, None
 
-    def dist_init(self, comm) -> None:
-        """Join the RCCL communicator of a one-process-per-GPU job.  `comm` is the control
-        plane (`_dist.Comm`): rank 0 creates the unique id, everybody receives it, then
-        `ncclCommInitRank`.  From here on `GramMatrix.assemble/potrf` run the distributed
-        factorisation (cyclic panel ownership, replicated factor)."""
-        if comm.world == 1 and not os.environ.get("LPGP_FORCE_RCCL"):
+    def dist_init(self, comm, transport: str = "rccl") -> None:
+        """Join a one-process-per-GPU job.  `comm` is the control plane (`_dist.Comm`).
+        transport "rccl" (the product path): rank 0 creates the RCCL unique id, everybody receives
+        it, then `ncclCommInitRank`; panels travel by `ncclBroadcast` over xGMI.  transport "host"
+        (bring-up / tests): panels are staged through the host and exchanged over the control
+        plane, so that several ranks may share one GPU.  From here on `GramMatrix.assemble/potrf`
+        run the distributed factorisation (cyclic panel ownership, replicated factor)."""
+        if transport not in ("rccl", "host"):
+            raise ValueError("transport must be 'rccl' or 'host'")
+        if comm.world == 1 and not os.environ.get("LPGP_FORCE_RCCL") and transport == "rccl":
             self.comm = comm
+            return
+        if transport == "host":
+            def exchange(_user, op, buf, nbytes, root):
+                try:
+                    view = (C.c_char * nbytes).from_address(buf)
+                    if op == 0:
+                        data = comm.bcast_from(bytes(view) if comm.rank == root else None, root)
+                        if comm.rank != root:
+                            view[:] = data
+                    else:
+                        vals = comm.allgather(int.from_bytes(bytes(view), "little", signed=True))
+                        view[:] = int(max(vals)).to_bytes(nbytes, "little", signed=True)
+                    return 0
+                except Exception:  # noqa: BLE001 (reported through the C return code)
+                    return 1
+            self._host_exchange = _lib.HOST_EXCHANGE_FN(exchange)      # keep the callback alive
+            check(lib.lpgp_dist_init_host(self._h, comm.rank, comm.world, self._host_exchange, None),
+                  "lpgp_dist_init_host")
+            self.rank, self.world, self.comm = comm.rank, comm.world, comm
             return
         uid = None
         if comm.rank == 0:

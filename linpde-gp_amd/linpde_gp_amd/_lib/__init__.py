@@ -37,6 +37,10 @@ class KDesc(C.Structure):
     ]
 
 
+# int fn(void* user, int32 op, void* buf, int64 bytes, int32 root)   (lpgp_host_exchange_fn)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32)
+
+
 class LpgpError(RuntimeError):
     pass
 
@@ -66,6 +70,7 @@ def _load() -> C.CDLL:
     sig("lpgp_dist_unique_id", C.c_int, C.c_char_p)
     sig("lpgp_dist_init", C.c_int, vp, i32, i32, C.c_char_p)
     sig("lpgp_dist_info", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
+    sig("lpgp_dist_init_host", C.c_int, vp, i32, i32, HOST_EXCHANGE_FN, vp)
     sig("lpgp_pts_create", C.c_int, vp, pd, i64, i32, C.POINTER(vp))
     sig("lpgp_pts_destroy", C.c_int, vp)
     sig("lpgp_mat_create", C.c_int, vp, i64, C.POINTER(vp))
@@ -106,7 +111,7 @@ lib = _load()
 
 EXPORTED = [
     "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
-    "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
+    "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_dist_init_host", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",

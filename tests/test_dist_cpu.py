@@ -210,3 +210,34 @@ def test_predict_sharding_bounds():
     for n, world in ((4096, 8), (10, 3), (7, 7)):
         b = np.linspace(0, n, world + 1).astype(int)
         assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and np.diff(b).max() - np.diff(b).min() <= 1
+
+
+def _bcast_from_worker(rank, world, port, q):
+    import os, sys
+    sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd", "linpde_gp_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dist", os.path.join(ROOT, "linpde-gp_amd", "linpde_gp_amd", "_dist.py"))
+    _dist = importlib.util.module_from_spec(spec); spec.loader.exec_module(_dist)
+    comm = _dist.Comm(rank, world, "127.0.0.1", port)
+    got = [comm.bcast_from(("payload", root, bytes(range(7))) if rank == root else None, root) for root in range(world)]
+    got.append(comm.allreduce_max(float(rank)))
+    comm.barrier()
+    comm.close()
+    q.put((rank, got))
+
+
+def test_control_plane_bcast_from_any_root():
+    """`Comm.bcast_from` (used by the host-staged test transport of the distributed factorisation)."""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    world, port = 3, 29891
+    q = ctxm.Queue()
+    ps = [ctxm.Process(target=_bcast_from_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+    for r in range(world):
+        assert res[r][:world] == [("payload", root, bytes(range(7))) for root in range(world)]
+        assert res[r][world] == float(world - 1)

@@ -1,7 +1,14 @@
-"""Distributed code path on ONE GPU: world_size 1 through RCCL (ncclCommInitRank, panel
-pack / ncclBroadcast / all-reduce of info) must reproduce the single-GPU factorisation.
-Multi-rank behaviour is modelled on CPU in tests/test_dist_cpu.py (the 8-GPU node is only
-available to the driver)."""
+"""Distributed code path on ONE GPU.
+
+* world_size 1 through RCCL (ncclCommInitRank, panel pack / ncclBroadcast / all-reduce of info)
+  must reproduce the single-GPU factorisation;
+* world_size 2 and 3 as separate processes SHARING the GPU: RCCL refuses two ranks on one device,
+  so these jobs use the host-staged test transport (`lpgp_dist_init_host`: every panel goes D2H ->
+  control plane -> H2D); everything else is the product path: ownership-filtered assembly, cyclic
+  panel ownership with block append, pack / unpack, replicated factor, sharded prediction,
+  gathered results.  Every rank must match the oracle.
+The 8-GPU node with RCCL over xGMI is only available to the driver; a NumPy mirror of the
+algorithm also runs on gloo ranks in tests/test_dist_cpu.py."""
 import os
 import subprocess
 import sys
@@ -39,6 +46,64 @@ def test_world1_rccl_path_matches_oracle():
     out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST1" in out.stdout
+
+
+MULTI = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine, problems
+from oracle import workloads as owl
+comm = _dist.Comm.from_env()
+ctx = _engine.default_context()            # LPGP_DEVICE=0 on every rank: the ranks share the GPU
+ctx.dist_init(comm, transport="host")
+assert ctx.world == comm.world and ctx.rank == comm.rank
+ctx.set_option("nb", %(nb)d)
+wl = problems.%(workload)s
+u, mean, var = problems.condition_and_predict(wl)
+ref = owl.run(wl)
+em = np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))
+ev = np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))
+# the factor is replicated: every rank holds all of it
+Lf = u.gram.cholesky(True)
+G = Lf @ Lf.T
+from oracle import gp as ogp
+G_ref = ogp.gram(wl.kernel, owl.blocks_of(wl))
+eg = np.max(np.abs(G - G_ref)) / np.max(np.abs(G_ref))
+print("RANK", comm.rank, "of", comm.world, em, ev, eg, flush=True)
+assert em < 1e-8 and ev < 1e-8 and eg < 1e-12
+comm.barrier()
+comm.close()
+"""
+
+
+def _run_ranks(world, workload, nb, port):
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
+    env.pop("LOCAL_RANK", None)
+    procs = [subprocess.Popen([sys.executable, "-c", MULTI % {"root": ROOT, "workload": workload, "nb": nb}],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
+        assert f"RANK {r} of {world}" in so
+
+
+@pytest.mark.parametrize("world,workload,nb,port", [
+    (2, "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 512, 29711),      # 4 panels, ragged, 5 blocks (append)
+    (3, "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 29731),      # 8 panels over 3 ranks
+    (2, "heat_1d(nt=40, nx=24, m_side=8)", 256, 29751),                 # mixed functional / differential blocks
+])
+def test_multi_rank_on_one_gpu_host_transport(world, workload, nb, port):
+    _run_ranks(world, workload, nb, port)
 
 
 def test_assembly_ownership_filter():
