@@ -337,6 +337,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   }
   if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_TRSM_SLAB")) ctx->trsm_slab = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_big = v;
@@ -404,6 +405,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->test_own_rank = (int)(value % 1000);
   } else if (std::strcmp(key, "small_tiles_max") == 0) {
     ctx->small_tiles_max = (int)value;
+  } else if (std::strcmp(key, "trsm_slab") == 0) {
+    ctx->trsm_slab = (int)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {

@@ -563,6 +563,143 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
       *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
 }
 
+// =========================================================================================
+// Panel triangular solve as a product with the explicit tile inverse, IN PLACE:
+//     X[rows, 0:128] <- X[rows, 0:128] * Linv^T        (Linv: 128 x 128 lower triangular, ld 128)
+// This is the second kernel of every step of the panel chain (tile Cholesky -> this -> rank-128
+// update inside the panel), i.e. latency, not throughput: with one 128 x 128 x 128 tile per
+// workgroup (gemm_f64_kernel) a CU needs 21 us for it whatever else idles.  Here a workgroup of
+// eight waves owns a 64-row slab and all 128 columns (it reads only the rows it overwrites, and
+// all of them before its first store: in place is safe), wave = 64 x 16 column slab as in
+// gemm64_f64_kernel, both operands streamed through the same 4-stage LDS-DMA ring (A: 64 x 16 per
+// stage, the [k/2][2][64] image of gemm64; Linv^T: 128 x 16 per stage, image [k/2][2][128]).
+// Column slab c needs only k < 16 (c + 1) (Linv is lower triangular): a wave skips the matrix
+// work of the stages beyond, and the slabs are dealt so that the two waves of a SIMD hold slabs
+// s and 7 - s (9 stage units of 16 per SIMD instead of 12).
+// =========================================================================================
+constexpr int LDP2 = 272;                // pair of k-rows of 128 indices + 16 doubles of padding (LDP2 % 32 == 16)
+constexpr int TS_A = 8 * LDMP;           // doubles per stage: A image
+constexpr int TS_B = 8 * LDP2;           // doubles per stage: Linv^T image
+constexpr int TS_STAGE = TS_A + TS_B;
+
+struct TrsmTileArgs {
+  double* X;                       // rows x 128, column-major
+  int64_t ldx;
+  const double* linv;              // 128 x 128, column-major, ld 128
+  int32_t slabs;                   // 64-row slabs
+};
+
+__global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int slab = wu < 4 ? wu : 11 - wu;                 // column slab [16 slab, 16 slab + 16)
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
+  constexpr int KT = TILE / BK;                            // 8 stages of 16
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+
+  auto issue = [&](int kt) {
+    double* sa = smem + (size_t)(kt & (SSTAGES - 1)) * TS_STAGE;
+    double* sb = sa + TS_A;
+    // A: k-row pair wu of the stage (lanes 0-31 / 32-63 = the two k-rows, 64 indices each)
+    {
+      const unsigned voff = ((unsigned)(lane >> 5) * (unsigned)g.ldx + (unsigned)(lane & 31) * 2u) * 8u;
+      const char* ub = reinterpret_cast<const char*>(g.X + row0 + ((int64_t)kt * BK + 2 * wu) * g.ldx);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sa + wu * LDMP), 16, 0, 0);
+    }
+    // Linv^T: element (k, c) = Linv[c + 128 k]: one k-row of 128 indices per wave instruction
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 2 * wu + h;                            // k-row of the stage; pair wu, half h
+      const char* ub = reinterpret_cast<const char*>(g.linv + ((int64_t)kt * BK + r) * TILE);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + wu * LDP2 + h * 128), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int kt = 0; kt < SSTAGES - 1; ++kt) issue(kt);
+
+  const int j = lane >> 4;
+  unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDMP + (j >> 1) * 64 + (lane & 15));
+  unsigned laneN = lds_base + 8u * (unsigned)(TS_A + (j & 1) * LDP2 + (j >> 1) * 128 + 16 * slab + (lane & 3));
+
+  double acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);
+    if (kt > slab) continue;                               // Linv[c][k] = 0 for k > c (wave-uniform)
+    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * TS_STAGE) * 8u;
+    const unsigned aM = laneM + stoff, aN = laneN + stoff;
+    double am[2][4], bn[2][4];
+    asm volatile("" ::: "memory");
+    static_for<0, 4>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      am[0][t] = lds_read_async<16 * t>(aM);
+    });
+    static_for<0, 4>([&](auto U_) {
+      constexpr int u = decltype(U_)::value;
+      bn[0][u] = lds_read_async<4 * u>(aN);
+    });
+    static_for<0, 4>([&](auto K_) {
+      constexpr int ks = decltype(K_)::value;
+      if constexpr (ks + 1 < 4) {
+        static_for<0, 4>([&](auto T_) {
+          constexpr int t = decltype(T_)::value;
+          am[(ks + 1) & 1][t] = lds_read_async<2 * (ks + 1) * LDMP + 16 * t>(aM);
+        });
+        static_for<0, 4>([&](auto U_) {
+          constexpr int u = decltype(U_)::value;
+          bn[(ks + 1) & 1][u] = lds_read_async<2 * (ks + 1) * LDP2 + 4 * u>(aN);
+        });
+        LDS_WAIT(8);
+      } else {
+        LDS_WAIT(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[ks & 1][u], am[ks & 1][t], acc[t][u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  // in place: the slab's rows were read from global memory by DMA only, the last of it waited for
+  // (vmcnt) by every wave before the barrier of stage 7, which every wave has passed here
+  char* const cub = reinterpret_cast<char*>(g.X + (int64_t)(16 * slab) * g.ldx + row0);
+  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldx + (unsigned)(lane & 15)) * 8u;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldx + t * 16) * 8 + cvoff) = acc[t][u];
+}
+
+int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel) {
+  if (mt <= 0) return 0;
+  const size_t shmem = (size_t)SSTAGES * TS_STAGE * sizeof(double);       // 106 496 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  TrsmTileArgs a;
+  a.X = X; a.ldx = ldx; a.linv = linv; a.slabs = mt * 2;
+  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)mt * TILE * TILE * TILE, 0.0);
+  hipLaunchKernelGGL(trsm_tile_kernel, dim3((unsigned)(mt * 2)), dim3(512), shmem, stream, a);
+  if (prof_kernel >= 0) prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
 template <bool TA, bool TB, int TRI>
 static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   const size_t shmem = (size_t)SSTAGES * 2 * SOPER * sizeof(double);      // 73 728 B

@@ -99,6 +99,7 @@ struct lpgp_ctx {
   int nb_big_min_tiles = 96;
   int lookahead = 1;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
+  int trsm_slab = 1;               // panel triangular solves by trsm_tile_kernel (0: one 128x128x128 tile per workgroup)
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
@@ -209,6 +210,8 @@ struct GemmArgs {
   unsigned long long* timeline = nullptr; // diagnostic builds: per-workgroup life cycle + hardware id
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
+// X (mt*128 rows x 128, column-major ldx) <- X * linv^T in place, linv a 128 x 128 lower-triangular tile inverse
+int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel);
 
 // potrf.hip -------------------------------------------------------------------------------
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,

@@ -308,6 +308,15 @@ static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t
   return g;
 }
 
+// X (mt tiles of rows x one tile column) <- X * linv^T, in place
+static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, double* X, int64_t ld, const double* linv, int mt) {
+  if (ctx->trsm_slab) return launch_trsm_tile(ctx, st, X, ld, linv, mt, LPGP_K_TRSM);
+  GemmArgs g;
+  g.A = X; g.B = linv; g.C = X; g.lda = ld; g.ldb = TILE; g.ldc = ld;
+  g.mt = mt; g.nt = 1; g.k = TILE; g.alpha = 1.0; g.beta = 0.0; g.tri = 0;
+  return launch_gemm(ctx, st, 0, 0, g, LPGP_K_TRSM);
+}
+
 #define LPGP_TRY(expr)            \
   do {                            \
     int _rc = (expr);             \
@@ -332,9 +341,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
       for (int jt = p0; jt < p1; ++jt) {
         double* X = rows + (int64_t)jt * tb * ld;
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                             mk(X, ld, mat->linv + (int64_t)jt * tb * tb, tb, X, ld, mnew, 1, TILE, 1.0, 0.0, 0),
-                             LPGP_K_TRSM));
+        LPGP_TRY(panel_trsm(ctx, sP, X, ld, mat->linv + (int64_t)jt * tb * tb, mnew));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
@@ -377,8 +384,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
       LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
       if (jt + 1 < T) {
         double* X = dj + tb;     // rows below, same tile column
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0, mk(X, ld, linv, tb, X, ld, T - jt - 1, 1, TILE, 1.0, 0.0, 0),
-                             LPGP_K_TRSM));
+        LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
@@ -517,9 +523,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
       for (int jt = p0; jt < p1; ++jt) {
         double* X = rows + (int64_t)jt * tb * ld;
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                             mk(X, ld, mat->linv + (int64_t)jt * tb * tb, tb, X, ld, mnew, 1, TILE, 1.0, 0.0, 0),
-                             LPGP_K_TRSM));
+        LPGP_TRY(panel_trsm(ctx, sP, X, ld, mat->linv + (int64_t)jt * tb * tb, mnew));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
@@ -563,8 +567,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
         LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
         if (jt + 1 < T) {
           double* X = dj + tb;
-          LPGP_TRY(launch_gemm(ctx, sP, 0, 0, mk(X, ld, linv, tb, X, ld, T - jt - 1, 1, TILE, 1.0, 0.0, 0),
-                               LPGP_K_TRSM));
+          LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
           if (jt + 1 < p1)
             LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                  mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
