@@ -700,6 +700,138 @@ int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, 
   return 0;
 }
 
+// =========================================================================================
+// Tile step of the forward substitution, IN PLACE:   V[0:128, cols] <- Linv * V[0:128, cols]
+// (Linv: 128 x 128 lower triangular tile inverse; V: 128 rows of a column-major block of
+// right-hand sides).  The latency twin of trsm_tile_kernel: a workgroup of eight waves owns 64
+// right-hand-side columns and all 128 rows (it reads exactly the region it overwrites), wave =
+// 64 x 16 slab (row half mh, column slab ns), Linv streamed as [k/2][2][128] stages, V as the
+// swizzled k-fastest image of gemm64.  Rows [0, 64) need only k < 64: the waves of the upper row
+// half skip the matrix work of stages 4-7, and the halves are dealt so that every SIMD holds one
+// wave of each.
+// =========================================================================================
+struct TrsvTileArgs {
+  double* V;                       // 128 x ncols, column-major, leading dimension ldv
+  int64_t ldv;
+  const double* linv;
+};
+
+__global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int b0 = wu & 1, b1 = (wu >> 1) & 1, b2 = wu >> 2;
+  const int mh = b2 ^ b0, ns = 2 * b1 + b0;               // rows [64 mh, 64 mh + 64), columns [16 ns, 16 ns + 16)
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
+  constexpr int KT = TILE / BK;
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  constexpr int TV_A = 8 * LDP2;                           // Linv stage: 16 k-rows of 128 row indices
+  constexpr int TV_B = 1024;                               // V stage: 64 columns x 16 k, swizzled K image
+  constexpr int TV_STAGE = TV_A + TV_B;
+
+  auto issue = [&](int kt) {
+    double* sa = smem + (size_t)(kt & (SSTAGES - 1)) * TV_STAGE;
+    double* sb = sa + TV_A;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                          // Linv: element (i, k) at linv[i + 128 k]
+      const int r = 2 * wu + h;
+      const char* ub = reinterpret_cast<const char*>(g.linv + ((int64_t)kt * BK + r) * TILE);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sa + wu * LDP2 + h * 128), 16, 0, 0);
+    }
+    {                                                      // V: 8 columns x 16 k per wave (dma_tile64<true>, q = wu)
+      const unsigned row8 = (unsigned)(lane >> 3);
+      const unsigned c = ((unsigned)lane & 7u) ^ ((((unsigned)wu << 2) + ((unsigned)lane >> 4)) & 7u);
+      const unsigned voff = (c * 2u + row8 * (unsigned)g.ldv) * 8u;
+      const char* ub = reinterpret_cast<const char*>(g.V + (int64_t)kt * BK + (col0 + (int64_t)wu * 8) * g.ldv);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sb + wu * 128), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int kt = 0; kt < SSTAGES - 1; ++kt) issue(kt);
+
+  const int j = lane >> 4;
+  const unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDP2 + (j >> 1) * 128 + 64 * mh + (lane & 15));
+  const unsigned laneNb = lds_base + 8u * (unsigned)(TV_A + frag64_lane_n<true>(lane, ns));
+
+  double acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);
+    if (mh == 0 && kt >= 4) continue;                      // Linv[i][k] = 0 for k > i (wave-uniform)
+    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * TV_STAGE) * 8u;
+    const unsigned aM = laneM + stoff, aN = laneNb + stoff;
+    double am[2][4], bn[2][4];
+    asm volatile("" ::: "memory");
+    static_for<0, 4>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      am[0][t] = lds_read_async<16 * t>(aM);
+    });
+    static_for<0, 4>([&](auto U_) {
+      constexpr int u = decltype(U_)::value;
+      bn[0][u] = lds_read_async<frag64_imm_n<true>(0, u)>(aN);
+    });
+    static_for<0, 4>([&](auto K_) {
+      constexpr int ks = decltype(K_)::value;
+      if constexpr (ks + 1 < 4) {
+        static_for<0, 4>([&](auto T_) {
+          constexpr int t = decltype(T_)::value;
+          am[(ks + 1) & 1][t] = lds_read_async<2 * (ks + 1) * LDP2 + 16 * t>(aM);
+        });
+        static_for<0, 4>([&](auto U_) {
+          constexpr int u = decltype(U_)::value;
+          bn[(ks + 1) & 1][u] = lds_read_async<frag64_imm_n<true>(ks + 1, u)>(aN);
+        });
+        LDS_WAIT(8);
+      } else {
+        LDS_WAIT(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[ks & 1][u], am[ks & 1][t], acc[t][u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  // in place: the 128 x 64 block was read by DMA only, all of it waited for before the barrier of
+  // stage 7, which every wave has passed here
+  char* const cub = reinterpret_cast<char*>(g.V + (col0 + 16 * ns) * g.ldv + 64 * mh);
+  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldv + (unsigned)(lane & 15)) * 8u;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldv + t * 16) * 8 + cvoff) = acc[t][u];
+}
+
+// V (128 rows x nt*128 columns, column-major ldv) <- linv * V in place
+int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel) {
+  if (nt <= 0) return 0;
+  const size_t shmem = (size_t)SSTAGES * (8 * LDP2 + 1024) * sizeof(double);       // 102 400 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  TrsvTileArgs a;
+  a.V = V; a.ldv = ldv; a.linv = linv;
+  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)nt * TILE * TILE * TILE, 0.0);
+  hipLaunchKernelGGL(trsv_tile_kernel, dim3((unsigned)(nt * 2)), dim3(512), shmem, stream, a);
+  if (prof_kernel >= 0) prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
 template <bool TA, bool TB, int TRI>
 static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   const size_t shmem = (size_t)SSTAGES * 2 * SOPER * sizeof(double);      // 73 728 B

@@ -211,6 +211,8 @@ struct GemmArgs {
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
 // X (mt*128 rows x 128, column-major ldx) <- X * linv^T in place, linv a 128 x 128 lower-triangular tile inverse
+// V (128 rows x nt*128 columns, column-major ldv) <- linv * V in place (tile step of the forward substitution)
+int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel);
 int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel);
 
 // potrf.hip -------------------------------------------------------------------------------

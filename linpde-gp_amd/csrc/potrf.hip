@@ -670,9 +670,12 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
     const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
     for (int jt = p0; jt < p1; ++jt) {
       double* Vj = v + (int64_t)jt * tb;
-      LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
-                           mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
-                           LPGP_K_TRSM));
+      if (ctx->trsm_slab)
+        LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)jt * tb * tb, mtl, LPGP_K_TRSM));
+      else
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
+                             mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
+                             LPGP_K_TRSM));
       if (jt + 1 < p1)
         LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                              mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, ldv,
