@@ -405,6 +405,12 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->test_own_rank = (int)(value % 1000);
   } else if (std::strcmp(key, "small_tiles_max") == 0) {
     ctx->small_tiles_max = (int)value;
+  } else if (std::strcmp(key, "chain_us_tile") == 0) {
+    ctx->chain_us_tile = (double)value;
+  } else if (std::strcmp(key, "solve_chain_us_tile") == 0) {
+    ctx->solve_chain_us_tile = (double)value;
+  } else if (std::strcmp(key, "chain_us_fixed") == 0) {
+    ctx->chain_us_fixed = (double)value;
   } else if (std::strcmp(key, "trsm_slab") == 0) {
     ctx->trsm_slab = (int)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {

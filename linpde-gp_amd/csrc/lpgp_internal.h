@@ -98,6 +98,10 @@ struct lpgp_ctx {
   int64_t nb_big = 0;              // optional wider panels while more than nb_big_min_tiles tile rows remain (0 = off; measured: no gain at c3)
   int nb_big_min_tiles = 96;
   int lookahead = 1;
+  // estimated duration of one tile step of the panel chain (factorisation / forward substitution) and of
+  // the per-panel rest, in microseconds: decides whether the remainder update is released with the panel
+  // (update-bound) or after the look-ahead half (chain-bound)
+  double chain_us_tile = 115.0, solve_chain_us_tile = 115.0, chain_us_fixed = 80.0;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int trsm_slab = 1;               // panel triangular solves by trsm_tile_kernel (0: one 128x128x128 tile per workgroup)
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)

@@ -408,7 +408,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     // chain: decides who bounds the pipeline from here on.
     const double rem = (double)(T - p2);
     const double t_b_us = 0.5 * rem * (rem + 1.0) * (2.0 * TILE * TILE * (double)K / 50e6);
-    const double t_chain_us = 115.0 * (double)(p2 - p1) + 80.0;
+    const double t_chain_us = ctx->chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
     const bool chain_bound = t_b_us < t_chain_us;
     // While the CHAIN bounds it, (b) starts only when (a) is COMPLETE: (a) is on the critical
     // path (the next panel waits for it), (b) is not, and launched together they share the chip by
@@ -697,7 +697,7 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
     // while the update does, (a) -- here only (p2-p1) x mtl tiles, too few to fill the chip alone
     // (measured: 62 us at 35 TFLOP/s per panel) -- runs underneath (b)
     const double t_b_us = (double)(T - p2) * mtl * (2.0 * TILE * TILE * (double)K / 50e6);
-    const bool chain_bound = t_b_us < 115.0 * (double)(p2 - p1) + 80.0;
+    const bool chain_bound = t_b_us < ctx->solve_chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
     hipEvent_t evp = ctx->ev_panel[it & 1];
     if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
