@@ -5,7 +5,14 @@ Host mirror of
   `linfunctls/_linfunctl.py:14-129`   LinearFunctional (+ `@` with a function operator)
   `linfunctls/_evaluation.py:10-64`   _EvaluationFunctional (output = codomain shape, then
                                       batch shape; scalar-valued priors only here)
-  `linfunctls/_arithmetic.py:92-174`  CompositeLinearFunctional
+  `linfunctls/_dirac.py:10-45`        DiracFunctional (output = batch shape, then codomain shape:
+                                      the same functional for the scalar-valued priors here)
+  `linfunctls/_arithmetic.py:13-174`  Scaled / Sum / CompositeLinearFunctional and the operators
+                                      `-L`, `a * L`, `L1 + L2`, `L1 - L2`, `L @ D`
+                                      (`_linfunctl.py:76-112`)
+Every functional of this path has the canonical form "point evaluation of `sum_a c_a d^a f` at
+X": scaling multiplies the coefficient map, a sum over the SAME points adds the maps (a sum
+over different point sets is not one observation block and raises NotImplementedError).
 Integrals, L2 projections and weak forms are out of scope.
 """
 
@@ -84,6 +91,27 @@ class LinearFunctional:
             return CompositeLinearFunctional(linfunctl=self, linfuncop=other)
         return NotImplemented
 
+    # -- arithmetic (`_linfunctl.py:76-98`) --
+    __array_ufunc__ = None
+
+    def __neg__(self):
+        return -1.0 * self
+
+    def __add__(self, other):
+        if isinstance(other, LinearFunctional):
+            return SumLinearFunctional(self, other)
+        return NotImplemented
+
+    def __sub__(self, other):
+        if isinstance(other, LinearFunctional):
+            return self + (-other)
+        return NotImplemented
+
+    def __rmul__(self, other):
+        if np.ndim(other) == 0:
+            return ScaledLinearFunctional(linfunctl=self, scalar=other)
+        return NotImplemented
+
 
 class _EvaluationFunctional(LinearFunctional):
     def __init__(self, input_domain_shape, input_codomain_shape, X):
@@ -128,6 +156,106 @@ class _EvaluationFunctional(LinearFunctional):
         return res
 
 
+class DiracFunctional(_EvaluationFunctional):
+    """Point evaluation with output layout batch shape + codomain shape (`_dirac.py:10-45`); for
+    scalar-valued functions (the only ones on this path) the same functional as
+    `_EvaluationFunctional`."""
+
+    def __init__(self, input_domain_shape, input_codomain_shape, X):
+        super().__init__(input_domain_shape, input_codomain_shape, X)
+        self._output_shape = self._X_batch_shape + self._input_codomain_shape
+
+    @property
+    def X_batch_ndim(self):
+        return len(self._X_batch_shape)
+
+    def _apply_to_function(self, f):
+        return np.asarray(f(self._X))
+
+
+class ScaledLinearFunctional(LinearFunctional):
+    """`scalar * linfunctl` (`_arithmetic.py:13-55`)."""
+
+    def __init__(self, linfunctl: LinearFunctional, scalar):
+        if np.ndim(scalar) != 0:
+            raise ValueError("`scalar` must be a scalar")
+        self._linfunctl = linfunctl
+        self._scalar = float(scalar)
+        super().__init__(input_shapes=linfunctl.input_shapes, output_shape=linfunctl.output_shape)
+
+    @property
+    def linfunctl(self):
+        return self._linfunctl
+
+    @property
+    def scalar(self):
+        return self._scalar
+
+    def points(self):
+        return self._linfunctl.points()
+
+    def device_points(self, ctx):
+        return self._linfunctl.device_points(ctx)
+
+    def coefficients_dict(self):
+        return {mi: self._scalar * c for mi, c in self._linfunctl.coefficients_dict().items()}
+
+    def _apply_to_function(self, f):
+        return self._scalar * self._linfunctl(f)
+
+    def __rmul__(self, other):
+        if np.ndim(other) == 0:
+            return ScaledLinearFunctional(linfunctl=self._linfunctl, scalar=float(other) * self._scalar)
+        return NotImplemented
+
+
+class SumLinearFunctional(LinearFunctional):
+    """`L1 + L2 + ...` (`_arithmetic.py:58-89`).  On the MI355X path the summands must evaluate at
+    the same points (e.g. a Robin condition `a * Id + b * d/dn` on one boundary grid)."""
+
+    def __init__(self, *summands: LinearFunctional):
+        if len(summands) < 1:
+            raise ValueError("at least one summand is required")
+        s0 = summands[0]
+        if not all(s.input_shapes == s0.input_shapes for s in summands):
+            raise ValueError("all summands must have the same input shapes")
+        if not all(s.output_shape == s0.output_shape for s in summands):
+            raise ValueError("all summands must have the same output shape")
+        self._summands = tuple(summands)
+        super().__init__(input_shapes=s0.input_shapes, output_shape=s0.output_shape)
+
+    @property
+    def summands(self):
+        return self._summands
+
+    def points(self):
+        P = self._summands[0].points()
+        for s in self._summands[1:]:
+            Q = s.points()
+            if Q.shape != P.shape or not np.array_equal(P, Q):
+                raise NotImplementedError(
+                    "a sum of functionals over different point sets is not one observation block; "
+                    "condition on the summands' blocks separately")
+        return P
+
+    def device_points(self, ctx):
+        self.points()
+        return self._summands[0].device_points(ctx)
+
+    def coefficients_dict(self):
+        out: dict = {}
+        for s in self._summands:
+            for mi, c in s.coefficients_dict().items():
+                out[mi] = out.get(mi, 0.0) + c
+        return out
+
+    def _apply_to_function(self, f):
+        res = self._summands[0](f)
+        for s in self._summands[1:]:
+            res = res + s(f)
+        return res
+
+
 class CompositeLinearFunctional(LinearFunctional):
     """`linfunctl @ linfuncop` -- here: point evaluation of `linfuncop[f]`."""
 
@@ -166,4 +294,5 @@ class CompositeLinearFunctional(LinearFunctional):
         return self._linfunctl(self._linfuncop(f))
 
 
-__all__ = ["LinearFunctional", "_EvaluationFunctional", "CompositeLinearFunctional"]
+__all__ = ["LinearFunctional", "_EvaluationFunctional", "DiracFunctional", "ScaledLinearFunctional",
+           "SumLinearFunctional", "CompositeLinearFunctional"]

@@ -134,3 +134,40 @@ def test_iso_posterior_with_neumann_blocks(lp):
     assert np.max(np.abs(mean - post.mean(Xp))) / np.max(np.abs(post.mean(Xp))) < 1e-8
     assert np.max(np.abs(var - post.var(Xp))) / np.max(np.abs(post.var(Xp))) < 1e-8
     assert np.max(np.abs(mean - f(Xp))) < 5e-2           # and it does regress the function
+
+
+def test_robin_and_dirac_functionals(lp):
+    """Conditioning through functional arithmetic: a Robin condition `2 u - 0.5 du/dy` on one edge as
+    `2 * Ev + 0.5 * (Ev @ DirectionalDerivative)` (SumLinearFunctional over one point set), values
+    through a `DiracFunctional`, a scaled functional -- against the oracle's dense conditioning with the
+    same coefficient maps; isotropic Matérn and tensor-product priors."""
+    from linpde_gp_amd.linfuncops import diffops
+    cf, lf = lp.randprocs.covfuncs, lp.linfunctls
+    rng = np.random.default_rng(3)
+    Xv = rng.uniform(0, 1, size=(140, 2))
+    e = np.linspace(0.03, 0.97, 70)
+    Xe = np.column_stack([e, np.zeros_like(e)])
+    f = lambda X: np.cos(1.3 * X[:, 0]) * np.exp(-0.7 * X[:, 1])
+    dfdy = lambda X: -0.7 * f(X)
+    yr = 2.0 * f(Xe) + 0.5 * (-dfdy(Xe))                 # outward normal (0, -1)
+    robin_coeffs = {(0, 0): 2.0, (0, 1): -0.5}
+    priors = [
+        (1.2 * cf.Matern((2,), nu=2.5, lengthscales=0.8), [(1.2, [("matern_iso", 2.5, np.full(2, 0.8))])]),
+        (1.2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=0.8), cf.Matern((), nu=3.5, lengthscales=1.1)),
+         [(1.2, [("matern", 2.5, 0.8), ("matern", 3.5, 1.1)])]),
+    ]
+    g = np.linspace(0.1, 0.9, 9)
+    Xp = np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)
+    for k, okern in priors:
+        prior = lp.GaussianProcess(lp.functions.Zero((2,)), k)
+        ev = lf._EvaluationFunctional((2,), (), Xe)
+        robin = 2.0 * ev + 0.5 * (ev @ diffops.DirectionalDerivative(np.array([0.0, -1.0])))
+        u = prior.condition_on_observations(-3.0 * f(Xv), L=-3.0 * lf.DiracFunctional((2,), (), Xv),
+                                            b=lp.randvars.Normal(np.zeros(140), 1e-6 * np.eye(140)))
+        u = u.condition_on_observations(yr, L=robin, b=lp.randvars.Normal(np.zeros(70), 1e-6 * np.eye(70)))
+        blocks = [ogp.ObsBlock(Xv, {(0, 0): -3.0}, -3.0 * f(Xv), 0.0, 1e-6), ogp.ObsBlock(Xe, robin_coeffs, yr, 0.0, 1e-6)]
+        post = ogp.condition(okern, blocks)
+        mean, var = u.predict(Xp)
+        assert np.max(np.abs(mean - post.mean(Xp))) / np.max(np.abs(post.mean(Xp))) < 1e-8
+        assert np.max(np.abs(var - post.var(Xp))) / np.max(np.abs(post.var(Xp))) < 1e-8
+        assert np.max(np.abs(mean - f(Xp))) < 5e-2

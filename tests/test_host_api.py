@@ -187,3 +187,31 @@ def test_domains_and_problem_builders():
     assert h.initial_domain.uniform_grid(5).shape == (1, 5, 2)
     x = np.linspace(-1, 1, 7)
     np.testing.assert_allclose(h.solution(np.stack([np.zeros(7), x], -1)), h.initial_condition.values(x), atol=1e-14)
+
+
+def test_functional_arithmetic():
+    """`-L`, `a * L`, `L1 + L2`, `L1 - L2`, `L @ D`, DiracFunctional (`linfunctls/_linfunctl.py:76-112`,
+    `_arithmetic.py:13-174`, `_dirac.py:10-45`): everything lowers to one coefficient map over one point set."""
+    lf = lp.linfunctls
+    X = np.linspace(0.0, 1.0, 12).reshape(6, 2)
+    ev = lf._EvaluationFunctional((2,), (), X)
+    dn = ev @ diffops.DirectionalDerivative(np.array([0.0, -1.0]))
+    robin = 2.0 * ev + 0.5 * dn
+    assert isinstance(robin, lf.SumLinearFunctional) and robin.output_shape == (6,)
+    assert robin.coefficients_dict() == {(0, 0): 2.0, (0, 1): -0.5}
+    assert np.array_equal(robin.points(), X)
+    assert (-ev).coefficients_dict() == {(0, 0): -1.0}
+    assert (3.0 * (2.0 * ev)).scalar == 6.0
+    assert (ev - dn).coefficients_dict() == {(0, 0): 1.0, (0, 1): 1.0}
+    dirac = lf.DiracFunctional((2,), (), X)
+    assert dirac.output_shape == (6,) and dirac.X_batch_ndim == 1 and dirac.coefficients_dict() == {(0, 0): 1.0}
+    f = lp.functions.Constant((2,), 3.0)
+    assert np.array_equal(robin(f), np.full(6, 6.0)) and np.array_equal(dirac(f), np.full(6, 3.0))
+    with pytest.raises(NotImplementedError):          # different point sets: not one observation block
+        (ev + lf._EvaluationFunctional((2,), (), X + 1.0)).points()
+    with pytest.raises(ValueError):
+        lf.SumLinearFunctional(ev, lf._EvaluationFunctional((1,), (), X[:, :1]))
+    with pytest.raises(ValueError):
+        lf.ScaledLinearFunctional(ev, np.ones(2))
+    with pytest.raises(TypeError):
+        np.ones(3) * ev
