@@ -321,6 +321,18 @@ int lpgp_init(int device, lpgp_ctx** out) {
   //  with 8 CUs removed (tile-count quantisation on 496 instead of 512 slots), 44.3 with 64
   //  removed; LPGP_TEST_GEMM_STREAM + scratch/gemm_sweep.py.  Only the factorisation needs it.)
   LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd_all, hipStreamNonBlocking, lo));
+  masked_stream(reserve, &ctx->s_outer);
+  if (!ctx->s_outer) LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_outer, hipStreamNonBlocking, lo));
+  if (const char* e = std::getenv("LPGP_NB_OUTER")) {
+    long v = std::atol(e);
+    if (v >= 0 && v % TILE == 0) ctx->nb_outer = v;
+  }
+  if (const char* e = std::getenv("LPGP_NB_OUTER_MIN_TILES")) ctx->nb_outer_min_tiles = std::atoi(e);
+  for (int i = 0; i < 2; ++i) {
+    LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer[i], hipEventDisableTiming));
+    LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_fact[i], hipEventDisableTiming));
+    LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_a1[i], hipEventDisableTiming));
+  }
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
@@ -359,6 +371,9 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
+    (void)hipEventDestroy(ctx->ev_outer[i]);
+    (void)hipEventDestroy(ctx->ev_outer_fact[i]);
+    (void)hipEventDestroy(ctx->ev_outer_a1[i]);
   }
   for (auto& sl : ctx->desc_ring) {
     (void)hipHostFree(sl.h);
@@ -375,6 +390,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipStreamDestroy(ctx->s_upd);
   if (ctx->s_upd_narrow) (void)hipStreamDestroy(ctx->s_upd_narrow);
   (void)hipStreamDestroy(ctx->s_upd_all);
+  if (ctx->s_outer) (void)hipStreamDestroy(ctx->s_outer);
   delete ctx;
   return 0;
 }
@@ -417,6 +433,11 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
+  } else if (std::strcmp(key, "nb_outer") == 0) {
+    LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer must be a multiple of %d (0 disables)", TILE);
+    ctx->nb_outer = value;
+  } else if (std::strcmp(key, "nb_outer_min_tiles") == 0) {
+    ctx->nb_outer_min_tiles = (int)value;
   } else if (std::strcmp(key, "nb_big") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_big must be a multiple of %d (0 disables)", TILE);
     ctx->nb_big = value;

@@ -91,6 +91,12 @@ struct lpgp_ctx {
   hipStream_t s_upd = nullptr;     // trailing-update stream (all CUs but `reserve`, default 8)
   hipStream_t s_upd_narrow = nullptr;  // same with `reserve_narrow` CUs (default 64) left to the panel chain
   hipStream_t s_upd_all = nullptr;     // unmasked update stream: the blocked solves have no whole-CU kernel to protect
+  hipStream_t s_outer = nullptr;       // rank-nb_outer updates (a1), (b) of the factorisation (masked like s_upd)
+  hipEvent_t ev_outer[2] = {nullptr, nullptr};
+  hipEvent_t ev_outer_fact[2] = {nullptr, nullptr};
+  hipEvent_t ev_outer_a1[2] = {nullptr, nullptr};
+  int64_t nb_outer = 2048;             // far columns are updated once per nb_outer columns (0 or <= nb: every panel) ...
+  int nb_outer_min_tiles = 192;        // ... while more than this many tile columns remain
   int reserve_narrow = 64;
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};

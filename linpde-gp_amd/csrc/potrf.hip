@@ -323,6 +323,112 @@ static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, double* X, int64_t l
     if (_rc != 0) return _rc;     \
   } while (0)
 
+// Factor tile columns [c0, cl) (all rows down to T) right-looking by panels of nb columns with a
+// look-ahead of one panel; the rank-nb updates touch only columns < cl (cl == T: the whole trailing
+// matrix).  `dep`: event behind the last write to columns [c0 + nb, cl) by an earlier launch on
+// another stream (null: none); the first panel chain does not wait for it, the first update does.
+// On return the panel stream is behind every update of the call.
+static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, hipStream_t sU, hipEvent_t dep) {
+  const int64_t ld = mat->cap;
+  double* a = mat->a;
+  const int nbt = (int)(ctx->nb / TILE);
+  const int64_t tb = TILE;
+  hipStream_t sP = ctx->s_main;
+  bool dep_pending_p = dep != nullptr, dep_pending_u = dep != nullptr;
+  // Panel width schedule: while the trailing matrix is large the pipeline is bound by the
+  // SYRK update, whose efficiency grows with K (46 TFLOP/s at K = 512, ~52 at K = 1024, in
+  // situ), and the longer panel chain hides behind it; once the update gets short the
+  // pipeline is bound by the panel chain and the narrow panel wins.
+  const bool la = ctx->lookahead != 0;
+  auto width_at = [&](int p0) {
+    const int rem = T - p0;
+    return (ctx->nb_big > ctx->nb && rem > ctx->nb_big_min_tiles) ? (int)(ctx->nb_big / TILE) : nbt;
+  };
+  int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
+  hipEvent_t last_upd = nullptr;
+  int it = 0;
+  for (int p0 = c0; p0 < cl; ++it) {
+    const int w0 = width_at(p0);
+    const int p1 = (p0 + w0 < cl) ? p0 + w0 : cl;
+    // panel factorisation on sP
+    for (int jt = p0; jt < p1; ++jt) {
+      double* dj = a + (int64_t)jt * tb * (ld + 1);
+      double* linv = mat->linv + (int64_t)jt * tb * tb;
+      LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
+      if (jt + 1 < T) {
+        double* X = dj + tb;     // rows below, same tile column
+        LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
+        if (jt + 1 < p1)
+          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                               mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
+                                  p1 - jt - 1, TILE, -1.0, 1.0, 2),
+                               LPGP_K_SYRK_PANEL));
+      }
+    }
+    if (p1 >= cl) break;
+    const int K = (p1 - p0) * TILE;
+    const double* P = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;      // panel rows below
+    if (dep_pending_p) {
+      LPGP_HIP(hipStreamWaitEvent(sP, dep, 0));
+      dep_pending_p = false;
+    }
+    if (!la) {
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, cl - p1, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+      p0 = p1;
+      continue;
+    }
+    const int w1 = width_at(p1);
+    const int p2 = (p1 + w1 < cl) ? p1 + w1 : cl;
+    // Estimated duration of the remainder update (b) at 50 TFLOP/s against that of the next panel
+    // chain: decides who bounds the pipeline from here on.
+    const double remc = (double)(cl - p2), remr = (double)(T - p2);          // (b): remr x remc lower trapezoid
+    const double t_b_us = (remr * remc - 0.5 * remc * (remc - 1.0)) * (2.0 * TILE * TILE * (double)K / 50e6);
+    const double t_chain_us = ctx->chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
+    const bool chain_bound = t_b_us < t_chain_us;
+    // While the CHAIN bounds it, (b) starts only when (a) is COMPLETE: (a) is on the critical
+    // path (the next panel waits for it), (b) is not, and launched together they share the chip by
+    // workgroup count -- measured at panel 20 of c3: (a) took 229 us next to (b) instead of
+    // ~70 us alone.  While the UPDATE bounds it, (b) is released with the panel and (a) runs
+    // underneath it (alone it would leave part of the chip idle).
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    // (a) next panel's columns on sP; they were last written by the previous remainder update
+    if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
+    LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 3),
+                         LPGP_K_SYRK_AHEAD));
+    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    // (b) remainder on an update stream.  Once its estimated duration even on the narrow stream
+    // (which leaves a quarter of the CUs to the panel chain) is below that of the chain, it moves
+    // there.
+    if (p2 < cl) {
+      const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
+      hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
+      if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
+      if (dep_pending_u) {
+        LPGP_HIP(hipStreamWaitEvent(sB, dep, 0));
+        dep_pending_u = false;
+      }
+      const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
+      LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
+      LPGP_TRY(launch_gemm(ctx, sB, 0, 0,
+                           mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, cl - p2, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
+      have_upd_event = 1;
+      last_upd = ctx->ev_upd[it & 1];
+    } else {
+      have_upd_event = 0;
+    }
+    p0 = p1;
+  }
+  // join: sP must not run ahead of the last remainder update
+  if (la && last_upd) LPGP_HIP(hipStreamWaitEvent(sP, last_upd, 0));
+  return 0;
+}
+
 // Factor tile columns [t_done, T) of the padded matrix; columns [0, t_done) already hold L.
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
   const int T = (int)T64, t_done = (int)t_done64;
@@ -361,90 +467,68 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     }
   }
 
-  // ---- phase B: right-looking with look-ahead ----
-  // Panel width schedule: while the trailing matrix is large the pipeline is bound by the
-  // SYRK update, whose efficiency grows with K (46 TFLOP/s at K = 512, ~52 at K = 1024, in
-  // situ), and the longer panel chain hides behind it; once the update gets short the
-  // pipeline is bound by the panel chain and the narrow panel wins.
+  // ---- phase B: right-looking with look-ahead; on LARGE matrices the far columns are updated once
+  //      per nb_outer columns ----
+  // A trailing update costs more than its flops when K is short: every C tile is read and written
+  // once per launch (traffic that also pulls the core clock down: 1.83-1.94 GHz inside a K = 512
+  // launch against 2.12 GHz at K = 2048, in-kernel s_memtime / s_memrealtime) and while a workgroup
+  // loads C its CU has a single workgroup in the k-loop (27 % of the time at K = 512, 11 % at 2048;
+  // scratch/timeline.hip): the same output runs at 51-53 TFLOP/s with K = 512, 58 with K = 1024, 62
+  // with K = 2048.  Longer-K workgroups hold their CU slots longer, which slows every kernel of the
+  // panel chain next to them; at c3 sizes that costs more than the update gains,
+  // so the schedule below is used only while more than nb_outer_min_tiles tile columns remain.
+  // Then nb_outer / nb consecutive panels form an OUTER panel: inside it the rank-nb updates touch
+  // only the outer panel's own columns, and everything to the right is updated once per outer panel
+  // with K = nb_outer, in three pieces:
+  //   (a0) the first inner panel of the next outer panel, on the panel stream (critical path);
+  //   (a1) the rest of the next outer panel, on the outer update stream: it runs underneath the
+  //        first chain of the next outer panel and is awaited by that panel's first inner update;
+  //   (b)  all columns beyond, behind (a1) on the same stream.
+  const int NBt = (int)(ctx->nb_outer / TILE);
   const bool la = ctx->lookahead != 0;
-  auto width_at = [&](int p0) {
-    const int rem = T - p0;
-    return (ctx->nb_big > ctx->nb && rem > ctx->nb_big_min_tiles) ? (int)(ctx->nb_big / TILE) : nbt;
-  };
-  int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
-  hipEvent_t last_upd = nullptr;
-  int it = 0;
-  for (int p0 = t_done; p0 < T; ++it) {
-    const int w0 = width_at(p0);
-    const int p1 = (p0 + w0 < T) ? p0 + w0 : T;
-    // panel factorisation on sP
-    for (int jt = p0; jt < p1; ++jt) {
-      double* dj = a + (int64_t)jt * tb * (ld + 1);
-      double* linv = mat->linv + (int64_t)jt * tb * tb;
-      LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
-      if (jt + 1 < T) {
-        double* X = dj + tb;     // rows below, same tile column
-        LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
-        if (jt + 1 < p1)
-          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                               mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
-                                  p1 - jt - 1, TILE, -1.0, 1.0, 2),
-                               LPGP_K_SYRK_PANEL));
-      }
-    }
-    if (p1 >= T) break;
-    const int K = (p1 - p0) * TILE;
-    const double* P = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;      // panel rows below
-    if (!la) {
-      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, T - p1, K, -1.0, 1.0, 1),
-                           LPGP_K_SYRK));
-      p0 = p1;
-      continue;
-    }
-    const int w1 = width_at(p1);
-    const int p2 = (p1 + w1 < T) ? p1 + w1 : T;
-    // Estimated duration of the remainder update (b) at 50 TFLOP/s against that of the next panel
-    // chain: decides who bounds the pipeline from here on.
-    const double rem = (double)(T - p2);
-    const double t_b_us = 0.5 * rem * (rem + 1.0) * (2.0 * TILE * TILE * (double)K / 50e6);
-    const double t_chain_us = ctx->chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
-    const bool chain_bound = t_b_us < t_chain_us;
-    // While the CHAIN bounds it, (b) starts only when (a) is COMPLETE: (a) is on the critical
-    // path (the next panel waits for it), (b) is not, and launched together they share the chip by
-    // workgroup count -- measured at panel 20 of c3: (a) took 229 us next to (b) instead of
-    // ~70 us alone.  While the UPDATE bounds it, (b) is released with the panel and (a) runs
-    // underneath it (alone it would leave part of the chip idle).
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
-    // (a) next panel's columns on sP; they were last written by the previous remainder update
-    if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
+  hipStream_t sO = ctx->s_outer ? ctx->s_outer : sU;
+  hipEvent_t ev_a1 = nullptr, ev_b = nullptr;
+  int oit = 0;
+  for (int q0 = t_done; q0 < T; ++oit) {
+    const bool outer = la && NBt > nbt && (T - q0) > ctx->nb_outer_min_tiles && (T - q0) > NBt;
+    const int q1 = outer ? q0 + NBt : T;
+    LPGP_TRY(factor_columns(ctx, mat, T, q0, q1, sU, ev_a1));
+    if (q1 >= T) break;
+    hipEvent_t ev_fact = ctx->ev_outer_fact[oit & 1];
+    LPGP_HIP(hipEventRecord(ev_fact, sP));             // outer panel [q0, q1) is final (factor_columns joins its updates into sP)
+    const int K = (q1 - q0) * TILE;
+    const bool next_outer = (T - q1) > ctx->nb_outer_min_tiles && (T - q1) > NBt;
+    const int q2 = next_outer ? q1 + NBt : T;
+    const int qa = (q1 + nbt < q2) ? q1 + nbt : q2;    // end of the next outer panel's first inner panel
+    // (a0) on the panel stream; its columns were last written by the previous (b)
+    if (ev_b) LPGP_HIP(hipStreamWaitEvent(sP, ev_b, 0));
+    const double* P = a + (int64_t)q1 * tb + (int64_t)q0 * tb * ld;
     LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 3),
+                         mk(P, ld, P, ld, a + (int64_t)q1 * tb * (ld + 1), ld, T - q1, qa - q1, K, -1.0, 1.0, 3),
                          LPGP_K_SYRK_AHEAD));
-    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
-    // (b) remainder on an update stream.  Once its estimated duration even on the narrow stream
-    // (which leaves a quarter of the CUs to the panel chain) is below that of the chain, it moves
-    // there.
-    if (p2 < T) {
-      const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
-      hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
-      if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
-      const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
-      LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
-      LPGP_TRY(launch_gemm(ctx, sB, 0, 0,
-                           mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1),
+    LPGP_HIP(hipStreamWaitEvent(sO, ev_fact, 0));
+    ev_a1 = nullptr;
+    if (qa < q2) {                                     // (a1): columns [qa, q2), rows [qa, T)
+      const double* Pa = a + (int64_t)qa * tb + (int64_t)q0 * tb * ld;
+      LPGP_TRY(launch_gemm(ctx, sO, 0, 0,
+                           mk(Pa, ld, Pa, ld, a + (int64_t)qa * tb * (ld + 1), ld, T - qa, q2 - qa, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
-      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
-      have_upd_event = 1;
-      last_upd = ctx->ev_upd[it & 1];
-    } else {
-      have_upd_event = 0;
+      ev_a1 = ctx->ev_outer_a1[oit & 1];
+      LPGP_HIP(hipEventRecord(ev_a1, sO));
     }
-    p0 = p1;
+    ev_b = nullptr;
+    if (q2 < T) {                                      // (b): columns [q2, T)
+      const double* Pb = a + (int64_t)q2 * tb + (int64_t)q0 * tb * ld;
+      LPGP_TRY(launch_gemm(ctx, sO, 0, 0,
+                           mk(Pb, ld, Pb, ld, a + (int64_t)q2 * tb * (ld + 1), ld, T - q2, T - q2, K, -1.0, 1.0, 1),
+                           LPGP_K_SYRK));
+      ev_b = ctx->ev_outer[oit & 1];
+      LPGP_HIP(hipEventRecord(ev_b, sO));
+    }
+    q0 = q1;
   }
-  // join: sP must not run ahead of the last remainder update
-  if (la && last_upd) LPGP_HIP(hipStreamWaitEvent(sP, last_upd, 0));
+  if (ev_a1) LPGP_HIP(hipStreamWaitEvent(sP, ev_a1, 0));
+  if (ev_b) LPGP_HIP(hipStreamWaitEvent(sP, ev_b, 0));
   int h_info = 0;
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
