@@ -452,3 +452,34 @@ def test_api_errors(lp):
     L = diffops.Laplacian((1,)).to_linfunctl(np.zeros((3, 1)))
     with pytest.raises(TypeError):
         prior.condition_on_observations(np.zeros(3), np.zeros((3, 1)), L=L)   # functional + X
+
+
+def test_outer_update_schedule_matches_single_level(lp):
+    """The large-matrix schedule of the factorisation (far columns updated once per nb_outer columns,
+    pieces (a0) / (a1) / (b); on by default only beyond 24 576 rows) forced onto a small problem:
+    same posterior as the single-level schedule and as the oracle, block append included."""
+    from linpde_gp_amd import _engine
+    cf = lp.randprocs.covfuncs
+    ctx = _engine.default_context()
+    blocks = _poisson_blocks(nb=40, npde=50)       # 160 + 2500 observations: 22 tile rows
+    okern = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 1.0)])]
+    prior = lp.GaussianProcess(
+        lp.functions.Zero((2,)),
+        2.0**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=1.0)))
+    t = np.linspace(-1 + 1 / 16, 1 - 1 / 16, 16)
+    Xt = np.stack(np.meshgrid(t, t, indexing="ij"), axis=-1).reshape(-1, 2)
+    post = ogp.condition(okern, blocks)
+    res = {}
+    try:
+        for name, nbo, mn in [("single", 0, 1 << 20), ("outer1024", 1024, 2), ("outer1536", 1536, 5)]:
+            ctx.set_option("nb_outer", nbo)
+            ctx.set_option("nb_outer_min_tiles", mn)
+            u = _condition_host(lp, prior, blocks)
+            res[name] = u.predict(Xt)
+    finally:
+        ctx.set_option("nb_outer", 2048)
+        ctx.set_option("nb_outer_min_tiles", 192)
+    for name, (mean, var) in res.items():
+        assert _rel(mean, post.mean(Xt)) < 1e-8, name
+        assert np.max(np.abs(var - post.var(Xt))) / np.max(np.abs(post.var(Xt))) < 1e-8, name
+    assert _rel(res["outer1024"][0], res["single"][0]) < 1e-10
