@@ -141,6 +141,10 @@ class ConditionalGaussianProcess(GaussianProcess):
 
     @classmethod
     def _extend(cls, prior, state, old_blocks, new_block):
+        if new_block.points.n == 0:
+            # no observations: nothing to assemble or factor, the factor in HBM stays as it is (and
+            # stays valid for the object this one was derived from)
+            return cls(prior=prior, blocks=tuple(old_blocks), state=state, representer_weights=None)
         mat = state.mat
         base = prior.cov
         bi = mat.add_block(new_block.points.n)
@@ -217,9 +221,14 @@ class ConditionalGaussianProcess(GaussianProcess):
         return self._representer_weights
 
     def _residual(self) -> np.ndarray:
+        if not self._blocks:
+            return np.zeros(0)
         return np.concatenate([ob.Y - ob.pred_mean for ob in self._blocks])
 
     def _ensure_weights(self):
+        if not self._blocks:
+            self._representer_weights = np.zeros(0)
+            return
         if self._representer_weights is None:
             self._check_current()
             self._representer_weights = self._state.mat.solve_weights(self._residual())
@@ -337,6 +346,12 @@ class ConditionalGaussianProcess(GaussianProcess):
         self._check_current()
         X, batch = self._flat(x)
         ctx = self._state.ctx
+        if X.shape[0] == 0 or not self._blocks:
+            # nothing to predict, or nothing observed yet: the prior (`x1 is None` diagonal)
+            mean = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0]).reshape(batch)
+            if not return_var:
+                return mean
+            return mean, np.full(batch, self._prior_diag() if X.shape[0] else 0.0)
         if ctx.world > 1 and X.shape[0] >= ctx.world:
             bounds = np.linspace(0, X.shape[0], ctx.world + 1).astype(int)
             lo, hi = bounds[ctx.rank], bounds[ctx.rank + 1]
@@ -408,19 +423,25 @@ class _PosteriorCovarianceFunction(covfuncs.CovarianceFunction):
         base = cgp._prior.cov
         kxx_f = covfuncs.DifferentiatedCovarianceFunction(
             covfuncs._base(base), *_combine(base, cgp._test_coeffs, cgp._test_coeffs))
-        P0 = _engine.Points(ctx, X0)
-        V0 = cgp._cross(P0)
-        V0.trsm_lower()
-        if x1 is None:
-            P1, V1 = P0, V0
-        else:
+        X1 = X0
+        if x1 is not None:
             X1, b1 = cgp._flat(x1)
             if len(b1) != 1:
                 raise ValueError("`matrix` needs inputs of shape (N,) + input_shape")
-            P1 = _engine.Points(ctx, X1)
+        if X0.shape[0] == 0 or X1.shape[0] == 0:
+            return np.zeros((X0.shape[0], X1.shape[0]))
+        P0 = _engine.Points(ctx, X0)
+        P1 = P0 if x1 is None else _engine.Points(ctx, X1)
+        k_xx = _engine.kernel_matrix(ctx, kxx_f.lower(), P0, P1)
+        if not cgp._blocks:                       # nothing observed yet: the prior covariance
+            return k_xx
+        V0 = cgp._cross(P0)
+        V0.trsm_lower()
+        if x1 is None:
+            V1 = V0
+        else:
             V1 = cgp._cross(P1)
             V1.trsm_lower()
-        k_xx = _engine.kernel_matrix(ctx, kxx_f.lower(), P0, P1)
         return k_xx - V0.inner(V1)
 
     def __call__(self, x0, x1=None):

@@ -483,3 +483,35 @@ def test_outer_update_schedule_matches_single_level(lp):
         assert _rel(mean, post.mean(Xt)) < 1e-8, name
         assert np.max(np.abs(var - post.var(Xt))) / np.max(np.abs(post.var(Xt))) < 1e-8, name
     assert _rel(res["outer1024"][0], res["single"][0]) < 1e-10
+
+
+def test_empty_observation_and_prediction_sets(lp):
+    """Empty inputs behave like the NumPy reference's: conditioning on zero observations leaves the
+    process unchanged (prior, or the posterior it extends), predicting at zero points returns empty
+    arrays, and the posterior covariance of empty point sets is an empty matrix."""
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(0)
+    prior = lp.GaussianProcess(lp.functions.Constant((2,), 0.3),
+                               1.7 * cf.TensorProduct(cf.Matern((), nu=2.5), cf.Matern((), nu=2.5)))
+    X, Y = rng.uniform(-1, 1, (5, 2)), rng.standard_normal(5)
+    Xt = rng.uniform(-1, 1, (7, 2))
+    e = prior.condition_on_observations(np.zeros(0), X=np.zeros((0, 2)))
+    m, v = e.predict(Xt)
+    np.testing.assert_allclose(m, 0.3)
+    np.testing.assert_allclose(v, 1.7)
+    assert e.representer_weights.shape == (0,)
+    np.testing.assert_allclose(e.cov.matrix(Xt), prior.cov.matrix(Xt), rtol=1e-14)
+    u = prior.condition_on_observations(Y, X=X)
+    m0, v0 = u.predict(Xt)
+    u2 = u.condition_on_observations(np.zeros(0), X=np.zeros((0, 2)))
+    m2, v2 = u2.predict(Xt)
+    assert np.array_equal(m0, m2) and np.array_equal(v0, v2)
+    # the empty posterior can still be extended
+    u3 = e.condition_on_observations(Y, X=X)
+    np.testing.assert_allclose(u3.predict(Xt)[0], m0, rtol=1e-12)
+    me, ve = u.predict(np.zeros((0, 2)))
+    assert me.shape == (0,) and ve.shape == (0,)
+    assert u.mean(np.zeros((0, 2))).shape == (0,)
+    assert u.cov.matrix(np.zeros((0, 2))).shape == (0, 0)
+    assert u.cov.matrix(Xt, np.zeros((0, 2))).shape == (7, 0)
+    assert prior.cov.matrix(np.zeros((0, 2)), X[:3]).shape == (0, 3)
