@@ -785,8 +785,28 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
     return -1;
   }
   r->v = (double*)pv;
-  LPGP_HIP(hipMemsetAsync(r->v, 0, (size_t)r->ld * r->m_pad * sizeof(double), ctx->s_main));
+  // lpgp_cross_assemble writes every logical row of every logical column: only the spare columns and
+  // the rows of the blocks' padding tails have to be cleared (c3: 17 MB instead of 571 MB per prediction)
+  LPGP_HIP(hipMemsetAsync(r->v + (size_t)r->ld * m, 0, (size_t)r->ld * (r->m_pad - m) * sizeof(double), ctx->s_main));
+  for (const auto& b : mat->blocks)
+    if (b.pn > b.n)
+      LPGP_HIP(hipMemset2DAsync(r->v + b.poff + b.n, (size_t)r->ld * sizeof(double), 0, (size_t)(b.pn - b.n) * sizeof(double),
+                                (size_t)m, ctx->s_main));
+  r->assembled.assign(mat->blocks.size(), 0);
   *out = r;
+  return 0;
+}
+
+// rows of observation blocks that were never assembled count as zero cross-covariance
+static int rhs_clear_unassembled(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* r) {
+  for (size_t bi = 0; bi < r->assembled.size() && bi < mat->blocks.size(); ++bi) {
+    if (r->assembled[bi]) continue;
+    const lpgp_block& b = mat->blocks[bi];
+    if (b.n > 0)
+      LPGP_HIP(hipMemset2DAsync(r->v + b.poff, (size_t)r->ld * sizeof(double), 0, (size_t)b.n * sizeof(double), (size_t)r->m,
+                                ctx->s_main));
+    r->assembled[bi] = 1;
+  }
   return 0;
 }
 
@@ -810,13 +830,16 @@ int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, co
   if (rc != 0) return rc;
   rc = launch_assemble(ctx, ctx->s_main, desc, X_obs->x, X_obs->n, X_obs->n_pad, X_test->x, X_test->n,
                        X_test->n_pad, rhs->v, rhs->ld, B.poff, 0, 0);
+  if (rc == 0 && bi < (int)rhs->assembled.size()) rhs->assembled[bi] = 1;
   return rc;       // asynchronous (see lpgp_gram_assemble)
 }
 
 int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   LPGP_CHECK(ctx && mat && V, "lpgp_trsm_lower: null argument");
   LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
-  int rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
+  int rc = rhs_clear_unassembled(ctx, mat, V);
+  if (rc != 0) return rc;
+  rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
   if (rc != 0) return rc;
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   return 0;
@@ -828,6 +851,8 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
   LPGP_CHECK(mat->pn_fact == mat->pn && K->ld == mat->pn, "lpgp_predict: matrix not factored or size mismatch");
   const int64_t m = K->m;
   int rc = ensure_tmp(ctx, 2 * K->m_pad);
+  if (rc != 0) return rc;
+  rc = rhs_clear_unassembled(ctx, mat, K);
   if (rc != 0) return rc;
   std::vector<double> h((size_t)m), h2;
   // Mean and variance together: the variance needs V = L^{-1} K_Xx anyway, and
@@ -901,6 +926,10 @@ int lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* 
   LPGP_CHECK(ctx && mat && rhs && out_host, "lpgp_rhs_to_host: null argument");
   LPGP_CHECK(rhs->ld == mat->pn, "lpgp_rhs_to_host: size mismatch");
   std::vector<double> h((size_t)rhs->ld * rhs->m);
+  {
+    int rc = rhs_clear_unassembled(ctx, mat, rhs);
+    if (rc != 0) return rc;
+  }
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
   LPGP_HIP(hipMemcpy(h.data(), rhs->v, h.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (const auto& b : mat->blocks)

@@ -180,6 +180,7 @@ struct lpgp_rhs {
   int64_t m;                       // columns
   int64_t m_pad;                   // multiple of TILE, > m: column m is spare (carries the residual through the solve)
   double* v;                       // device ld x m_pad column-major
+  std::vector<char> assembled;     // per observation block: rows written by lpgp_cross_assemble (the others are cleared on first use)
 };
 
 namespace lpgp {
