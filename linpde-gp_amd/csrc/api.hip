@@ -1108,6 +1108,42 @@ int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) 
   return rc;
 }
 
+int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, int64_t n, const double* Linv, double* ms) {
+  LPGP_CHECK(ctx && XV && Linv && n > 0 && n % TILE == 0 && (which == 0 || which == 1), "lpgp_test_tile_step: bad argument");
+  double *d = nullptr, *dl = nullptr;
+  const size_t bytes = (size_t)n * TILE * sizeof(double);
+  LPGP_HIP(hipMalloc(&d, bytes));
+  LPGP_HIP(hipMalloc(&dl, (size_t)TILE * TILE * sizeof(double)));
+  LPGP_HIP(hipMemcpy(d, XV, bytes, hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dl, Linv, (size_t)TILE * TILE * sizeof(double), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  LPGP_HIP(hipEventCreate(&e0));
+  LPGP_HIP(hipEventCreate(&e1));
+  const int nt = (int)(n / TILE);
+  LPGP_HIP(hipEventRecord(e0, ctx->s_main));
+  int rc;
+  if (slab) {
+    rc = which == 0 ? launch_trsm_tile(ctx, ctx->s_main, d, n, dl, nt, -1) : launch_trsv_tile(ctx, ctx->s_main, d, TILE, dl, nt, -1);
+  } else {
+    GemmArgs g;
+    g.k = TILE; g.alpha = 1.0; g.beta = 0.0; g.tri = 0;
+    if (which == 0) { g.A = d; g.lda = n; g.B = dl; g.ldb = TILE; g.C = d; g.ldc = n; g.mt = nt; g.nt = 1; }
+    else { g.A = dl; g.lda = TILE; g.B = d; g.ldb = TILE; g.C = d; g.ldc = TILE; g.mt = 1; g.nt = nt; }
+    rc = launch_gemm(ctx, ctx->s_main, 0, which == 0 ? 0 : 1, g, -1);
+  }
+  LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+  LPGP_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  LPGP_HIP(hipEventElapsedTime(&t, e0, e1));
+  if (ms) *ms = t;
+  if (rc == 0) LPGP_HIP(hipMemcpy(XV, d, bytes, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  (void)hipFree(dl);
+  return rc;
+}
+
 int lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops) {
   const int blocks = ctx->cus * 4, iters = 4000;
   double* d = nullptr;

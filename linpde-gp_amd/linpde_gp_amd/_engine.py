@@ -394,6 +394,19 @@ def test_gemm(ctx: Context, ta: int, tb: int, lower_only: int, alpha: float, A: 
     return Cm, ms.value
 
 
+def test_tile_step(ctx: Context, which: int, slab: bool, XV: np.ndarray, Linv: np.ndarray):
+    """In-place tile step on host buffers (`lpgp_test_tile_step`): which = 0: X (rows x 128) <- X Linv^T,
+    which = 1: V (128 x cols) <- Linv V.  Returns (result, milliseconds)."""
+    XV = np.asfortranarray(XV, dtype=np.double).copy(order="F")
+    Linv = np.asfortranarray(Linv, dtype=np.double)
+    n = XV.shape[0] if which == 0 else XV.shape[1]
+    ms = C.c_double(0.0)
+    pd = C.POINTER(C.c_double)
+    check(lib.lpgp_test_tile_step(ctx._h, which, int(bool(slab)), XV.ctypes.data_as(pd), n, Linv.ctypes.data_as(pd),
+                                  C.byref(ms)), "lpgp_test_tile_step")
+    return XV, ms.value
+
+
 def test_potrf_tile(ctx: Context, T: np.ndarray):
     T = np.asfortranarray(T, dtype=np.double).copy(order="F")
     Linv = np.zeros((128, 128), order="F")

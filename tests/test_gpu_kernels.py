@@ -152,3 +152,28 @@ def test_matrix_free_product_throughput(ctx):
     print(f"\n[matvec] N={n}, 4 rhs: kernel {p['ms']:.3f} ms = {n * n / p['ms'] / 1e6:.1f} G entries/s; "
           f"call incl. H2D/D2H {dt * 1e3:.2f} ms")
     assert p["ms"] > 0
+
+
+@pytest.mark.parametrize("which,n", [(0, 128), (0, 640), (0, 16896), (1, 128), (1, 1152), (1, 4224)])
+def test_tile_step_slab_kernels(which, n):
+    """The in-place slab kernels of the panel chain (`trsm_tile_kernel`: X <- X Linv^T on n rows) and of
+    the forward substitution (`trsv_tile_kernel`: V <- Linv V on n right-hand sides) against NumPy and
+    against the same product on the general GEMM kernel; Linv lower triangular with garbage above the
+    diagonal (the kernels skip the stages beyond the diagonal instead of multiplying by zero)."""
+    import linpde_gp_amd  # noqa: F401
+    from linpde_gp_amd import _engine
+    ctx = _engine.default_context()
+    rng = np.random.default_rng(100 * which + n % 97)
+    Linv = np.tril(rng.standard_normal((128, 128))) + 4.0 * np.eye(128)
+    XV = rng.standard_normal((n, 128) if which == 0 else (128, n))
+    ref = XV @ Linv.T if which == 0 else Linv @ XV
+    got, ms = _engine.test_tile_step(ctx, which, True, XV, Linv)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    via_gemm, ms_g = _engine.test_tile_step(ctx, which, False, XV, Linv)
+    np.testing.assert_allclose(via_gemm, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    # entries above the diagonal of Linv must not matter to the slab kernels
+    junk = Linv + np.triu(rng.standard_normal((128, 128)), 1) * 1e6
+    got2, _ = _engine.test_tile_step(ctx, which, True, XV, junk)
+    if which == 1:      # (the upper row half skips k >= 64 entirely; inside a stage the product is dense)
+        np.testing.assert_allclose(got2[:64], (np.tril(junk[:64, :64]) + np.triu(junk[:64, :64], 1)) @ XV[:64], rtol=0,
+                                   atol=1e-6 * np.abs(got2).max())
