@@ -347,6 +347,10 @@ int lpgp_init(int device, lpgp_ctx** out) {
     long v = std::atol(e);
     if (v >= TILE && v % TILE == 0) ctx->nb = v;
   }
+  if (const char* e = std::getenv("LPGP_NB_SOLVE")) {
+    long v = std::atol(e);
+    if (v >= 0 && v % TILE == 0) ctx->nb_solve = v;
+  }
   if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_TRSM_SLAB")) ctx->trsm_slab = std::atoi(e) != 0;
@@ -433,6 +437,9 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
+  } else if (std::strcmp(key, "nb_solve") == 0) {
+    LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_solve must be a multiple of %d (0: nb)", TILE);
+    ctx->nb_solve = value;
   } else if (std::strcmp(key, "nb_outer") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer must be a multiple of %d (0 disables)", TILE);
     ctx->nb_outer = value;

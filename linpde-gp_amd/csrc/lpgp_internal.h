@@ -101,6 +101,7 @@ struct lpgp_ctx {
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};
   int64_t nb = 512;                // panel width of the blocked Cholesky
+  int64_t nb_solve = 0;            // panel width of the blocked forward substitution (0: by size, see trsm_lower_blocked)
   int64_t nb_big = 0;              // optional wider panels while more than nb_big_min_tiles tile rows remain (0 = off; measured: no gain at c3)
   int nb_big_min_tiles = 96;
   int lookahead = 1;

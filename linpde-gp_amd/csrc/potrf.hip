@@ -350,6 +350,11 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
   for (int p0 = c0; p0 < cl; ++it) {
     const int w0 = width_at(p0);
     const int p1 = (p0 + w0 < cl) ? p0 + w0 : cl;
+    // `dep` covers the columns from c0 + nb on: a first panel wider than nb needs it before its chain
+    if (dep_pending_p && p1 - p0 > nbt) {
+      LPGP_HIP(hipStreamWaitEvent(sP, dep, 0));
+      dep_pending_p = false;
+    }
     // panel factorisation on sP
     for (int jt = p0; jt < p1; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
@@ -744,7 +749,12 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   const int T = (int)T64;
   const int64_t ld = mat->cap, tb = TILE;
   const int mtl = (int)(m_pad / TILE);
-  const int nbt = (int)(ctx->nb / TILE);
+  // panel width of the substitution: its chain has no tile Cholesky, so wider panels (longer K in the
+  // updates) pay earlier than in the factorisation.  Measured (nb_solve = 512 / 768 / 1024 / 2048):
+  // c2 (65 tile rows) 9.57 / - / 9.74 / - ms, c3 (132) 55.5 / 55.1 / 56.1 / - ms, c4 (520) 2702 / - / 2671 /
+  // 2655 ms.
+  const int64_t nb_auto = T >= 384 ? 2048 : (T >= 96 ? 768 : ctx->nb);
+  const int nbt = (int)((ctx->nb_solve > 0 ? ctx->nb_solve : nb_auto) / TILE);
   const double* a = mat->a;
   const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
   hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
