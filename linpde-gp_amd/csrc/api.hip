@@ -301,7 +301,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   // so a single workgroup of the panel stream finds a free CU on whichever XCD it is dealt to
   auto masked_stream = [&](int nreserve, hipStream_t* out) {
     *out = nullptr;
-    if (nreserve <= 0 || nreserve >= ctx->cus) return;
+    if (nreserve == 0 || nreserve >= ctx->cus) return;       // (negative: a CU-masked queue with every CU enabled, for measurements)
     const int words = (ctx->cus + 31) / 32;
     std::vector<uint32_t> mask(words, 0u);
     for (int cu = 0; cu < ctx->cus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
