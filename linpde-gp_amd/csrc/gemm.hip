@@ -577,6 +577,12 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
 // work of the stages beyond, and the slabs are dealt so that the two waves of a SIMD hold slabs
 // s and 7 - s (9 stage units of 16 per SIMD instead of 12).
 // =========================================================================================
+#ifndef LPGP_LSTAGES
+#define LPGP_LSTAGES 3
+#endif
+constexpr int LSTAGES = LPGP_LSTAGES;    // ring depth of the two slab kernels: 3 stages = 80 / 77 KB, so that a slab workgroup
+                                         // finds room on a CU as soon as ONE of its two GEMM workgroups retires (4 stages: 106 KB
+                                         // = a whole CU)
 constexpr int LDP2 = 272;                // pair of k-rows of 128 indices + 16 doubles of padding (LDP2 % 32 == 16)
 constexpr int TS_A = 8 * LDMP;           // doubles per stage: A image
 constexpr int TS_B = 8 * LDP2;           // doubles per stage: Linv^T image
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
   const int64_t row0 = (int64_t)blockIdx.x * 64;
 
   auto issue = [&](int kt) {
-    double* sa = smem + (size_t)(kt & (SSTAGES - 1)) * TS_STAGE;
+    double* sa = smem + (size_t)(kt % LSTAGES) * TS_STAGE;
     double* sb = sa + TS_A;
     // A: k-row pair wu of the stage (lanes 0-31 / 32-63 = the two k-rows, 64 indices each)
     {
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
     }
   };
 #pragma unroll
-  for (int kt = 0; kt < SSTAGES - 1; ++kt) issue(kt);
+  for (int kt = 0; kt < LSTAGES - 1; ++kt) issue(kt);
 
   const int j = lane >> 4;
   unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDMP + (j >> 1) * 64 + (lane & 15));
@@ -629,14 +635,14 @@ __global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
     for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
 
   for (int kt = 0; kt < KT; ++kt) {
-    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage, LSTAGES - 1 stages in flight
+    if (later >= 2 && LSTAGES >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);
+    if (kt + LSTAGES - 1 < KT) issue(kt + LSTAGES - 1);
     if (kt > slab) continue;                               // Linv[c][k] = 0 for k > c (wave-uniform)
-    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * TS_STAGE) * 8u;
+    const unsigned stoff = (unsigned)((kt % LSTAGES) * TS_STAGE) * 8u;
     const unsigned aM = laneM + stoff, aN = laneN + stoff;
     double am[2][4], bn[2][4];
     asm volatile("" ::: "memory");
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
 
 int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel) {
   if (mt <= 0) return 0;
-  const size_t shmem = (size_t)SSTAGES * TS_STAGE * sizeof(double);       // 106 496 B
+  const size_t shmem = (size_t)LSTAGES * TS_STAGE * sizeof(double);       // 79 872 B: fits beside ONE 73-KB GEMM workgroup
   static bool attr_set = false;
   if (!attr_set) {
     LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_tile_kernel),
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
   constexpr int TV_STAGE = TV_A + TV_B;
 
   auto issue = [&](int kt) {
-    double* sa = smem + (size_t)(kt & (SSTAGES - 1)) * TV_STAGE;
+    double* sa = smem + (size_t)(kt % LSTAGES) * TV_STAGE;
     double* sb = sa + TV_A;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                          // Linv: element (i, k) at linv[i + 128 k]
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
     }
   };
 #pragma unroll
-  for (int kt = 0; kt < SSTAGES - 1; ++kt) issue(kt);
+  for (int kt = 0; kt < LSTAGES - 1; ++kt) issue(kt);
 
   const int j = lane >> 4;
   const unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDP2 + (j >> 1) * 128 + 64 * mh + (lane & 15));
@@ -760,14 +766,14 @@ __global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
     for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
 
   for (int kt = 0; kt < KT; ++kt) {
-    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage, LSTAGES - 1 stages in flight
+    if (later >= 2 && LSTAGES >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);
+    if (kt + LSTAGES - 1 < KT) issue(kt + LSTAGES - 1);
     if (mh == 0 && kt >= 4) continue;                      // Linv[i][k] = 0 for k > i (wave-uniform)
-    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * TV_STAGE) * 8u;
+    const unsigned stoff = (unsigned)((kt % LSTAGES) * TV_STAGE) * 8u;
     const unsigned aM = laneM + stoff, aN = laneNb + stoff;
     double am[2][4], bn[2][4];
     asm volatile("" ::: "memory");
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
 // V (128 rows x nt*128 columns, column-major ldv) <- linv * V in place
 int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel) {
   if (nt <= 0) return 0;
-  const size_t shmem = (size_t)SSTAGES * (8 * LDP2 + 1024) * sizeof(double);       // 102 400 B
+  const size_t shmem = (size_t)LSTAGES * (8 * LDP2 + 1024) * sizeof(double);       // 76 800 B: fits beside ONE 73-KB GEMM workgroup
   static bool attr_set = false;
   if (!attr_set) {
     LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_tile_kernel),
