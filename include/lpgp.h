@@ -221,6 +221,9 @@ int  lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info)
  * slab = 0 runs the same product on the general GEMM kernel (the two must agree).          */
 int  lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, int64_t n,
                          const double* Linv, double* ms);
+/* diagnostics: histogram over the 8 XCDs of where the single workgroup of the tile Cholesky ran
+ * since the last reset (the CU reservation of the update streams is built on it)           */
+int  lpgp_debug_tile_xcc(lpgp_ctx* ctx, int32_t* out8, int32_t reset);
 /* peak probes: fp64 MFMA issue loop and streaming write; returns TFLOP/s resp. GB/s     */
 int  lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops);
 int  lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps);

@@ -1151,6 +1151,12 @@ int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, 
   return rc;
 }
 
+int lpgp_debug_tile_xcc(lpgp_ctx* ctx, int32_t* out8, int32_t reset) {
+  LPGP_CHECK(ctx && out8, "lpgp_debug_tile_xcc: null argument");
+  LPGP_HIP(hipDeviceSynchronize());
+  return debug_tile_xcc(out8, reset);
+}
+
 int lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops) {
   const int blocks = ctx->cus * 4, iters = 4000;
   double* d = nullptr;

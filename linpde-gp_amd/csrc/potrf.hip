@@ -50,6 +50,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // n = 4q + (lane>>4)); per 4-deep k-step it takes ONE "m-side" fragment
 // (lane -> M[m = lane&15][k = lane>>4]) and four replicated "n-side" fragments
 // (lane -> N[n = 4q + (lane&3)][k = lane>>4]).
+// where the single workgroup of the tile Cholesky ran (XCC id histogram; lpgp_debug_tile_xcc)
+__device__ int g_tile_xcc_hist[8];
+
 __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
                                                           double* __restrict__ linv, int* __restrict__ info,
                                                           int info_base) {
@@ -67,6 +70,11 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicAdd(&g_tile_xcc_hist[xcc & 7], 1);
+  }
   // ---- load tile: one 1-KiB LDS-DMA piece per column ----
   for (int c = wu; c < TILE; c += TILE_WAVES)
     __builtin_amdgcn_global_load_lds((gptr_t)(a + (int64_t)c * lda + 2 * lane), (lptr_t)(s + c * TL), 16, 0, 0);
@@ -278,6 +286,17 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
   TSTAMP(5);
   if (tid == 0) for (int i = 0; i < 7; ++i) g_stamps[i] = ts_[i];
 #endif
+}
+
+int debug_tile_xcc(int32_t* out8, int reset) {
+  int h[8];
+  LPGP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_xcc_hist), sizeof(h)));
+  for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  if (reset) {
+    int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LPGP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_xcc_hist), z, sizeof(z)));
+  }
+  return 0;
 }
 
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
