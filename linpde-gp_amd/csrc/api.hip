@@ -431,6 +431,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->solve_chain_us_tile = (double)value;
   } else if (std::strcmp(key, "chain_us_fixed") == 0) {
     ctx->chain_us_fixed = (double)value;
+  } else if (std::strcmp(key, "dist_merged_update") == 0) {
+    ctx->dist_merged_update = (int)value;
   } else if (std::strcmp(key, "trsm_slab") == 0) {
     ctx->trsm_slab = (int)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {
@@ -1072,6 +1074,12 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
   g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.mt = (int)(m / TILE); g.nt = (int)(n / TILE); g.k = (int)k; g.alpha = alpha; g.beta = beta;
   g.tri = lower_only;
+  if (const char* e = std::getenv("LPGP_TEST_OWN")) {          // "world,rank,base,width": ownership filter of the distributed update
+    int w = 1, r = 0, b = 0, wd = 4;
+    if (lower_only && std::sscanf(e, "%d,%d,%d,%d", &w, &r, &b, &wd) == 4 && w > 1) {
+      g.own_world = w; g.own_rank = r; g.own_base = b; g.own_w = wd;
+    }
+  }
   int rc = launch_gemm(ctx, ts, ta, tb, g, -1);
   if (rc == 0 && hipStreamSynchronize(ts) != hipSuccess) rc = -1;
   if (rc == 0) LPGP_HIP(hipMemcpy(C, dC, (size_t)ldc * n * sizeof(double), hipMemcpyDeviceToHost));

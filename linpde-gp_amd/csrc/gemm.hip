@@ -174,6 +174,24 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 // on SYRK n x n x 512: n = 16384 51.2 -> 51.9, 12288 48.1 -> 49.9, 6144 49.2 -> 51.0 TFLOP/s,
 // rectangular shapes unchanged; scratch/dense_ab.py.)
 constexpr int BAND = 8;
+// ownership filter of the distributed factorisation (see GemmArgs): number of owned columns among
+// the local tile columns [0, n), and the o-th owned column
+__host__ __device__ __forceinline__ int own_first(const GemmArgs& g) {       // first owned local column
+  return ((g.own_rank - g.own_base) % g.own_world + g.own_world) % g.own_world * g.own_w;
+}
+__host__ __device__ __forceinline__ int own_count(const GemmArgs& g, int n) {
+  const int f = own_first(g);
+  if (n <= f) return 0;
+  const int span = g.own_world * g.own_w, m = n - f;
+  const int full = m / span, rem = m - full * span;
+  return full * g.own_w + (rem < g.own_w ? rem : g.own_w);
+}
+__host__ __device__ __forceinline__ int own_col(const GemmArgs& g, int o) {
+  return own_first(g) + (o / g.own_w) * g.own_world * g.own_w + o % g.own_w;
+}
+__host__ __device__ __forceinline__ bool own_is(const GemmArgs& g, int c) {
+  return (g.own_base + c / g.own_w) % g.own_world == g.own_rank;
+}
 template <bool TRI>
 __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr, int& tc) {
   const int xcd = v & 7, q = v >> 3;
@@ -201,7 +219,26 @@ __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr
     r = r0 + (j - c * R);
   } else {
     const int cfull = (r0 + 1 < g.nt) ? r0 + 1 : g.nt;       // columns c <= r0: all R rows valid
-    if (j < cfull * R) {
+    if (g.own_world > 1) {
+      // only owned columns: the full ones by ordinal, the (at most 7) columns inside the band's
+      // diagonal triangle one by one
+      const int nfull = own_count(g, cfull);
+      if (j < nfull * R) {
+        const int o = j / R;
+        c = own_col(g, o);
+        r = r0 + (j - o * R);
+      } else {
+        int jj = j - nfull * R, t = 0;
+        for (;; ++t) {
+          const int cc = r0 + 1 + t;
+          if (!own_is(g, cc)) continue;
+          if (jj < R - 1 - t) break;
+          jj -= R - 1 - t;
+        }
+        c = r0 + 1 + t;
+        r = c + jj;
+      }
+    } else if (j < cfull * R) {
       c = j / R;
       r = r0 + (j - c * R);
     } else {
@@ -872,19 +909,27 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
       for (int b = 0; b < ga.nbands; ++b) {
         ga.band_prefix[b] = acc;
         const int r0 = b * BAND, R = std::min(BAND, g.mt - r0);
-        acc += std::min(r0 + 1, g.nt) * R;
-        for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t) acc += R - 1 - t;
+        if (g.own_world > 1) {
+          acc += own_count(g, std::min(r0 + 1, g.nt)) * R;
+          for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t)
+            if (own_is(g, r0 + 1 + t)) acc += R - 1 - t;
+        } else {
+          acc += std::min(r0 + 1, g.nt) * R;
+          for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t) acc += R - 1 - t;
+        }
       }
       ga.band_prefix[ga.nbands] = acc;
       ga.ntiles = acc;
     } else {
       ga.ntiles = g.mt * g.nt;
     }
+    if (ga.ntiles == 0) return 0;                    // (ownership filter: nothing owned in this region)
     ga.chunk = (ga.ntiles + 7) / 8;
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)(8 * ga.chunk)), dim3(256), shmem, stream, ga);
     LPGP_HIP(hipGetLastError());
     return 0;
   }
+  LPGP_CHECK(g.own_world <= 1, "gemm: the ownership filter needs the dense tile enumeration");
   int nsuper = 0, SS = 64;
   for (int sh = 3; sh >= 0; --sh) {
     const int S = 1 << sh;
@@ -912,7 +957,7 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
   // (not for in-place products X <- X * B: with 64-column tiles another workgroup would still be
   //  reading the columns of X this one overwrites)
   const int64_t tiles = g.tri ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
-  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C;
+  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C && g.own_world <= 1;
   if (prof_kernel >= 0) {
     // one profiling slot == one kernel symbol (family)
     if (small) prof_kernel = LPGP_K_GEMM_SMALL;

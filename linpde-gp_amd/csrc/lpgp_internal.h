@@ -110,6 +110,7 @@ struct lpgp_ctx {
   // (update-bound) or after the look-ahead half (chain-bound)
   double chain_us_tile = 115.0, solve_chain_us_tile = 115.0, chain_us_fixed = 80.0;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
+  int dist_merged_update = 1;      // distributed factorisation: one ownership-filtered update launch per panel (0: one launch per owned panel)
   int trsm_slab = 1;               // panel triangular solves by trsm_tile_kernel (0: one 128x128x128 tile per workgroup)
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
@@ -218,6 +219,10 @@ struct GemmArgs {
   int32_t ntiles = 0, chunk = 0, nbands = 0;
   static constexpr int MAXB = 192; // bands of 8 tile rows: 1536 tile rows = 196 608 matrix rows (> 288 GB of fp64)
   int32_t band_prefix[MAXB + 1];   // triangular shapes only: tiles before band b
+  // distributed factorisation (triangular shapes, dense enumeration): only the tile columns of the
+  // panels this rank owns are enumerated -- local tile column c belongs to panel own_base + c / own_w,
+  // owned if that is congruent to own_rank modulo own_world (own_world <= 1: every column)
+  int32_t own_world = 1, own_rank = 0, own_base = 0, own_w = 4;
   unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
   unsigned long long* timeline = nullptr; // diagnostic builds: per-workgroup life cycle + hardware id
 };

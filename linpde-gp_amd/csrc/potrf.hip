@@ -728,6 +728,19 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
     LPGP_HIP(hipEventRecord(evp, sP));
     // (b) the other owned panels on the update stream
     LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+    if (ctx->dist_merged_update && ctx->dense_tiles && p2 < T) {
+      // ONE launch over the lower triangle from p2 on, enumerating only the tile columns of the
+      // panels this rank owns (a launch per owned panel -- (T - q0) x 4 tiles each, one after the
+      // other on the update stream -- leaves a partly filled last round per panel: with P = 2 a rank
+      // owns every other panel, 20 launches of ~1.3 rounds per step at N = 20k)
+      const double* Pq = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
+      GemmArgs g = mk(Pq, ld, Pq, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1);
+      g.own_world = P;
+      g.own_rank = me;
+      g.own_base = ((p2 - t_done) / nbt) % P;
+      g.own_w = nbt;
+      LPGP_TRY(launch_gemm(ctx, sU, 0, 0, g, LPGP_K_SYRK));
+    } else
     for (int q0 = p2; q0 < T; q0 += nbt) {
       if (owner_of(q0) != me) continue;
       const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
