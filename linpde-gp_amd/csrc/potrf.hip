@@ -645,6 +645,15 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
                              mk(Xp, ld, a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld,
                                 rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
                              LPGP_K_GEMM));
+      if (ctx->dist_merged_update && ctx->dense_tiles) {   // owned panels of the new region: one filtered launch
+        const double* Xq = a + (int64_t)t_done * tb + (int64_t)p0 * tb * ld;
+        GemmArgs g = mk(Xq, ld, Xq, ld, a + (int64_t)t_done * tb * (ld + 1), ld, T - t_done, T - t_done, K, -1.0, 1.0, 1);
+        g.own_world = P;
+        g.own_rank = me;
+        g.own_base = 0;
+        g.own_w = nbt;
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0, g, LPGP_K_SYRK));
+      } else
       for (int q0 = t_done; q0 < T; q0 += nbt) {           // owned panels of the new region
         if (owner_of(q0) != me) continue;
         const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
