@@ -106,7 +106,26 @@ int  lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out);
 int  lpgp_mat_destroy(lpgp_mat* mat);
 /* declare the next observation block of n rows; returns its index (>= 0) or < 0       */
 int  lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n);
-int64_t lpgp_mat_size(const lpgp_mat* mat);           /* logical size = sum of block sizes */
+/* Undo the last lpgp_mat_add_block whose block has NOT been factored (a failed lpgp_potrf leaves it
+ * so): the matrix is again what it was before the block was declared -- the leading factor, its tile
+ * inverses and the earlier blocks are untouched by a failed append (its phases only write the new
+ * rows / columns).  This is how a failed `condition_on_observations` leaves the object it was called on
+ * intact, as in the reference (a failed `BlockMatrix2x2` construction has no side effect on the old
+ * operator, linops/_block.py:84-130).                                                          */
+int  lpgp_mat_pop_block(lpgp_ctx* ctx, lpgp_mat* mat);
+/* VIEW on the leading nblocks observation blocks (nblocks >= 1, all of them factored): every solve /
+ * prediction call then sees exactly the factor an earlier conditioning produced -- a block append never
+ * touches the leading part of the factor -- so an earlier posterior object stays usable after a later
+ * one has extended the shared matrix (reference semantics: posteriors are immutable values,
+ * _conditional.py:253-294).  nblocks = -1: all blocks.  While a strict prefix is in view the matrix
+ * cannot be extended or assembled into (branching = lpgp_mat_clone).                            */
+int  lpgp_mat_set_view(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks);
+int32_t lpgp_mat_num_blocks(const lpgp_mat* mat);     /* blocks in view */
+int32_t lpgp_mat_num_blocks_total(const lpgp_mat* mat);
+/* independent copy of the leading nblocks (factored) blocks: a second conditioning of an object that
+ * has already been extended continues on its own copy (device-to-device, 8 n^2 bytes)          */
+int  lpgp_mat_clone(lpgp_ctx* ctx, const lpgp_mat* mat, int32_t nblocks, lpgp_mat** out);
+int64_t lpgp_mat_size(const lpgp_mat* mat);           /* logical size = sum of block sizes (of the view) */
 int64_t lpgp_mat_padded_size(const lpgp_mat* mat);    /* internal padded size              */
 /* block (bi, bj), bi >= bj  <-  sum_g (kd[g])(X0, X1) with X0 the points of block bi
  * (operator on argument 0) and X1 those of block bj (operator on argument 1).  For
@@ -196,7 +215,9 @@ enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing u
                       LPGP_K_GEMM_SMALL = 6 /* any product small enough for the 64x64-tile kernel */,
                       LPGP_K_MATVEC = 7 /* matrix-free kernel product */,
                       LPGP_K_SYRK_AHEAD = 8 /* look-ahead half of the trailing update (next panel's columns) */,
-                      LPGP_K_COUNT = 9 };
+                      LPGP_K_ASSEMBLE_GRID = 9 /* tensor-grid (Kronecker) expansion kernels; LPGP_K_ASSEMBLE = per-entry kernel */,
+                      LPGP_K_PANEL = 10 /* fused panel factorisation / fused substitution tile steps */,
+                      LPGP_K_COUNT = 11 };
 /* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
 int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);

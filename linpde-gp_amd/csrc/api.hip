@@ -10,15 +10,6 @@
 
 namespace lpgp {
 
-static thread_local char g_err[1024] = "";
-
-void set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
 // ---------------------------------------------------------------------------------------
 // profiling with HIP events on the launching stream
 // ---------------------------------------------------------------------------------------
@@ -273,7 +264,7 @@ using namespace lpgp;
 
 extern "C" {
 
-const char* lpgp_last_error(void) { return lpgp::g_err; }
+const char* lpgp_last_error(void) { return lpgp::last_error(); }
 
 int lpgp_init(int device, lpgp_ctx** out) {
   LPGP_CHECK(out != nullptr, "lpgp_init: null out");
@@ -400,6 +391,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
 }
 
 int lpgp_device_info(lpgp_ctx* ctx, char* name, int len, int* cus, int64_t* hbm_bytes) {
+  LPGP_DEVICE(ctx);
   hipDeviceProp_t prop;
   LPGP_HIP(hipGetDeviceProperties(&prop, ctx->device));
   if (name && len > 0) {
@@ -417,6 +409,7 @@ int lpgp_sync(lpgp_ctx* ctx) {
 }
 
 int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
+  LPGP_DEVICE(ctx);
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
@@ -488,6 +481,7 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
 
 int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user) {
   LPGP_CHECK(ctx && fn && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init_host: bad argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init_host: already initialised");
   ctx->host_xfer = fn;
   ctx->host_xfer_user = user;
@@ -497,6 +491,7 @@ int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_ex
 }
 
 int lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world) {
+  LPGP_DEVICE(ctx);
   if (rank) *rank = ctx->rank;
   if (world) *world = ctx->world;
   return 0;
@@ -505,6 +500,7 @@ int lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world) {
 // ---- points ----------------------------------------------------------------------------
 int lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out) {
   LPGP_CHECK(ctx && X_host && out, "lpgp_pts_create: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(n >= 0 && d >= 1 && d <= LPGP_MAXD, "lpgp_pts_create: n=%lld d=%d", (long long)n, d);
   lpgp_pts* p = new lpgp_pts();
   p->ctx = ctx;
@@ -522,6 +518,7 @@ int lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, l
 
 int lpgp_pts_destroy(lpgp_pts* p) {
   if (!p) return 0;
+  (void)hipSetDevice(p->ctx->device);
   (void)hipFree(p->x);
   delete p;
   return 0;
@@ -530,6 +527,7 @@ int lpgp_pts_destroy(lpgp_pts* p) {
 // ---- matrix ----------------------------------------------------------------------------
 int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
   LPGP_CHECK(ctx && out, "lpgp_mat_create: null argument");
+  LPGP_DEVICE(ctx);
   lpgp_mat* m = new lpgp_mat();
   m->ctx = ctx;
   m->cap = 0;
@@ -549,6 +547,7 @@ int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
 
 int lpgp_mat_destroy(lpgp_mat* m) {
   if (!m) return 0;
+  (void)hipSetDevice(m->ctx->device);
   mat_release(m->ctx, m);
   delete m;
   return 0;
@@ -556,6 +555,8 @@ int lpgp_mat_destroy(lpgp_mat* m) {
 
 int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   LPGP_CHECK(ctx && mat && n > 0, "lpgp_mat_add_block: bad argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_mat_add_block: a strict prefix of the blocks is in view (lpgp_mat_set_view); extend a clone instead");
   lpgp_block b;
   b.n = n;
   b.off = mat->n;
@@ -587,12 +588,86 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   return (int)mat->blocks.size() - 1;
 }
 
+int lpgp_mat_pop_block(lpgp_ctx* ctx, lpgp_mat* mat) {
+  LPGP_CHECK(ctx && mat, "lpgp_mat_pop_block: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_mat_pop_block: a strict prefix of the blocks is in view");
+  LPGP_CHECK(!mat->blocks.empty(), "lpgp_mat_pop_block: no block");
+  const lpgp_block b = mat->blocks.back();
+  LPGP_CHECK(b.poff >= mat->pn_fact, "lpgp_mat_pop_block: the last block is part of the factor");
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));      // nothing of a failed append still in flight
+  mat->blocks.pop_back();
+  mat->n -= b.n;
+  mat->pn -= b.pn;
+  mat->has_w = 0;
+  mat->has_r = 0;
+  return 0;
+}
+
+int32_t lpgp_mat_num_blocks(const lpgp_mat* mat) { return mat ? (int32_t)mat->blocks.size() : -1; }
+int32_t lpgp_mat_num_blocks_total(const lpgp_mat* mat) { return mat ? (int32_t)(mat->blocks.size() + mat->hidden.size()) : -1; }
+
+int lpgp_mat_set_view(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks) {
+  LPGP_CHECK(ctx && mat, "lpgp_mat_set_view: null argument");
+  const int total = (int)(mat->blocks.size() + mat->hidden.size());
+  if (nblocks < 0) nblocks = total;
+  LPGP_CHECK(nblocks >= 1 && nblocks <= total, "lpgp_mat_set_view: %d of %d blocks", nblocks, total);
+  if (nblocks == (int)mat->blocks.size()) return 0;
+  const int64_t fact_all = mat->hidden.empty() ? mat->pn_fact : mat->pn_fact_all;
+  std::vector<lpgp_block> all = mat->blocks;
+  all.insert(all.end(), mat->hidden.begin(), mat->hidden.end());
+  const lpgp_block& last = all[nblocks - 1];
+  LPGP_CHECK(nblocks == total || last.poff + last.pn <= fact_all, "lpgp_mat_set_view: block %d is not factored yet", nblocks - 1);
+  mat->blocks.assign(all.begin(), all.begin() + nblocks);
+  mat->hidden.assign(all.begin() + nblocks, all.end());
+  mat->n = last.off + last.n;
+  mat->pn = last.poff + last.pn;
+  mat->pn_fact_all = fact_all;
+  mat->pn_fact = fact_all < mat->pn ? fact_all : mat->pn;
+  mat->has_w = 0;                                    // resident weights / residual belong to the previous view
+  mat->has_r = 0;
+  return 0;
+}
+
+int lpgp_mat_clone(lpgp_ctx* ctx, const lpgp_mat* src, int32_t nblocks, lpgp_mat** out) {
+  LPGP_CHECK(ctx && src && out, "lpgp_mat_clone: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed(), "lpgp_mat_clone: not available in a multi-GPU job");
+  std::vector<lpgp_block> all = src->blocks;
+  all.insert(all.end(), src->hidden.begin(), src->hidden.end());
+  LPGP_CHECK(nblocks >= 1 && nblocks <= (int)all.size(), "lpgp_mat_clone: %d of %d blocks", nblocks, (int)all.size());
+  const int64_t fact_all = src->hidden.empty() ? src->pn_fact : src->pn_fact_all;
+  const lpgp_block& last = all[nblocks - 1];
+  const int64_t pn = last.poff + last.pn;
+  LPGP_CHECK(pn <= fact_all, "lpgp_mat_clone: block %d is not factored yet", nblocks - 1);
+  lpgp_mat* m = nullptr;
+  int rc = lpgp_mat_create(ctx, pn, &m);
+  if (rc != 0) return rc;
+  hipError_t e = hipMemcpy2DAsync(m->a, (size_t)m->cap * sizeof(double), src->a, (size_t)src->cap * sizeof(double),
+                                  (size_t)pn * sizeof(double), (size_t)pn, hipMemcpyDeviceToDevice, ctx->s_main);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(m->linv, src->linv, (size_t)pn * TILE * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_main);
+  if (e != hipSuccess) {
+    set_error("lpgp_mat_clone: %s", hipGetErrorString(e));
+    lpgp_mat_destroy(m);
+    return -1;
+  }
+  m->blocks.assign(all.begin(), all.begin() + nblocks);
+  m->n = last.off + last.n;
+  m->pn = pn;
+  m->pn_fact = pn;
+  *out = m;
+  return 0;
+}
+
 int64_t lpgp_mat_size(const lpgp_mat* mat) { return mat ? mat->n : -1; }
 int64_t lpgp_mat_padded_size(const lpgp_mat* mat) { return mat ? mat->pn : -1; }
 
 int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
                        const lpgp_pts* X1, lpgp_mat* mat, int32_t bi, int32_t bj) {
   LPGP_CHECK(ctx && kd && X0 && mat, "lpgp_gram_assemble: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size() && bj >= 0 && bj <= bi, "lpgp_gram_assemble: bad block (%d,%d)", bi, bj);
   const lpgp_block& Bi = mat->blocks[bi];
   const lpgp_block& Bj = mat->blocks[bj];
@@ -619,6 +694,7 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
 int lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* const* F0,
                             const lpgp_pts* const* F1, lpgp_mat* mat, int32_t bi, int32_t bj) {
   LPGP_CHECK(ctx && kd && F0 && mat, "lpgp_gram_assemble_grid: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(ngroups >= 1 && ngroups <= LPGP_MAXG, "lpgp_gram_assemble_grid: bad ngroups %d", ngroups);
   LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size() && bj >= 0 && bj <= bi, "lpgp_gram_assemble_grid: bad block (%d,%d)", bi, bj);
   const lpgp_block& Bi = mat->blocks[bi];
@@ -654,6 +730,7 @@ int lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups
 
 int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar) {
   LPGP_CHECK(ctx && mat && bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_mat_add_diag: bad argument");
+  LPGP_DEVICE(ctx);
   const lpgp_block& B = mat->blocks[bi];
   LPGP_CHECK(B.poff >= mat->pn_fact, "lpgp_mat_add_diag: block %d is already factored", bi);
   double* dv = nullptr;
@@ -671,6 +748,7 @@ int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_
 
 int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B_host) {
   LPGP_CHECK(ctx && mat && B_host && bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_mat_add_dense: bad argument");
+  LPGP_DEVICE(ctx);
   const lpgp_block& B = mat->blocks[bi];
   LPGP_CHECK(B.poff >= mat->pn_fact, "lpgp_mat_add_dense: block %d is already factored", bi);
   int rc = ensure_tmp(ctx, B.n * B.n);
@@ -684,6 +762,7 @@ int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B
 
 int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host) {
   LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_to_host: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(what == 0 || what == 1, "lpgp_mat_to_host: what must be 0 or 1");
   if (what == 0) LPGP_CHECK(mat->pn_fact == 0, "lpgp_mat_to_host: Gram no longer available after potrf");
   if (what == 1) LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_to_host: matrix is not (fully) factored");
@@ -709,8 +788,10 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
 // ---- factor + solve -----------------------------------------------------------------------
 int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   LPGP_CHECK(ctx && mat, "lpgp_potrf: null argument");
+  LPGP_DEVICE(ctx);
   if (info) *info = 0;
   if (mat->pn_fact == mat->pn) return 0;
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf: a strict prefix of the blocks is in view");
   int32_t h = 0;
   int rc = ctx->distributed()
                ? potrf_blocked_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
@@ -725,6 +806,7 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
 
 int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
   LPGP_CHECK(ctx && mat && b_host && nrhs >= 1, "lpgp_potrs: bad argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_potrs: matrix is not factored");
   const int64_t pn = mat->pn, n = mat->n, m_pad = round_up(nrhs, TILE);
   double* dv = nullptr;
@@ -752,6 +834,7 @@ int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
 
 int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host) {
   LPGP_CHECK(ctx && mat && r_host, "lpgp_solve_weights: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_solve_weights: matrix is not factored");
   const int64_t pn = mat->pn;
   int rc = ensure_tmp(ctx, pn);
@@ -770,6 +853,7 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
 
 int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
   LPGP_CHECK(ctx && mat && r_host, "lpgp_mat_set_residual: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_mat_set_residual: matrix is not factored");
   std::vector<double> hp((size_t)mat->pn);
   scatter_padded(mat, r_host, hp.data());
@@ -782,6 +866,7 @@ int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
 // ---- prediction -----------------------------------------------------------------------------
 int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out) {
   LPGP_CHECK(ctx && mat && out && m >= 1, "lpgp_rhs_create: bad argument");
+  LPGP_DEVICE(ctx);
   lpgp_rhs* r = new lpgp_rhs();
   r->ctx = ctx;
   r->ld = mat->pn;
@@ -821,6 +906,7 @@ static int rhs_clear_unassembled(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* r
 
 int lpgp_rhs_destroy(lpgp_rhs* r) {
   if (!r) return 0;
+  (void)hipSetDevice(r->ctx->device);
   pool_free(r->ctx, r->v, (size_t)r->ld * r->m_pad * sizeof(double));
   delete r;
   return 0;
@@ -829,6 +915,7 @@ int lpgp_rhs_destroy(lpgp_rhs* r) {
 int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X_obs,
                         const lpgp_pts* X_test, lpgp_rhs* rhs, const lpgp_mat* mat, int32_t bi) {
   LPGP_CHECK(ctx && kd && X_obs && X_test && rhs && mat, "lpgp_cross_assemble: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(bi >= 0 && bi < (int)mat->blocks.size(), "lpgp_cross_assemble: bad block %d", bi);
   const lpgp_block& B = mat->blocks[bi];
   LPGP_CHECK(X_obs->n == B.n && X_test->n == rhs->m && X_obs->d == X_test->d && kd[0].d == X_obs->d,
@@ -845,6 +932,7 @@ int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, co
 
 int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   LPGP_CHECK(ctx && mat && V, "lpgp_trsm_lower: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
   int rc = rhs_clear_unassembled(ctx, mat, V);
   if (rc != 0) return rc;
@@ -857,6 +945,7 @@ int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
 int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_mean_host,
                  const double* kxx_host, double* mean_host, double* var_host) {
   LPGP_CHECK(ctx && mat && K, "lpgp_predict: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && K->ld == mat->pn, "lpgp_predict: matrix not factored or size mismatch");
   const int64_t m = K->m;
   int rc = ensure_tmp(ctx, 2 * K->m_pad);
@@ -912,6 +1001,7 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
 
 int lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host) {
   LPGP_CHECK(ctx && A && B && out_host, "lpgp_rhs_inner: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(A->ld == B->ld, "lpgp_rhs_inner: row mismatch");
   const int64_t ma = A->m_pad, mb = B->m_pad;
   double* dc = nullptr;
@@ -933,6 +1023,7 @@ int lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host) {
 
 int lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* out_host) {
   LPGP_CHECK(ctx && mat && rhs && out_host, "lpgp_rhs_to_host: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(rhs->ld == mat->pn, "lpgp_rhs_to_host: size mismatch");
   std::vector<double> h((size_t)rhs->ld * rhs->m);
   {
@@ -953,18 +1044,14 @@ int lpgp_kernel_diag(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, doubl
   DevDesc desc;
   int rc = lower_kdesc(kd, ngroups, &desc);
   if (rc != 0) return rc;
-  // at x == x' every r_d = 0: only the constant coefficient of the all-even parity class survives
-  double v = 0.0;
-  for (int g = 0; g < desc.ngroups; ++g)
-    for (int c = 0; c < desc.g[g].ncls; ++c)
-      if (desc.g[g].parity[c] == 0) v += desc.g[g].scale * desc.coef[desc.g[g].coef_off[c]];
-  *out_value = v;
+  *out_value = desc_diag(desc);      // at x == x' every r_d = 0
   return 0;
 }
 
 int lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
                        const lpgp_pts* X1, double* out_host) {
   LPGP_CHECK(ctx && kd && X0 && X1 && out_host, "lpgp_kernel_matrix: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(X0->d == X1->d && kd[0].d == X0->d, "lpgp_kernel_matrix: dimension mismatch");
   if (X0->n == 0 || X1->n == 0) return 0;
   DevDesc desc;
@@ -988,6 +1075,7 @@ int lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
 int lpgp_kernel_matvec(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0,
                        const lpgp_pts* X1, const double* v_host, int64_t nrhs, double* out_host) {
   LPGP_CHECK(ctx && kd && X0 && X1 && v_host && out_host && nrhs >= 1, "lpgp_kernel_matvec: bad argument");
+  LPGP_DEVICE(ctx);
   LPGP_CHECK(X0->d == X1->d && kd[0].d == X0->d, "lpgp_kernel_matvec: dimension mismatch");
   const int64_t n0 = X0->n, n1 = X1->n;
   if (n0 == 0) return 0;
@@ -1031,12 +1119,14 @@ int lpgp_kernel_matvec(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
 }
 
 int lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask) {
+  LPGP_DEVICE(ctx);
   int rc = prof_collect(ctx);
   ctx->prof_on = mask;
   return rc;
 }
 
 int lpgp_profile_reset(lpgp_ctx* ctx) {
+  LPGP_DEVICE(ctx);
   int rc = prof_collect(ctx);
   for (auto& s : ctx->prof) s = ProfSlot();
   return rc;
@@ -1044,6 +1134,7 @@ int lpgp_profile_reset(lpgp_ctx* ctx) {
 
 int lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* launches, double* flops, double* bytes) {
   LPGP_CHECK(kernel_id >= 0 && kernel_id < LPGP_K_COUNT, "lpgp_profile_get: bad kernel id");
+  LPGP_DEVICE(ctx);
   int rc = prof_collect(ctx);
   if (rc != 0) return rc;
   const ProfSlot& s = ctx->prof[kernel_id];
@@ -1058,6 +1149,7 @@ int lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* laun
 int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, int64_t m, int64_t n, int64_t k,
                    double alpha, const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
                    double* C, int64_t ldc, int32_t reps, double* ms_per_rep) {
+  LPGP_DEVICE(ctx);
   hipStream_t ts = ctx->s_main;
   if (const char* e = std::getenv("LPGP_TEST_GEMM_STREAM")) { const int v = std::atoi(e); ts = v == 1 ? ctx->s_upd : (v == 2 && ctx->s_upd_narrow ? ctx->s_upd_narrow : ctx->s_main); }
   LPGP_CHECK(m % TILE == 0 && n % TILE == 0 && k % 16 == 0, "lpgp_test_gemm: m,n multiples of 128 and k of 16 required");
@@ -1104,6 +1196,7 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
 }
 
 int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) {
+  LPGP_DEVICE(ctx);
   double *dT = nullptr, *dL = nullptr;
   LPGP_HIP(hipMalloc(&dT, (size_t)TILE * TILE * sizeof(double)));
   LPGP_HIP(hipMalloc(&dL, (size_t)TILE * TILE * sizeof(double)));
@@ -1125,6 +1218,7 @@ int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) 
 
 int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, int64_t n, const double* Linv, double* ms) {
   LPGP_CHECK(ctx && XV && Linv && n > 0 && n % TILE == 0 && (which == 0 || which == 1), "lpgp_test_tile_step: bad argument");
+  LPGP_DEVICE(ctx);
   double *d = nullptr, *dl = nullptr;
   const size_t bytes = (size_t)n * TILE * sizeof(double);
   LPGP_HIP(hipMalloc(&d, bytes));
@@ -1161,11 +1255,13 @@ int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, 
 
 int lpgp_debug_tile_xcc(lpgp_ctx* ctx, int32_t* out8, int32_t reset) {
   LPGP_CHECK(ctx && out8, "lpgp_debug_tile_xcc: null argument");
+  LPGP_DEVICE(ctx);
   LPGP_HIP(hipDeviceSynchronize());
   return debug_tile_xcc(out8, reset);
 }
 
 int lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops) {
+  LPGP_DEVICE(ctx);
   const int blocks = ctx->cus * 4, iters = 4000;
   double* d = nullptr;
   LPGP_HIP(hipMalloc(&d, (size_t)blocks * 256 * sizeof(double)));
@@ -1188,6 +1284,7 @@ int lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops) {
 }
 
 int lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps) {
+  LPGP_DEVICE(ctx);
   double* d = nullptr;
   bytes = round_up(bytes, 16);
   LPGP_HIP(hipMalloc(&d, (size_t)bytes));

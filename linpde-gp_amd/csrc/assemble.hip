@@ -17,261 +17,14 @@
 #include <cstring>
 
 #include "lpgp_internal.h"
+#include "eval_entries.h"
 
 namespace lpgp {
-
-// ---------------------------------------------------------------------------------------
-// host: polynomial tables
-// ---------------------------------------------------------------------------------------
-static long double ifact(int n) {
-  long double r = 1;
-  for (int i = 2; i <= n; ++i) r *= i;
-  return r;
-}
-
-// Integer numerators of P_n for Matern nu = p + 1/2 over the common denominator
-// D_p = (2p)!/p!  (c_k D_p = (2p-k)!/((p-k)! k!) 2^k are integers; P_n = P'_{n-1} - P_{n-1}).
-static void matern_poly(int p, int n, long double* out /* p+1 */) {
-  long double cur[16], nxt[16];
-  for (int k = 0; k <= p; ++k)
-    cur[k] = ifact(2 * p - k) / (ifact(p - k) * ifact(k)) * std::pow(2.0L, k);
-  for (int it = 0; it < n; ++it) {
-    for (int k = 0; k <= p; ++k) {
-      long double d = (k + 1 <= p) ? (k + 1) * cur[k + 1] : 0.0L;
-      nxt[k] = d - cur[k];
-    }
-    for (int k = 0; k <= p; ++k) cur[k] = nxt[k];
-  }
-  long double D = ifact(2 * p) / ifact(p);
-  // round to double exactly like float(Fraction(num, D)) and continue in long double
-  for (int k = 0; k <= p; ++k) out[k] = (long double)(double)(cur[k] / D);
-}
-
-// Integer numerators of P_n over D_p = (2p)!/p! (exact in long double for p <= 6, n <= 12).
-static long double matern_poly_num(int p, int n, long double* num /* p+1 */) {
-  long double cur[16], nxt[16];
-  for (int k = 0; k <= p; ++k)
-    cur[k] = ifact(2 * p - k) / (ifact(p - k) * ifact(k)) * std::pow(2.0L, k);
-  for (int it = 0; it < n; ++it) {
-    for (int k = 0; k <= p; ++k) nxt[k] = ((k + 1 <= p) ? (k + 1) * cur[k + 1] : 0.0L) - cur[k];
-    for (int k = 0; k <= p; ++k) cur[k] = nxt[k];
-  }
-  for (int k = 0; k <= p; ++k) num[k] = cur[k];
-  return ifact(2 * p) / ifact(p);
-}
-
-// Isotropic Matern with at most one derivative per argument (diffops/_matern.py:17-86,138-203):
-//   k = kappa(s), s = |u|, u = a .* (x - x');   d/dx_i k = (P_1/s) e^{-s} a_i u_i = -d/dx'_i k
-//   d/dx_i d/dx'_j k = -[ a_i a_j u_i u_j (P_2 - P_1/s)/s^2 + a_i^2 delta_ij P_1/s ] e^{-s}
-// summed over the term list into  e^{-s} [Q0(s) + (w.u) Q1(s) + (u^T B u) Q2(s)].
-static int lower_iso_group(const lpgp_kdesc& K, int d, DevGroup& G, double* coef, int& coef_used) {
-  const int p = K.p[0];
-  LPGP_CHECK(p >= 0 && p <= 6, "lower_kdesc: Matern p=%d unsupported", p);
-  long double a[LPGP_MAXD];
-  for (int j = 0; j < d; ++j) {
-    LPGP_CHECK(K.family[j] == LPGP_MATERN_ISO && K.p[j] == p,
-               "lower_kdesc: an isotropic Matern spans all dimensions with one nu");
-    LPGP_CHECK(K.lengthscale[j] > 0, "lower_kdesc: lengthscale must be positive");
-    const double as = std::sqrt(2.0 * (p + 0.5)) / K.lengthscale[j];
-    a[j] = as;
-    G.a[j] = as;
-    G.expkind[j] = 1;
-    G.deg[j] = 0;
-  }
-  G.deg[0] = p;
-  G.iso = 1;
-  long double c00 = 0, tr = 0, w[LPGP_MAXD] = {0, 0, 0, 0}, B[LPGP_MAXD][LPGP_MAXD] = {};
-  bool first = false, second = false;
-  for (int t = 0; t < K.nterms; ++t) {
-    const lpgp_term& T = K.terms[t];
-    int i0 = -1, i1 = -1, o0 = 0, o1 = 0;
-    for (int j = 0; j < d; ++j) {
-      LPGP_CHECK(T.n0[j] >= 0 && T.n1[j] >= 0, "lower_kdesc: derivative order out of range");
-      o0 += T.n0[j];
-      o1 += T.n1[j];
-      if (T.n0[j]) i0 = j;
-      if (T.n1[j]) i1 = j;
-    }
-    LPGP_CHECK(o0 <= 1 && o1 <= 1,
-               "lower_kdesc: the isotropic Matern has closed forms for identity and directional derivatives only");
-    if (T.coef == 0.0) continue;
-    if (!o0 && !o1) c00 += T.coef;
-    else if (o0 && !o1) { w[i0] += T.coef * a[i0]; first = true; }
-    else if (!o0 && o1) { w[i1] -= T.coef * a[i1]; first = true; }
-    else {
-      B[i0][i1] += T.coef * a[i0] * a[i1];
-      if (i0 == i1) tr += T.coef * a[i0] * a[i0];
-      second = true;
-    }
-  }
-  LPGP_CHECK(!first || p >= 1, "lower_kdesc: Matern-1/2 is not differentiable");
-  LPGP_CHECK(!second || p >= 2, "lower_kdesc: a multivariate Matern needs nu >= 5/2 for a derivative on both arguments");
-  long double P0[16], P1[16], P2[16];
-  const long double D = matern_poly_num(p, 0, P0);
-  matern_poly_num(p, 1, P1);
-  matern_poly_num(p, 2, P2);
-  LPGP_CHECK(coef_used + 3 * (p + 1) <= MAXCOEF, "lower_kdesc: coefficient table overflow");
-  double* Q0 = coef + coef_used;
-  double* Q1 = Q0 + (p + 1);
-  double* Q2 = Q1 + (p + 1);
-  for (int k = 0; k <= p; ++k) Q0[k] = Q1[k] = Q2[k] = 0.0;
-  // P_1 // s   (P_1(0) = 0 for p >= 1), rounded to double per coefficient like the reference's
-  // RationalPolynomial -> np.double conversion
-  long double P1s[16] = {0};
-  if (p >= 1) for (int k = 0; k < p; ++k) P1s[k] = P1[k + 1];
-  for (int k = 0; k <= p; ++k) {
-    Q0[k] = (double)(c00 * (long double)(double)(P0[k] / D) - tr * (long double)(double)(P1s[k] / D));
-    Q1[k] = (double)(P1s[k] / D);
-  }
-  if (p >= 2) {
-    // -(P_2 - P_1 // s) // s^2   (its two lowest coefficients vanish for p >= 2)
-    for (int k = 0; k + 2 <= p; ++k) Q2[k] = -(double)((P2[k + 2] - P1s[k + 2]) / D);
-  }
-  G.ncls = 3;
-  G.parity[0] = 0; G.parity[1] = 1; G.parity[2] = 1;
-  G.coef_off[0] = coef_used;
-  G.coef_off[1] = coef_used + (p + 1);
-  G.coef_off[2] = coef_used + 2 * (p + 1);
-  coef_used += 3 * (p + 1);
-  G.has_lin = first ? 1 : 0;
-  G.has_quad = second ? 1 : 0;
-  for (int i = 0; i < LPGP_MAXD; ++i) {
-    G.w[i] = (double)w[i];
-    // symmetric part only: u^T B u sees nothing else
-    for (int j = 0; j < LPGP_MAXD; ++j) G.B[i * LPGP_MAXD + j] = (double)(0.5L * (B[i][j] + B[j][i]));
-  }
-  return 0;
-}
-
-// Probabilists' Hermite He_n, ascending coefficients, degree n.
-static void hermite_poly(int n, long double* out /* n+1 */) {
-  long double a[16] = {1}, b[16];
-  int deg = 0;
-  for (int it = 0; it < n; ++it) {
-    for (int k = 0; k <= deg + 1; ++k) b[k] = 0;
-    for (int k = 0; k <= deg; ++k) b[k + 1] += a[k];            // u * He
-    for (int k = 1; k <= deg; ++k) b[k - 1] -= k * a[k];        // - He'
-    ++deg;
-    for (int k = 0; k <= deg; ++k) a[k] = b[k];
-  }
-  for (int k = 0; k <= n; ++k) out[k] = a[k];
-}
-
-int lower_kdesc(const lpgp_kdesc* kd, int ngroups, DevDesc* out) {
-  LPGP_CHECK(kd != nullptr && ngroups >= 1 && ngroups <= LPGP_MAXG, "lower_kdesc: bad ngroups %d", ngroups);
-  std::memset(out, 0, sizeof(*out));
-  const int d = kd[0].d;
-  LPGP_CHECK(d >= 1 && d <= LPGP_MAXD, "lower_kdesc: d=%d out of range", d);
-  out->d = d;
-  out->ngroups = ngroups;
-  int coef_used = 0;
-  for (int g = 0; g < ngroups; ++g) {
-    const lpgp_kdesc& K = kd[g];
-    LPGP_CHECK(K.d == d, "lower_kdesc: group %d has d=%d != %d", g, K.d, d);
-    LPGP_CHECK(K.nterms >= 1 && K.nterms <= LPGP_MAXT, "lower_kdesc: nterms=%d", K.nterms);
-    DevGroup& G = out->g[g];
-    G.scale = K.scale;
-    if (K.family[0] == LPGP_MATERN_ISO) {
-      int rc = lower_iso_group(K, d, G, out->coef, coef_used);
-      if (rc != 0) return rc;
-      continue;
-    }
-    long double a[LPGP_MAXD];
-    for (int j = 0; j < d; ++j) {
-      LPGP_CHECK(K.lengthscale[j] > 0, "lower_kdesc: lengthscale must be positive");
-      if (K.family[j] == LPGP_MATERN_HALFINT) {
-        LPGP_CHECK(K.p[j] >= 0 && K.p[j] <= 6, "lower_kdesc: Matern p=%d unsupported", K.p[j]);
-        // probnum Matern._scale_factors = sqrt(2 nu) / lengthscale, in fp64 like the reference
-        double as = std::sqrt(2.0 * (K.p[j] + 0.5)) / K.lengthscale[j];
-        a[j] = as;
-        G.expkind[j] = 1;
-      } else if (K.family[j] == LPGP_EXPQUAD) {
-        a[j] = 1.0 / K.lengthscale[j];
-        G.expkind[j] = 2;
-      } else {
-        LPGP_CHECK(false, "lower_kdesc: unknown family %d", K.family[j]);
-      }
-      G.a[j] = (double)a[j];
-    }
-    // degrees
-    for (int j = 0; j < d; ++j) {
-      int deg = 0;
-      for (int t = 0; t < K.nterms; ++t) {
-        int n = K.terms[t].n0[j] + K.terms[t].n1[j];
-        LPGP_CHECK(K.terms[t].n0[j] >= 0 && K.terms[t].n1[j] >= 0 && n <= 12,
-                   "lower_kdesc: derivative order out of range");
-        int dg = (K.family[j] == LPGP_MATERN_HALFINT) ? K.p[j] : n;
-        if (dg > deg) deg = dg;
-      }
-      G.deg[j] = deg;
-    }
-    int tsize = 1;
-    for (int j = 0; j < d; ++j) tsize *= (G.deg[j] + 1);
-    // accumulate per parity class
-    std::vector<std::vector<long double>> cls(1 << d);
-    for (int t = 0; t < K.nterms; ++t) {
-      const lpgp_term& T = K.terms[t];
-      int parity = 0;
-      long double pref = T.coef;
-      long double q[LPGP_MAXD][16];
-      int qdeg[LPGP_MAXD];
-      for (int j = 0; j < d; ++j) {
-        int n = T.n0[j] + T.n1[j];
-        if (n & 1) parity |= (1 << j);
-        pref *= std::pow(a[j], n);
-        if (K.family[j] == LPGP_MATERN_HALFINT) {
-          if (T.n1[j] & 1) pref = -pref;
-          matern_poly(K.p[j], n, q[j]);
-          qdeg[j] = K.p[j];
-        } else {
-          if (T.n0[j] & 1) pref = -pref;
-          hermite_poly(n, q[j]);
-          qdeg[j] = n;
-        }
-      }
-      auto& C = cls[parity];
-      if (C.empty()) C.assign(tsize, 0.0L);
-      // tensor product of the per-dim polynomials
-      int idx[LPGP_MAXD] = {0, 0, 0, 0};
-      for (;;) {
-        long double v = pref;
-        int lin = 0;
-        for (int j = 0; j < d; ++j) {
-          v *= q[j][idx[j]];
-          lin = lin * (G.deg[j] + 1) + idx[j];
-        }
-        C[lin] += v;
-        int j = d - 1;
-        while (j >= 0) {
-          if (++idx[j] <= qdeg[j]) break;
-          idx[j] = 0;
-          --j;
-        }
-        if (j < 0) break;
-      }
-    }
-    G.ncls = 0;
-    for (int c = 0; c < (1 << d); ++c) {
-      if (cls[c].empty()) continue;
-      bool nz = false;
-      for (long double v : cls[c]) nz |= (v != 0.0L);
-      if (!nz) continue;
-      LPGP_CHECK(coef_used + tsize <= MAXCOEF, "lower_kdesc: coefficient table overflow");
-      G.parity[G.ncls] = c;
-      G.coef_off[G.ncls] = coef_used;
-      for (int i = 0; i < tsize; ++i) out->coef[coef_used + i] = (double)cls[c][i];
-      coef_used += tsize;
-      ++G.ncls;
-    }
-  }
-  return 0;
-}
 
 // ---------------------------------------------------------------------------------------
 // device kernel
 // ---------------------------------------------------------------------------------------
 constexpr int AT = 64;          // tile: 64 rows x 64 cols per workgroup (256 threads)
-constexpr int AE = 8;           // entries per thread per pass (1 row x 8 cols)
 
 struct AsmArgs {
   const double* x0;             // SoA rows
@@ -286,153 +39,6 @@ struct AsmArgs {
   int32_t own_world, own_rank;  // distributed factorisation: only tile columns of panels owned by this rank
   int64_t own_from, own_width;
 };
-
-template <int D>
-__device__ __forceinline__ void eval_entries(const DevDesc* __restrict__ desc,
-                                             const double (&dx)[D][AE], double (&res)[AE]) {
-#pragma unroll
-  for (int e = 0; e < AE; ++e) res[e] = 0.0;
-  for (int g = 0; g < desc->ngroups; ++g) {
-    const DevGroup& G = desc->g[g];
-    if (G.iso) {
-      // isotropic Matern: e^{-s} [Q0(s) + (w.u) Q1(s) + (u^T B u) Q2(s)],  u = a .* dx, s = |u|
-      double s2[AE], lin[AE], quad[AE];
-#pragma unroll
-      for (int e = 0; e < AE; ++e) { s2[e] = 0.0; lin[e] = 0.0; quad[e] = 0.0; }
-      double u[D][AE];
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const double a = G.a[j], wj = G.w[j];
-#pragma unroll
-        for (int e = 0; e < AE; ++e) {
-          u[j][e] = a * dx[j][e];
-          s2[e] = fma(u[j][e], u[j][e], s2[e]);
-          lin[e] = fma(wj, u[j][e], lin[e]);
-        }
-      }
-      if (G.has_quad) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          double bu[AE];
-#pragma unroll
-          for (int e = 0; e < AE; ++e) bu[e] = 0.0;
-#pragma unroll
-          for (int j = 0; j < D; ++j) {
-            const double bij = G.B[i * LPGP_MAXD + j];
-#pragma unroll
-            for (int e = 0; e < AE; ++e) bu[e] = fma(bij, u[j][e], bu[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < AE; ++e) quad[e] = fma(u[i][e], bu[e], quad[e]);
-        }
-      }
-      const double* __restrict__ q0 = desc->coef + G.coef_off[0];
-      const double* __restrict__ q1 = desc->coef + G.coef_off[1];
-      const double* __restrict__ q2 = desc->coef + G.coef_off[2];
-      double sv[AE], v0[AE], v1[AE], v2[AE];
-#pragma unroll
-      for (int e = 0; e < AE; ++e) { sv[e] = sqrt(s2[e]); v0[e] = 0.0; v1[e] = 0.0; v2[e] = 0.0; }
-      for (int k = G.deg[0]; k >= 0; --k) {
-        const double c0 = q0[k], c1 = q1[k], c2 = q2[k];
-#pragma unroll
-        for (int e = 0; e < AE; ++e) {
-          v0[e] = fma(v0[e], sv[e], c0);
-          v1[e] = fma(v1[e], sv[e], c1);
-          v2[e] = fma(v2[e], sv[e], c2);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < AE; ++e)
-        res[e] = fma(G.scale * exp(-sv[e]), fma(quad[e], v2[e], fma(lin[e], v1[e], v0[e])), res[e]);
-      continue;
-    }
-    double r[D][AE];
-    unsigned sg[D][AE];
-    double expo[AE];
-#pragma unroll
-    for (int e = 0; e < AE; ++e) expo[e] = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const double a = G.a[j];
-      const int kind = G.expkind[j];
-#pragma unroll
-      for (int e = 0; e < AE; ++e) {
-        double v = a * dx[j][e];
-        sg[j][e] = ((unsigned)__double2hiint(v)) & 0x80000000u;
-        r[j][e] = fabs(v);
-        expo[e] += (kind == 1) ? r[j][e] : 0.5 * r[j][e] * r[j][e];
-      }
-    }
-    double tot[AE];
-#pragma unroll
-    for (int e = 0; e < AE; ++e) tot[e] = 0.0;
-    const int n1 = (D > 1) ? G.deg[D > 1 ? 1 : 0] + 1 : 1;
-    const int n2 = (D > 2) ? G.deg[D > 2 ? 2 : 0] + 1 : 1;
-    const int n3 = (D > 3) ? G.deg[D > 3 ? 3 : 0] + 1 : 1;
-    for (int c = 0; c < G.ncls; ++c) {
-      const double* __restrict__ cf = desc->coef + G.coef_off[c];
-      const int par = G.parity[c];
-      double acc0[AE];
-#pragma unroll
-      for (int e = 0; e < AE; ++e) acc0[e] = 0.0;
-      for (int i0 = G.deg[0]; i0 >= 0; --i0) {
-        if constexpr (D == 1) {
-          const double cv = cf[i0];
-#pragma unroll
-          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], cv);
-        } else {
-          double acc1[AE];
-#pragma unroll
-          for (int e = 0; e < AE; ++e) acc1[e] = 0.0;
-          for (int i1 = n1 - 1; i1 >= 0; --i1) {
-            if constexpr (D == 2) {
-              const double cv = cf[i0 * n1 + i1];
-#pragma unroll
-              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], cv);
-            } else {
-              double acc2[AE];
-#pragma unroll
-              for (int e = 0; e < AE; ++e) acc2[e] = 0.0;
-              for (int i2 = n2 - 1; i2 >= 0; --i2) {
-                if constexpr (D == 3) {
-                  const double cv = cf[(i0 * n1 + i1) * n2 + i2];
-#pragma unroll
-                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], cv);
-                } else {
-                  double acc3[AE];
-#pragma unroll
-                  for (int e = 0; e < AE; ++e) acc3[e] = 0.0;
-                  for (int i3 = n3 - 1; i3 >= 0; --i3) {
-                    const double cv = cf[((i0 * n1 + i1) * n2 + i2) * n3 + i3];
-#pragma unroll
-                    for (int e = 0; e < AE; ++e) acc3[e] = fma(acc3[e], r[D - 1][e], cv);
-                  }
-#pragma unroll
-                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], acc3[e]);
-                }
-              }
-#pragma unroll
-              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], acc2[e]);
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
-        }
-      }
-      // sign of the parity class: prod_{d in class} sign(x_d - x'_d)
-#pragma unroll
-      for (int e = 0; e < AE; ++e) {
-        unsigned s = 0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) s ^= ((par >> j) & 1) ? sg[j][e] : 0u;
-        double v = __hiloint2double((int)(((unsigned)__double2hiint(acc0[e])) ^ s), __double2loint(acc0[e]));
-        tot[e] += v;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * exp(-expo[e]), tot[e], res[e]);
-  }
-}
 
 template <int D>
 __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
@@ -963,7 +569,7 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
   dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
   const double entries = lower_only ? 0.5 * (double)a.n0 * ((double)a.n0 + 1.0) : (double)a.n0 * (double)a.n1;
-  prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+  prof_begin(ctx, stream, LPGP_K_ASSEMBLE_GRID, 0.0, 8.0 * entries);
   if (D == 2 && a.nuniq[1] <= 8 && a.n0d[1] >= 32 && a.n1d[1] >= 16) {
     const int ftr = (a.n0d[1] + 63) / 64, ftc = (a.n1d[1] + 31) / 32;
     const int64_t chunks = ((int64_t)a.n0d[0] * a.n1d[0] + KR_PAIRS - 1) / KR_PAIRS;

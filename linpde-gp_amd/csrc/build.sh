@@ -1,9 +1,19 @@
 #!/bin/bash
 # Build liblpgp.so for gfx950 (MI355X) in-tree.  Usage: build.sh [extra hipcc flags]
+#        build.sh --host-asan   host-only TEST library of the descriptor lowering, g++ -fsanitize=address
+#                               (csrc/hosttest/liblpgp_hosttest_asan.so; never loaded by the product)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/../linpde_gp_amd/_lib"
+if [[ "${1:-}" == "--host-asan" ]]; then
+  CXX="${CXX:-g++}"
+  "$CXX" -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined \
+    -shared -fPIC -Wall -Wno-unknown-pragmas -I"$ROOT/include" -I"$HERE" \
+    "$HERE/lower.cpp" "$HERE/hosttest/host_check.cpp" -o "$HERE/hosttest/liblpgp_hosttest_asan.so"
+  echo "built $HERE/hosttest/liblpgp_hosttest_asan.so"
+  exit 0
+fi
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
@@ -12,7 +22,9 @@ for f in api assemble gemm potrf; do
   "$HIPCC" $FLAGS "$@" -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
+"$HIPCC" -O2 -std=c++17 -fPIC -I"$ROOT/include" -I"$HERE" -Wall -c "$HERE/lower.cpp" -o "$OUT/lower.o" &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp.so" "$OUT/api.o" "$OUT/assemble.o" "$OUT/gemm.o" "$OUT/potrf.o" \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp.so" "$OUT/api.o" "$OUT/assemble.o" "$OUT/gemm.o" "$OUT/potrf.o" "$OUT/lower.o" \
   -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/liblpgp.so"

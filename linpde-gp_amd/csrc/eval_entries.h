@@ -1,0 +1,193 @@
+// Evaluation of one lowered kernel descriptor (`DevDesc`) on AE coordinate differences per call:
+// the arithmetic core of assemble_kernel / matvec_kernel (assemble.hip).  Kept in a header so that
+// the host-only AddressSanitizer build (`build.sh --host-asan`, csrc/hosttest/) runs the SAME code on
+// the CPU against the lowering under test.  Under hipcc this is device code; the host compiler sees
+// plain C++ (that build is test infrastructure: nothing in the product calls the host instantiation).
+#pragma once
+
+#include <cmath>
+#include <cstring>
+
+#include "lpgp_desc.h"
+
+#if defined(__HIPCC__)
+#define LPGP_HD __device__ __forceinline__
+#else
+#define LPGP_HD inline
+#endif
+
+namespace lpgp {
+
+constexpr int AE = 8;           // entries per thread per pass (1 row x 8 cols)
+
+LPGP_HD unsigned lpgp_hi32(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)__double2hiint(v);
+#else
+  unsigned long long b;
+  std::memcpy(&b, &v, 8);
+  return (unsigned)(b >> 32);
+#endif
+}
+
+// v with its sign bit XORed by `s` (s = 0 or 0x80000000)
+LPGP_HD double lpgp_xor_sign(double v, unsigned s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double((int)(((unsigned)__double2hiint(v)) ^ s), __double2loint(v));
+#else
+  unsigned long long b;
+  std::memcpy(&b, &v, 8);
+  b ^= ((unsigned long long)s) << 32;
+  std::memcpy(&v, &b, 8);
+  return v;
+#endif
+}
+
+template <int D>
+LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
+                                             const double (&dx)[D][AE], double (&res)[AE]) {
+#pragma unroll
+  for (int e = 0; e < AE; ++e) res[e] = 0.0;
+  for (int g = 0; g < desc->ngroups; ++g) {
+    const DevGroup& G = desc->g[g];
+    if (G.iso) {
+      // isotropic Matern: e^{-s} [Q0(s) + (w.u) Q1(s) + (u^T B u) Q2(s)],  u = a .* dx, s = |u|
+      double s2[AE], lin[AE], quad[AE];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) { s2[e] = 0.0; lin[e] = 0.0; quad[e] = 0.0; }
+      double u[D][AE];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const double a = G.a[j], wj = G.w[j];
+#pragma unroll
+        for (int e = 0; e < AE; ++e) {
+          u[j][e] = a * dx[j][e];
+          s2[e] = fma(u[j][e], u[j][e], s2[e]);
+          lin[e] = fma(wj, u[j][e], lin[e]);
+        }
+      }
+      if (G.has_quad) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double bu[AE];
+#pragma unroll
+          for (int e = 0; e < AE; ++e) bu[e] = 0.0;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const double bij = G.B[i * LPGP_MAXD + j];
+#pragma unroll
+            for (int e = 0; e < AE; ++e) bu[e] = fma(bij, u[j][e], bu[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < AE; ++e) quad[e] = fma(u[i][e], bu[e], quad[e]);
+        }
+      }
+      const double* __restrict__ q0 = desc->coef + G.coef_off[0];
+      const double* __restrict__ q1 = desc->coef + G.coef_off[1];
+      const double* __restrict__ q2 = desc->coef + G.coef_off[2];
+      double sv[AE], v0[AE], v1[AE], v2[AE];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) { sv[e] = sqrt(s2[e]); v0[e] = 0.0; v1[e] = 0.0; v2[e] = 0.0; }
+      for (int k = G.deg[0]; k >= 0; --k) {
+        const double c0 = q0[k], c1 = q1[k], c2 = q2[k];
+#pragma unroll
+        for (int e = 0; e < AE; ++e) {
+          v0[e] = fma(v0[e], sv[e], c0);
+          v1[e] = fma(v1[e], sv[e], c1);
+          v2[e] = fma(v2[e], sv[e], c2);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < AE; ++e)
+        res[e] = fma(G.scale * exp(-sv[e]), fma(quad[e], v2[e], fma(lin[e], v1[e], v0[e])), res[e]);
+      continue;
+    }
+    double r[D][AE];
+    unsigned sg[D][AE];
+    double expo[AE];
+#pragma unroll
+    for (int e = 0; e < AE; ++e) expo[e] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double a = G.a[j];
+      const int kind = G.expkind[j];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        double v = a * dx[j][e];
+        sg[j][e] = lpgp_hi32(v) & 0x80000000u;
+        r[j][e] = fabs(v);
+        expo[e] += (kind == 1) ? r[j][e] : 0.5 * r[j][e] * r[j][e];
+      }
+    }
+    double tot[AE];
+#pragma unroll
+    for (int e = 0; e < AE; ++e) tot[e] = 0.0;
+    const int n1 = (D > 1) ? G.deg[D > 1 ? 1 : 0] + 1 : 1;
+    const int n2 = (D > 2) ? G.deg[D > 2 ? 2 : 0] + 1 : 1;
+    const int n3 = (D > 3) ? G.deg[D > 3 ? 3 : 0] + 1 : 1;
+    for (int c = 0; c < G.ncls; ++c) {
+      const double* __restrict__ cf = desc->coef + G.coef_off[c];
+      const int par = G.parity[c];
+      double acc0[AE];
+#pragma unroll
+      for (int e = 0; e < AE; ++e) acc0[e] = 0.0;
+      for (int i0 = G.deg[0]; i0 >= 0; --i0) {
+        if constexpr (D == 1) {
+          const double cv = cf[i0];
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], cv);
+        } else {
+          double acc1[AE];
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc1[e] = 0.0;
+          for (int i1 = n1 - 1; i1 >= 0; --i1) {
+            if constexpr (D == 2) {
+              const double cv = cf[i0 * n1 + i1];
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], cv);
+            } else {
+              double acc2[AE];
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc2[e] = 0.0;
+              for (int i2 = n2 - 1; i2 >= 0; --i2) {
+                if constexpr (D == 3) {
+                  const double cv = cf[(i0 * n1 + i1) * n2 + i2];
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], cv);
+                } else {
+                  double acc3[AE];
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc3[e] = 0.0;
+                  for (int i3 = n3 - 1; i3 >= 0; --i3) {
+                    const double cv = cf[((i0 * n1 + i1) * n2 + i2) * n3 + i3];
+#pragma unroll
+                    for (int e = 0; e < AE; ++e) acc3[e] = fma(acc3[e], r[D - 1][e], cv);
+                  }
+#pragma unroll
+                  for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], acc3[e]);
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], acc2[e]);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
+        }
+      }
+      // sign of the parity class: prod_{d in class} sign(x_d - x'_d)
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        unsigned s = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s ^= ((par >> j) & 1) ? sg[j][e] : 0u;
+        double v = lpgp_xor_sign(acc0[e], s);
+        tot[e] += v;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * exp(-expo[e]), tot[e], res[e]);
+  }
+}
+
+}  // namespace lpgp

@@ -728,12 +728,7 @@ __global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
 int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel) {
   if (mt <= 0) return 0;
   const size_t shmem = (size_t)LSTAGES * TS_STAGE * sizeof(double);       // 79 872 B: fits beside ONE 73-KB GEMM workgroup
-  static bool attr_set = false;
-  if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&trsm_tile_kernel), shmem));
   TrsmTileArgs a;
   a.X = X; a.ldx = ldx; a.linv = linv; a.slabs = mt * 2;
   if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)mt * TILE * TILE * TILE, 0.0);
@@ -860,12 +855,7 @@ __global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
 int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel) {
   if (nt <= 0) return 0;
   const size_t shmem = (size_t)LSTAGES * (8 * LDP2 + 1024) * sizeof(double);       // 76 800 B: fits beside ONE 73-KB GEMM workgroup
-  static bool attr_set = false;
-  if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&trsv_tile_kernel), shmem));
   TrsvTileArgs a;
   a.V = V; a.ldv = ldv; a.linv = linv;
   if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)nt * TILE * TILE * TILE, 0.0);
@@ -878,12 +868,7 @@ int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, 
 template <bool TA, bool TB, int TRI>
 static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   const size_t shmem = (size_t)SSTAGES * 2 * SOPER * sizeof(double);      // 73 728 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_f64_kernel<TA, TB, TRI>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm64_f64_kernel<TA, TB, TRI>), shmem));
   const unsigned blocks = (unsigned)(g.mt * 2) * (unsigned)(g.nt * 2);
   hipLaunchKernelGGL((gemm64_f64_kernel<TA, TB, TRI>), dim3(blocks), dim3(256), shmem, stream, g);
   LPGP_HIP(hipGetLastError());
@@ -892,13 +877,8 @@ static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
 
 template <bool TA, bool TB, int TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
-  static bool attr_set = false;
   const size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
-  if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>), shmem));
   GemmArgs ga = g;
   if (ctx->dense_tiles && (g.mt + BAND - 1) / BAND <= GemmArgs::MAXB) {
     ga.dense = 1;

@@ -9,12 +9,12 @@
 #include <vector>
 
 #include "lpgp.h"
+#include "lpgp_desc.h"
 
 namespace lpgp {
 
 constexpr int TILE = 128;          // base tile: potrf_tile block, GEMM block tile, padding unit
 
-void set_error(const char* fmt, ...);
 
 #define LPGP_HIP(expr)                                                              \
   do {                                                                              \
@@ -26,48 +26,12 @@ void set_error(const char* fmt, ...);
     }                                                                               \
   } while (0)
 
-#define LPGP_CHECK(cond, ...)                                                       \
-  do {                                                                              \
-    if (!(cond)) {                                                                  \
-      ::lpgp::set_error(__VA_ARGS__);                                               \
-      return -2;                                                                    \
-    }                                                                               \
+#define LPGP_TRY_RC(expr)         \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != 0) return _rc;     \
   } while (0)
-
-inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-// ---- lowered kernel descriptor (device form) ------------------------------------------
-// entry = sum_g scale_g * exp(-sum_d E_d(r_d)) * sum_c sgn^{parity_c} Poly_c(r_1..r_d),
-// r_d = |a_d (x_d - x'_d)|, E = r (Matern) or r^2/2 (ExpQuad); Poly_c dense nested-Horner
-// coefficient tensor.  Built on the host by lower_kdesc (assemble.hip).
-constexpr int MAXCLS = 16;         // parity classes (2^d, d <= 4)
-constexpr int MAXCOEF = 2048;      // coefficient doubles over all groups
-
-struct DevGroup {
-  double scale;
-  double a[LPGP_MAXD];
-  int32_t expkind[LPGP_MAXD];      // 1: exp(-r), 2: exp(-r^2/2)
-  int32_t deg[LPGP_MAXD];          // polynomial degree per dim
-  int32_t ncls;
-  int32_t parity[MAXCLS];          // bit d set => factor sign(x_d - x'_d)
-  int32_t coef_off[MAXCLS];        // offset into coef[]
-  // isotropic Matern group (LPGP_MATERN_ISO): with u = a .* (x - x'), s = |u|,
-  //   entry = scale * exp(-s) * [ Q0(s) + (w . u) Q1(s) + (u^T B u) Q2(s) ],
-  // Q0, Q1, Q2 of degree deg[0] at coef_off[0..2] (ncls = 3; parity[0] = 0 so that the constant
-  // coefficient of Q0 is the diagonal value, as for the product form)
-  int32_t iso, has_lin, has_quad;
-  double w[LPGP_MAXD];
-  double B[LPGP_MAXD * LPGP_MAXD];
-};
-
-struct DevDesc {
-  int32_t d;
-  int32_t ngroups;
-  DevGroup g[LPGP_MAXG];
-  double coef[MAXCOEF];
-};
-
-int lower_kdesc(const lpgp_kdesc* kd, int ngroups, DevDesc* out);
+#define LPGP_TRY(expr) LPGP_TRY_RC(expr)
 
 // ---- profiling -------------------------------------------------------------------------
 struct ProfSlot {
@@ -138,6 +102,9 @@ struct lpgp_ctx {
   bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr; }
   double* d_pack = nullptr;        // packed panel staging for the broadcast
   size_t pack_cap = 0;             // doubles
+  // kernels whose dynamic-LDS attribute has been raised on THIS context's device (the attribute is
+  // per device, a process-wide flag would skip it for a second context on another GPU)
+  std::vector<const void*> lds_attr_done;
   // profiling
   int prof_on = 0;                 // bit k: bracket launches of kernel id k with HIP events
   int prof_open = 0;
@@ -167,10 +134,12 @@ struct lpgp_mat {
   double* a;                       // device cap x cap column-major (lower part meaningful)
   double* linv;                    // device (cap/TILE) tiles of TILE x TILE: inverse of each diagonal tile of L
   double* w;                       // device 2*cap: [representer weights | residual r] (padded layout)
-  std::vector<lpgp_block> blocks;
-  int64_t n;                       // logical size
-  int64_t pn;                      // padded size in use
-  int64_t pn_fact;                 // padded columns factored so far
+  std::vector<lpgp_block> blocks;  // blocks of the current VIEW (lpgp_mat_set_view): a leading run of the observation blocks
+  std::vector<lpgp_block> hidden;  // blocks behind the view (appended by later conditionings; their part of the factor stays in place)
+  int64_t n;                       // logical size (of the view)
+  int64_t pn;                      // padded size in use (of the view)
+  int64_t pn_fact;                 // padded columns factored so far (of the view)
+  int64_t pn_fact_all = 0;         // the same over view + hidden blocks (meaningful while hidden is non-empty)
   int has_w;
   int has_r;                       // residual resident (lpgp_mat_set_residual)
   double* r() const { return w + cap; }
@@ -186,6 +155,22 @@ struct lpgp_rhs {
 };
 
 namespace lpgp {
+
+// every C-ABI entry point runs on its context's device whatever the calling thread's current device is
+#define LPGP_DEVICE(ctx)                                        \
+  do {                                                          \
+    LPGP_CHECK((ctx) != nullptr, "null context handle");        \
+    LPGP_HIP(hipSetDevice((ctx)->device));                      \
+  } while (0)
+
+// raise the dynamic shared-memory limit of `fn` once per context (= per device)
+inline int ensure_lds_attr(lpgp_ctx* ctx, const void* fn, size_t bytes) {
+  for (const void* f : ctx->lds_attr_done)
+    if (f == fn) return 0;
+  LPGP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  ctx->lds_attr_done.push_back(fn);
+  return 0;
+}
 
 // device memory pool (api.hip)
 int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh);

@@ -301,13 +301,8 @@ int debug_tile_xcc(int32_t* out8, int reset) {
 
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base) {
-  static bool attr_set = false;
   const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
-  if (!attr_set) {
-    LPGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&potrf_tile_kernel), shmem));
   prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
   hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
   prof_end(ctx, stream);
@@ -335,12 +330,6 @@ static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, double* X, int64_t l
   g.mt = mt; g.nt = 1; g.k = TILE; g.alpha = 1.0; g.beta = 0.0; g.tri = 0;
   return launch_gemm(ctx, st, 0, 0, g, LPGP_K_TRSM);
 }
-
-#define LPGP_TRY(expr)            \
-  do {                            \
-    int _rc = (expr);             \
-    if (_rc != 0) return _rc;     \
-  } while (0)
 
 // Factor tile columns [c0, cl) (all rows down to T) right-looking by panels of nb columns with a
 // look-ahead of one panel; the rank-nb updates touch only columns < cl (cl == T: the whole trailing

@@ -217,12 +217,13 @@ def as_points(ctx: Context, X_original, X_flat: np.ndarray) -> Points:
 class GramMatrix:
     """Block Gram matrix that becomes its own Cholesky factor (`lpgp_mat_*`, `lpgp_potrf`)."""
 
-    def __init__(self, ctx: Context, capacity_hint: int = 0):
+    def __init__(self, ctx: Context, capacity_hint: int = 0, _handle=None, _block_sizes=None):
         self.ctx = ctx
-        h = C.c_void_p()
-        check(lib.lpgp_mat_create(ctx._h, int(capacity_hint), C.byref(h)), "lpgp_mat_create")
-        self._h = h
-        self.block_sizes: list[int] = []
+        if _handle is None:
+            _handle = C.c_void_p()
+            check(lib.lpgp_mat_create(ctx._h, int(capacity_hint), C.byref(_handle)), "lpgp_mat_create")
+        self._h = _handle
+        self.block_sizes: list[int] = list(_block_sizes or [])
 
     def __del__(self):  # pragma: no cover
         if getattr(self, "_h", None) and self.ctx._h:
@@ -243,6 +244,30 @@ class GramMatrix:
             check(bi, "lpgp_mat_add_block")
         self.block_sizes.append(int(n))
         return bi
+
+    def pop_block(self) -> None:
+        """Undo the last `add_block` (its block not factored): rollback of a failed conditioning."""
+        check(lib.lpgp_mat_pop_block(self.ctx._h, self._h), "lpgp_mat_pop_block")
+        self.block_sizes.pop()
+
+    @property
+    def num_blocks(self) -> int:
+        """Blocks in view."""
+        return int(lib.lpgp_mat_num_blocks(self._h))
+
+    @property
+    def num_blocks_total(self) -> int:
+        return int(lib.lpgp_mat_num_blocks_total(self._h))
+
+    def set_view(self, nblocks: int) -> None:
+        """Restrict every solve / prediction to the leading `nblocks` blocks (-1: all), i.e. to the
+        factor an earlier conditioning produced (`lpgp_mat_set_view`)."""
+        check(lib.lpgp_mat_set_view(self.ctx._h, self._h, int(nblocks)), "lpgp_mat_set_view")
+
+    def clone(self, nblocks: int) -> "GramMatrix":
+        h = C.c_void_p()
+        check(lib.lpgp_mat_clone(self.ctx._h, self._h, int(nblocks), C.byref(h)), "lpgp_mat_clone")
+        return GramMatrix(self.ctx, _handle=h, _block_sizes=self.block_sizes[:nblocks])
 
     def assemble(self, kdesc, X0: Points, X1: Points | None, bi: int, bj: int):
         arr = _lib.make_kdesc_array(kdesc)

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "liblpgp.so")
 MAXD, MAXT, MAXG = 4, 64, 4
 MATERN_HALFINT, EXPQUAD, MATERN_ISO = 1, 2, 3
 K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec", "syrk_lookahead")
+KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec", "syrk_lookahead",
+                "assemble_grid", "panel_fused")
 
 
 class Term(C.Structure):
@@ -76,6 +77,11 @@ def _load() -> C.CDLL:
     sig("lpgp_mat_create", C.c_int, vp, i64, C.POINTER(vp))
     sig("lpgp_mat_destroy", C.c_int, vp)
     sig("lpgp_mat_add_block", C.c_int, vp, vp, i64)
+    sig("lpgp_mat_pop_block", C.c_int, vp, vp)
+    sig("lpgp_mat_set_view", C.c_int, vp, vp, i32)
+    sig("lpgp_mat_num_blocks", i32, vp)
+    sig("lpgp_mat_num_blocks_total", i32, vp)
+    sig("lpgp_mat_clone", C.c_int, vp, vp, i32, C.POINTER(vp))
     sig("lpgp_mat_size", i64, vp)
     sig("lpgp_mat_padded_size", i64, vp)
     sig("lpgp_gram_assemble", C.c_int, vp, pk, i32, vp, vp, vp, i32, i32)
@@ -114,7 +120,8 @@ lib = _load()
 EXPORTED = [
     "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
     "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_dist_init_host", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
-    "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_size", "lpgp_mat_padded_size",
+    "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_pop_block", "lpgp_mat_set_view", "lpgp_mat_num_blocks",
+    "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",

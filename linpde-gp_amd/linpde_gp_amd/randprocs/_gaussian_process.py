@@ -121,14 +121,31 @@ class _GramOperator:
 
 
 class _DeviceState:
-    """Device-resident state shared along a chain of conditionings."""
+    """Device-resident state shared along a chain of conditionings: ONE matrix whose leading
+    blocks are the factor of every earlier posterior of the chain (a block append never touches the
+    leading part of the factor).  A posterior object uses the leading `len(blocks)` blocks through a
+    view (`lpgp_mat_set_view`), so earlier objects of the chain stay usable; conditioning an object
+    that has already been extended (branching) continues on a copy of its part of the factor."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, mat=None):
         from .. import config
 
         self.ctx = ctx
-        self.mat = _engine.GramMatrix(ctx, capacity_hint=config.gram_capacity_hint)
-        self.generation = 0
+        self.mat = mat if mat is not None else _engine.GramMatrix(ctx, capacity_hint=config.gram_capacity_hint)
+        self.view = None             # number of blocks the device-resident weights / residual belong to
+        self.weights_key = None
+        self.residual_key = None
+
+    def use(self, nblocks: int) -> None:
+        """Make the leading `nblocks` blocks the matrix every following call sees."""
+        if nblocks == 0:
+            return
+        if self.mat.num_blocks != nblocks:
+            self.mat.set_view(nblocks)
+        if self.view != nblocks:
+            self.view = nblocks
+            self.weights_key = None
+            self.residual_key = None
 
 
 class ConditionalGaussianProcess(GaussianProcess):
@@ -145,10 +162,37 @@ class ConditionalGaussianProcess(GaussianProcess):
             # no observations: nothing to assemble or factor, the factor in HBM stays as it is (and
             # stays valid for the object this one was derived from)
             return cls(prior=prior, blocks=tuple(old_blocks), state=state, representer_weights=None)
+        if state.mat.num_blocks_total != len(old_blocks):
+            # the object being conditioned has already been extended by another conditioning: this one
+            # branches off on its own copy of the leading part of the factor (multi-GPU: not supported)
+            state = _DeviceState(state.ctx, state.mat.clone(len(old_blocks)))
+        state.use(len(old_blocks))
         mat = state.mat
         base = prior.cov
         bi = mat.add_block(new_block.points.n)
         assert bi == len(old_blocks)
+        try:
+            info = cls._assemble_and_factor(mat, base, bi, old_blocks, new_block)
+        except BaseException:
+            # a failed conditioning leaves the object it was called on intact (as in the reference):
+            # drop the block again; the leading factor was never touched
+            try:
+                mat.pop_block()
+            except Exception:  # noqa: BLE001  (the original error is the one to report)
+                pass
+            raise
+        if info != 0:
+            mat.pop_block()
+            raise np.linalg.LinAlgError(
+                f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
+        blocks = tuple(old_blocks) + (new_block,)
+        state.view = None
+        # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
+        # in a chain of conditionings only the last object's weights are ever needed
+        return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)
+
+    @staticmethod
+    def _assemble_and_factor(mat, base, bi, old_blocks, new_block) -> int:
         # lower-left blocks  (L_new k L_j'^*)(X_new, X_j)   (`_conditional.py:270`)
         for bj, ob in enumerate(old_blocks):
             k = covfuncs.DifferentiatedCovarianceFunction(
@@ -168,21 +212,12 @@ class ConditionalGaussianProcess(GaussianProcess):
                     mat.add_dense(bi, cov)
                 else:
                     mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
-        info = mat.potrf()
-        if info != 0:
-            raise np.linalg.LinAlgError(
-                f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
-        blocks = tuple(old_blocks) + (new_block,)
-        state.generation += 1
-        # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
-        # in a chain of conditionings only the last object's weights are ever needed
-        return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)
+        return mat.potrf()
 
     def __init__(self, *, prior, blocks, state, representer_weights, test_coeffs=None):
         self._prior = prior
         self._blocks = tuple(blocks)
         self._state = state
-        self._generation = state.generation
         self._representer_weights = representer_weights
         d = max(int(np.prod(prior.input_shape, dtype=int)), 1)
         self._test_coeffs = dict(test_coeffs) if test_coeffs is not None else {(0,) * d: 1.0}
@@ -229,38 +264,32 @@ class ConditionalGaussianProcess(GaussianProcess):
         if not self._blocks:
             self._representer_weights = np.zeros(0)
             return
-        if self._representer_weights is None:
-            self._check_current()
+        self._check_current()
+        if self._representer_weights is None or self._state.weights_key != len(self._blocks):
+            # (second case: the device copy of the weights belongs to another view of the same factor)
             self._representer_weights = self._state.mat.solve_weights(self._residual())
-            self._state.weights_generation = self._generation
-        elif getattr(self._state, "weights_generation", None) != self._generation:
-            # the device copy of the weights belongs to another view of the same factor
-            self._check_current()
-            self._representer_weights = self._state.mat.solve_weights(self._residual())
-            self._state.weights_generation = self._generation
+            self._state.weights_key = len(self._blocks)
 
     def _ensure_residual(self):
         """Mean AND variance need no weights: `K_xX G^{-1} r = V^T (L^{-1} r)` with the solved
         cross-covariance `V = L^{-1} K_Xx` the variance computes anyway; the library only needs
         the residual (its forward substitution hides under the solve for `V`)."""
-        if getattr(self._state, "residual_generation", None) != self._generation:
-            self._check_current()
+        self._check_current()
+        if self._state.residual_key != len(self._blocks):
             self._state.mat.set_residual(self._residual())
-            self._state.residual_generation = self._generation
+            self._state.residual_key = len(self._blocks)
 
     @property
     def prior(self):
         return self._prior
 
     def _check_current(self):
-        if self._generation != self._state.generation:
-            raise RuntimeError(
-                "this ConditionalGaussianProcess has been extended by a later "
-                "`condition_on_observations`; its device-resident factor now belongs to the "
-                "newer object (the factor is updated in place in HBM)")
+        """Point the shared device matrix at THIS object's blocks.  A later `condition_on_observations`
+        appended to the same matrix without touching its leading part, so an earlier posterior keeps
+        working (the reference's posteriors are immutable values)."""
+        self._state.use(len(self._blocks))
 
     def condition_on_observations(self, Y, X=None, *, L=None, b=None):
-        self._check_current()
         if any(v != 1.0 or any(mi) for mi, v in self._test_coeffs.items()):
             raise NotImplementedError("conditioning a transformed posterior is not supported")
         Yf, Lf, bf, Xpts, coeffs, pred_mean = self._preprocess_observations(

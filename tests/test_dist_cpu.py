@@ -241,3 +241,118 @@ def test_control_plane_bcast_from_any_root():
     for r in range(world):
         assert res[r][:world] == [("payload", root, bytes(range(7))) for root in range(world)]
         assert res[r][world] == float(world - 1)
+
+
+# ---- wire format and authentication of the control plane (no pickle, authenticate first) ----
+def _load_dist():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dist_mod", os.path.join(ROOT, "linpde-gp_amd", "linpde_gp_amd", "_dist.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_wire_format_round_trip_and_rejects_garbage():
+    import pickle
+    import numpy as np
+    _dist = _load_dist()
+    msg = (True, None, -7, 2.5, "uid \u00e9", b"\x00\x01\xff", [1, [2.0, (3, "x")]], {"a": np.arange(6.0).reshape(2, 3), 4: np.array([1, 2], dtype=np.int64)},
+           np.zeros((0, 2)))
+    back = _dist.loads(_dist.dumps(msg))
+    assert back[:7] == msg[:7] and isinstance(back[6], list) and isinstance(back[6][1][1], tuple)
+    np.testing.assert_array_equal(back[7]["a"], msg[7]["a"])
+    np.testing.assert_array_equal(back[7][4], msg[7][4])
+    assert back[8].shape == (0, 2)
+    for bad in (pickle.dumps(("x", 1)), b"", b"i\x00", b"a" + b"z" + b"\x01", b"l" + (2**40).to_bytes(8, "big"), _dist.dumps(1) + b"N"):
+        with pytest.raises(ValueError):
+            _dist.loads(bad)
+    with pytest.raises(TypeError):
+        _dist.dumps(object())
+    with pytest.raises(TypeError):
+        _dist.dumps(np.zeros(2, dtype=np.float32))
+
+
+def _auth_worker(rank, world, port, q, key):
+    _dist = _load_dist()
+    comm = _dist.Comm(rank, world, "127.0.0.1", port, key=key)
+    out = comm.allgather(("r", rank))
+    ex = comm.exchange({(rank + 1) % world: bytes([rank]) * 3, rank: b"self"})
+    comm.close()
+    q.put((rank, out, sorted(ex.items())))
+
+
+def test_control_plane_rejects_unauthenticated_peers_and_exchanges_point_to_point():
+    """A connection that does not know the job key (wrong key, a pickle-speaking client of the old protocol,
+    raw garbage, an oversized length header) never becomes a peer and nothing it sends is deserialised; the
+    job still forms.  Also covers `Comm.exchange` (point-to-point messages of the 2-D test transport)."""
+    import pickle
+    import struct
+    import threading
+    import time
+    _dist = _load_dist()
+    port = _free_port()
+    key = b"k" * 32
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_auth_worker, args=(r, world, port, q, key)) for r in range(world)]
+    procs[0].start()
+    # intruders connect to rank 0 before the real peers do
+    def intruder(payload):
+        deadline = time.time() + 20
+        while time.time() < deadline:
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            return
+        try:
+            s.settimeout(5.0)
+            s.sendall(payload)
+            s.recv(64)
+        except OSError:
+            pass
+        finally:
+            s.close()
+    blob = pickle.dumps((("lpgp-comm", world), 1))
+    threads = [threading.Thread(target=intruder, args=(p,)) for p in (
+        struct.pack("!Q", len(blob)) + blob,                 # the old pickle handshake
+        struct.pack("!Q", 1 << 62) + b"x" * 64,              # oversized length header
+        struct.pack("!q", 1) + b"n" * 16 + b"h" * 32,        # right shape, wrong key
+    )]
+    for t in threads:
+        t.start()
+    # a well-formed client with the WRONG key is refused by both sides
+    with pytest.raises((ConnectionError, OSError)):
+        s = socket.create_connection(("127.0.0.1", port), timeout=5.0) if any(
+            _wait_port(port) for _ in range(1)) else None
+        s.settimeout(5.0)
+        try:
+            _dist._handshake_client(s, b"w" * 32, 1, world)
+        finally:
+            s.close()
+    for p in procs[1:]:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for t in threads:
+        t.join(timeout=30)
+    for rank, out, ex in res:
+        assert out == [("r", 0), ("r", 1), ("r", 2)]
+        assert ex == sorted([((rank - 1) % world, bytes([(rank - 1) % world]) * 3), (rank, b"self")])
+
+
+def _wait_port(port, timeout=20.0):
+    import time
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        try:
+            socket.create_connection(("127.0.0.1", port), timeout=1.0).close()
+            return True
+        except OSError:
+            time.sleep(0.05)
+    return False

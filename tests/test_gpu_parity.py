@@ -427,14 +427,68 @@ def test_not_positive_definite_raises(lp):
         prior.condition_on_observations(np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
 
 
-def test_superseded_object_raises(lp):
+def test_earlier_posteriors_stay_usable_and_branching(lp):
+    """The reference's posteriors are immutable values (`_conditional.py:253-294`): an earlier one keeps
+    working after a later conditioning, and two conditionings of the same object are independent.  Here
+    the chain shares ONE device matrix (views on its leading blocks); the second child gets a copy."""
     cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 0.5)])]
+    ident = ocf.identity(1)
     prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=0.5))
-    u1 = prior.condition_on_observations(np.zeros(2), np.array([[0.0], [1.0]]))
-    u2 = u1.condition_on_observations(np.ones(2), np.array([[0.3], [0.6]]))
-    assert u2.mean(np.array([[0.3]])).shape == (1,)
-    with pytest.raises(RuntimeError):
-        u1.mean(np.array([[0.3]]))
+    X1, Y1 = np.array([[0.0], [1.0]]), np.array([0.3, -0.2])
+    X2, Y2 = np.array([[0.3], [0.6]]), np.ones(2)
+    X3, Y3 = np.array([[-0.4], [1.4], [0.45]]), np.array([0.5, 0.1, -0.3])
+    Xt = np.linspace(-0.5, 1.5, 9)[:, None]
+    b1, b2, b3 = (ogp.ObsBlock(X, ident, Y) for X, Y in ((X1, Y1), (X2, Y2), (X3, Y3)))
+    u1 = prior.condition_on_observations(Y1, X1)
+    u2 = u1.condition_on_observations(Y2, X2)
+    p1, p12, p13 = ogp.condition(okern, [b1]), ogp.condition(okern, [b1, b2]), ogp.condition(okern, [b1, b3])
+
+    def same(u, post):
+        m, v = u.predict(Xt)
+        assert _rel(m, post.mean(Xt)) < 1e-9 and np.max(np.abs(v - post.var(Xt))) < 1e-9
+        np.testing.assert_allclose(u.representer_weights, post.weights, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(u.cov.matrix(Xt[:4]), post.cov(Xt[:4]), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(u.mean(Xt), post.mean(Xt), rtol=0, atol=1e-9)
+
+    same(u2, p12)
+    same(u1, p1)                  # superseded object: served from the leading part of the shared factor
+    same(u2, p12)                 # ... and back
+    u3 = u1.condition_on_observations(Y3, X3)      # branching: u1 was already extended by u2
+    assert u3._state is not u2._state
+    same(u3, p13)
+    same(u2, p12)
+    same(u1, p1)
+    assert u1.gram.shape == (2, 2) and u2.gram.shape == (4, 4) and u3.gram.shape == (5, 5)
+
+
+def test_failed_conditioning_leaves_the_parent_intact(lp):
+    """a failed `condition_on_observations` (Gram not positive definite) must not corrupt the
+    device state it shares with the object it was called on (the new block is rolled back)."""
+    cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 1.0)])]
+    ident = ocf.identity(1)
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    rng = np.random.default_rng(3)
+    X1, Y1 = rng.uniform(-1, 1, (150, 1)), rng.normal(size=150)      # two tile columns: phase A of the append runs
+    noise = lp.randvars.Normal(np.zeros(150), 1e-2 * np.eye(150))
+    u1 = prior.condition_on_observations(Y1, X1, b=noise)
+    post1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
+    Xt = np.linspace(-1, 1, 7)[:, None]
+    Xbad = np.array([[0.2], [0.2], [0.5]])           # duplicated point and negative noise: not PD
+    with pytest.raises(np.linalg.LinAlgError):
+        u1.condition_on_observations(np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+    with pytest.raises(ValueError):                 # host-side validation error: nothing reached the device
+        u1.condition_on_observations(np.zeros(4), Xbad)
+    m, v = u1.predict(Xt)
+    assert _rel(m, post1.mean(Xt)) < 1e-8 and np.max(np.abs(v - post1.var(Xt))) < 1e-9
+    np.testing.assert_allclose(u1.representer_weights, post1.weights, rtol=1e-7, atol=1e-9)
+    # and the parent can still be extended
+    X2, Y2 = np.array([[0.31], [-0.62]]), np.array([0.1, 0.2])
+    u2 = u1.condition_on_observations(Y2, X2)
+    post2 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2), ogp.ObsBlock(X2, ident, Y2)])
+    m2, v2 = u2.predict(Xt)
+    assert _rel(m2, post2.mean(Xt)) < 1e-8 and np.max(np.abs(v2 - post2.var(Xt))) < 1e-9
 
 
 def test_api_errors(lp):
