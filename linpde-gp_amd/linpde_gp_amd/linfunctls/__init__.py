@@ -79,6 +79,8 @@ class LinearFunctional:
             return gps.apply_linfunctl_to_gp(self, f)
         if isinstance(f, covfuncs.CovarianceFunction):
             return covfuncs.ProcessVectorCrossCovariance(f, self, argnum=argnum)
+        if isinstance(f, covfuncs.ProcessVectorCrossCovariance):
+            return covfuncs.apply_linfunctl_to_pv_crosscov(self, f)
         if isinstance(f, Function):
             return self._apply_to_function(f)
         raise NotImplementedError(f"cannot apply {type(self).__name__} to {type(f).__name__}")

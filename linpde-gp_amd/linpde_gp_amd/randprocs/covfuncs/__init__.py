@@ -504,6 +504,27 @@ class ProcessVectorCrossCovariance:
         return K.reshape(batch + (Xobs.shape[0],))
 
 
+def apply_linfunctl_to_pv_crosscov(L, pv: ProcessVectorCrossCovariance):
+    """`L(pv_crosscov)`: the covariance between two functionals of the process as a
+    `LinearOperatorCovariance` (`crosscov/linfunctls/_evaluation.py:163-173`: `covfunc.linop(X)` when
+    both functionals are the same evaluation, else `covfunc.linop(x, X)`).  The operator is the
+    device-resident `KernelLinearOperator`: `.matrix` = `lpgp_kernel_matrix`, `.linop @ v` = matrix-free
+    `lpgp_kernel_matvec`.  For `argnum=0` cross-covariances the new functional is the RIGHT variable."""
+    from ... import randvars
+
+    lc = L.coefficients_dict()
+    kL0, kL1 = pv._k._operator_coeffs()
+    k = DifferentiatedCovarianceFunction(_base(pv._k), _compose(lc, kL0), kL1)
+    X_new, X_old = L.points(), pv.linfunctl.points()
+    same = L is pv.linfunctl
+    if k.input_ndim == 0:
+        X_new, X_old = X_new[:, 0], X_old[:, 0]
+    op = KernelLinearOperator(k, X_new, X_new if same else X_old)
+    if pv.reverse:
+        return randvars.LinearOperatorCovariance(op.T, pv.randvar_shape, L.output_shape)
+    return randvars.LinearOperatorCovariance(op, L.output_shape, pv.randvar_shape)
+
+
 def _base(k: CovarianceFunction) -> CovarianceFunction:
     return k._covfunc if isinstance(k, DifferentiatedCovarianceFunction) else k
 
@@ -511,5 +532,5 @@ def _base(k: CovarianceFunction) -> CovarianceFunction:
 __all__ = [
     "CovarianceFunction", "Matern", "ExpQuad", "TensorProduct", "ScaledCovarianceFunction",
     "SumCovarianceFunction", "Zero", "DifferentiatedCovarianceFunction",
-    "ProcessVectorCrossCovariance", "apply_linfuncop", "lower_groups",
+    "ProcessVectorCrossCovariance", "apply_linfuncop", "apply_linfunctl_to_pv_crosscov", "lower_groups",
 ]

@@ -569,3 +569,32 @@ def test_empty_observation_and_prediction_sets(lp):
     assert u.cov.matrix(np.zeros((0, 2))).shape == (0, 0)
     assert u.cov.matrix(Xt, np.zeros((0, 2))).shape == (7, 0)
     assert prior.cov.matrix(np.zeros((0, 2)), X[:3]).shape == (0, 3)
+
+
+def test_functional_of_crosscovariance_is_a_linear_operator_covariance(lp):
+    """`L0(L1(k, argnum=1))` -> `LinearOperatorCovariance` over the device kernel operator
+    (`crosscov/linfunctls/_evaluation.py:163-173`, `randvars/_covariance.py:197-224`)."""
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(77)
+    X0, X1 = rng.uniform(-1, 1, (5, 7, 2)), rng.uniform(-1, 1, (9, 2))
+    k = 4.0 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=0.7))
+    okern = [(4.0, [("matern", 2.5, 1.0), ("matern", 2.5, 0.7)])]
+    lap, ident = {(2, 0): 1.0, (0, 2): 1.0}, ocf.identity(2)
+    L0 = diffops.Laplacian((2,)).to_linfunctl(X0)
+    L1 = lp.linfunctls._EvaluationFunctional((2,), (), X1)
+    cov = L0(L1(k, argnum=1))
+    assert isinstance(cov, lp.randvars.LinearOperatorCovariance)
+    assert cov.shape0 == (5, 7) and cov.shape1 == (9,) and cov.array.shape == (5, 7, 9)
+    ref = ocf.LkL(okern, lap, ident, X0.reshape(-1, 2), X1)
+    assert _rel(cov.matrix, ref) < 1e-12
+    V = rng.normal(size=(9, 3))
+    np.testing.assert_allclose(cov.linop @ V, ref @ V, rtol=0, atol=1e-11 * np.abs(ref @ V).max())
+    # argnum = 0: the functional applied first is the LEFT variable
+    cov_r = L0(L1(k, argnum=0))
+    assert cov_r.shape0 == (9,) and cov_r.shape1 == (5, 7)
+    assert _rel(cov_r.matrix, ref.T) < 1e-12
+    # the same functional twice: symmetric Gram of the observations (what `from_observations` factors)
+    G = L0(L0(k, argnum=1))
+    assert _rel(G.matrix, ocf.LkL(okern, lap, lap, X0.reshape(-1, 2), X0.reshape(-1, 2))) < 1e-12
+    assert isinstance(G + lp.randvars.ArrayCovariance(np.zeros((5, 7, 5, 7)), (5, 7), (5, 7)), lp.randvars.ArrayCovariance)

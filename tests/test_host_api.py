@@ -215,3 +215,31 @@ def test_functional_arithmetic():
         lf.ScaledLinearFunctional(ev, np.ones(2))
     with pytest.raises(TypeError):
         np.ones(3) * ev
+
+
+def test_covariance_classes():
+    """`randvars.Covariance` family (`randvars/_covariance.py:13-224` of the reference): shapes, both
+    representations, C-order flattening, arithmetic, error behaviour."""
+    rv = lp.randvars
+    A = np.arange(24.0).reshape(2, 3, 4)
+    c = rv.ArrayCovariance(A, (2, 3), (4,))
+    assert (c.shape0, c.shape1, c.ndim0, c.ndim1, c.size0, c.size1) == ((2, 3), (4,), 2, 1, 6, 4)
+    assert c.array is not None and np.array_equal(c.matrix, A.reshape(6, 4)) and c.linop.shape == (6, 4)
+    np.testing.assert_array_equal(c.linop @ np.ones(4), A.reshape(6, 4).sum(1))
+    np.testing.assert_array_equal(c.flatten0(np.arange(6).reshape(2, 3)), np.arange(6))
+    with pytest.raises(ValueError):
+        c.flatten1(np.zeros(3))
+    with pytest.raises(ValueError):
+        rv.ArrayCovariance(A, (2, 3), (5,))
+    s = rv.ArrayCovariance.from_scalar(2.5)
+    assert s.shape0 == () and s.matrix.shape == (1, 1) and float(s.array) == 2.5
+    assert np.array_equal((-c).array, -A) and np.array_equal((2.0 * c).array, 2.0 * A)
+    assert np.array_equal((c + c).array, 2 * A) and np.array_equal((c - c).array, 0 * A)
+    lo = rv.LinearOperatorCovariance(A.reshape(6, 4), (2, 3), 4)           # int shape = (4,)
+    assert lo.shape1 == (4,) and np.array_equal(lo.array, A) and np.array_equal(lo.matrix, A.reshape(6, 4))
+    assert isinstance(lo + c, rv.ArrayCovariance) and np.array_equal((c + lo).array, 2 * A)
+    np.testing.assert_array_equal(lo.linop.T @ np.ones(6), A.reshape(6, 4).sum(0))
+    with pytest.raises(ValueError):
+        rv.LinearOperatorCovariance(A.reshape(6, 4), (2, 3), (3,))
+    with pytest.raises(TypeError):
+        c + 1.0
