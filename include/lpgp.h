@@ -235,12 +235,13 @@ int  lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only,
                     double beta, double* C, int64_t ldc, int32_t reps, double* ms_per_rep);
 /* in-place 128x128 tile Cholesky + inverse: T (col-major 128x128) -> L, Linv            */
 int  lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info);
-/* the two in-place tile steps of the panel chain / forward substitution on host buffers:
- *   which = 0:  X (rows x 128, col-major ldx, rows a multiple of 128) <- X * Linv^T
- *   which = 1:  V (128 x cols, col-major ld 128, cols a multiple of 128) <- Linv * V
- * Linv: 128 x 128 column-major, lower triangular (entries above the diagonal are ignored).
- * slab = 0 runs the same product on the general GEMM kernel (the two must agree).          */
-int  lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, int64_t n,
+/* the two in-place tile solves of the panel chain / forward substitution on host buffers, each with its one
+ * step of iterative refinement (X0 = A Linv^T, X = X0 + (A - X0 L^T) Linv^T):
+ *   which = 0:  X (rows x 128, col-major ldx = rows, rows a multiple of 128) <- X * L^{-T}
+ *   which = 1:  V (128 x cols, col-major ld 128, cols a multiple of 128) <- L^{-1} * V
+ * L, Linv: 128 x 128 column-major, lower triangular WITH ZEROS above the diagonal (as the tile Cholesky
+ * stores them); Linv the fp64 inverse of L.                                                    */
+int  lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, const double* L,
                          const double* Linv, double* ms);
 /* diagnostics: histogram over the 8 XCDs of where the single workgroup of the tile Cholesky ran
  * since the last reset (the CU reservation of the update streams is built on it)           */

@@ -344,7 +344,6 @@ int lpgp_init(int device, lpgp_ctx** out) {
   }
   if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
-  if (const char* e = std::getenv("LPGP_TRSM_SLAB")) ctx->trsm_slab = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_big = v;
@@ -426,8 +425,6 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->chain_us_fixed = (double)value;
   } else if (std::strcmp(key, "dist_merged_update") == 0) {
     ctx->dist_merged_update = (int)value;
-  } else if (std::strcmp(key, "trsm_slab") == 0) {
-    ctx->trsm_slab = (int)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
@@ -1216,30 +1213,24 @@ int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) 
   return rc;
 }
 
-int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, int64_t n, const double* Linv, double* ms) {
-  LPGP_CHECK(ctx && XV && Linv && n > 0 && n % TILE == 0 && (which == 0 || which == 1), "lpgp_test_tile_step: bad argument");
+int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, const double* L, const double* Linv, double* ms) {
+  LPGP_CHECK(ctx && XV && L && Linv && n > 0 && n % TILE == 0 && (which == 0 || which == 1), "lpgp_test_tile_step: bad argument");
   LPGP_DEVICE(ctx);
-  double *d = nullptr, *dl = nullptr;
-  const size_t bytes = (size_t)n * TILE * sizeof(double);
+  double *d = nullptr, *dl = nullptr, *dt = nullptr;
+  const size_t bytes = (size_t)n * TILE * sizeof(double), tbytes = (size_t)TILE * TILE * sizeof(double);
   LPGP_HIP(hipMalloc(&d, bytes));
-  LPGP_HIP(hipMalloc(&dl, (size_t)TILE * TILE * sizeof(double)));
+  LPGP_HIP(hipMalloc(&dl, tbytes));
+  LPGP_HIP(hipMalloc(&dt, tbytes));
   LPGP_HIP(hipMemcpy(d, XV, bytes, hipMemcpyHostToDevice));
-  LPGP_HIP(hipMemcpy(dl, Linv, (size_t)TILE * TILE * sizeof(double), hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dl, Linv, tbytes, hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dt, L, tbytes, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   LPGP_HIP(hipEventCreate(&e0));
   LPGP_HIP(hipEventCreate(&e1));
   const int nt = (int)(n / TILE);
   LPGP_HIP(hipEventRecord(e0, ctx->s_main));
-  int rc;
-  if (slab) {
-    rc = which == 0 ? launch_trsm_tile(ctx, ctx->s_main, d, n, dl, nt, -1) : launch_trsv_tile(ctx, ctx->s_main, d, TILE, dl, nt, -1);
-  } else {
-    GemmArgs g;
-    g.k = TILE; g.alpha = 1.0; g.beta = 0.0; g.tri = 0;
-    if (which == 0) { g.A = d; g.lda = n; g.B = dl; g.ldb = TILE; g.C = d; g.ldc = n; g.mt = nt; g.nt = 1; }
-    else { g.A = dl; g.lda = TILE; g.B = d; g.ldb = TILE; g.C = d; g.ldc = TILE; g.mt = 1; g.nt = nt; }
-    rc = launch_gemm(ctx, ctx->s_main, 0, which == 0 ? 0 : 1, g, -1);
-  }
+  int rc = which == 0 ? launch_trsm_tile(ctx, ctx->s_main, d, n, dl, dt, TILE, nt, -1)
+                      : launch_trsv_tile(ctx, ctx->s_main, d, TILE, dl, dt, TILE, nt, -1);
   LPGP_HIP(hipEventRecord(e1, ctx->s_main));
   LPGP_HIP(hipEventSynchronize(e1));
   float t = 0.f;
@@ -1250,6 +1241,7 @@ int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, int32_t slab, double* XV, 
   (void)hipEventDestroy(e1);
   (void)hipFree(d);
   (void)hipFree(dl);
+  (void)hipFree(dt);
   return rc;
 }
 

@@ -601,268 +601,180 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
 }
 
 // =========================================================================================
-// Panel triangular solve as a product with the explicit tile inverse, IN PLACE:
-//     X[rows, 0:128] <- X[rows, 0:128] * Linv^T        (Linv: 128 x 128 lower triangular, ld 128)
-// This is the second kernel of every step of the panel chain (tile Cholesky -> this -> rank-128
-// update inside the panel), i.e. latency, not throughput: with one 128 x 128 x 128 tile per
-// workgroup (gemm_f64_kernel) a CU needs 21 us for it whatever else idles.  Here a workgroup of
-// eight waves owns a 64-row slab and all 128 columns (it reads only the rows it overwrites, and
-// all of them before its first store: in place is safe), wave = 64 x 16 column slab as in
-// gemm64_f64_kernel, both operands streamed through the same 4-stage LDS-DMA ring (A: 64 x 16 per
-// stage, the [k/2][2][64] image of gemm64; Linv^T: 128 x 16 per stage, image [k/2][2][128]).
-// Column slab c needs only k < 16 (c + 1) (Linv is lower triangular): a wave skips the matrix
-// work of the stages beyond, and the slabs are dealt so that the two waves of a SIMD hold slabs
-// s and 7 - s (9 stage units of 16 per SIMD instead of 12).
+// Tile solve with ONE STEP OF ITERATIVE REFINEMENT, in place -- the latency-bound second kernel of
+// every step of the panel chain and the tile step of the multi-RHS forward substitution:
+//   KFAST = false:  X[rows, 0:128] <- X L^{-T}            X(i, c) at P[i + c ld]   (panel rows below a factored tile)
+//   KFAST = true :  V[0:128, cols] <- L^{-1} V, as X = V^T:  X(i, c) at P[c + i ld]   (i = right-hand-side column)
+// with L the 128 x 128 lower-triangular diagonal tile of the factor and Linv its explicit inverse:
+//     X0 = A Linv^T;    R = A - X0 L^T;    X = X0 + R Linv^T.
+// A product with the explicit inverse alone has a backward error of cond(L) eps (Linv L = I + E,
+// |E| ~ cond(L) eps): measured at c3 (cond of the diagonal tiles up to 3e5) the posterior mean was 1.8e-8
+// away from LAPACK's, 65x LAPACK's own distance from the long-double-refined solution
+// (scratch/parity_diag.py, scratch/tileinv_accuracy.py).  The refinement step squares E away: what is
+// left is the rounding of R, i.e. the backward error of a substitution -- at three latency-bound tile
+// products instead of one and no dependent chain of 128 steps.
+//
+// A workgroup of eight waves owns 32 rows: two groups of 16 rows x four waves; wave `cc` of a group owns
+// the output fragments u = cc, cc + 4, ..., cc + 28 (fragment u = columns 4u .. 4u + 3 of the 16 rows, in
+// the accumulator layout of v_mfma_f64_4x4x4_4b_f64: lane -> (row = lane & 15, column 4u + (lane >> 4))).
+// That layout IS the instruction's m-side operand layout for k-step u, so the result fragments of one
+// product are the operand fragments of the next: they are exchanged between the four waves of a group
+// through a 16-KB LDS image `xa[group][fragment][lane]`, never reshuffled.  The triangular factor is
+// streamed through a 3-stage LDS-DMA ring of 16 k-rows x 128 columns (image [k][136]: the four k-rows of a
+// replicated n-side fragment read fall into four different bank groups), 24 stages in all: Linv^T, L^T,
+// Linv^T.  Fragment u needs k-steps g <= u only (lower triangle): stage kt feeds the fragments u >= 4 kt,
+// 144 MFMAs per wave and product instead of 256; the fragments of a stage's own diagonal block meet the
+// explicit zeros above the diagonal of Linv / L.  The two groups take their classes in opposite order, so
+// every SIMD holds a wave with 4 cc and one with 4 (3 - cc) columns beyond the stage's diagonal.
+// LDS: 32 KB + 3 x 17 KB = 85 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup.
 // =========================================================================================
-#ifndef LPGP_LSTAGES
-#define LPGP_LSTAGES 3
-#endif
-constexpr int LSTAGES = LPGP_LSTAGES;    // ring depth of the two slab kernels: 3 stages = 80 / 77 KB, so that a slab workgroup
-                                         // finds room on a CU as soon as ONE of its two GEMM workgroups retires (4 stages: 106 KB
-                                         // = a whole CU)
-constexpr int LDP2 = 272;                // pair of k-rows of 128 indices + 16 doubles of padding (LDP2 % 32 == 16)
-constexpr int TS_A = 8 * LDMP;           // doubles per stage: A image
-constexpr int TS_B = 8 * LDP2;           // doubles per stage: Linv^T image
-constexpr int TS_STAGE = TS_A + TS_B;
+constexpr int TSV_LDB = 136;                 // B image: row stride in doubles (2 * 136 % 64 == 16)
+constexpr int TSV_STAGE = 16 * TSV_LDB;      // doubles per stage
+constexpr int TSV_STAGES = 3;
+constexpr int TSV_NSTAGE = 24;               // 3 products x 8 stages of 16 k
+constexpr int TSV_XA = 2 * 32 * 64;          // doubles: two row groups x 32 fragments x 64 lanes
+constexpr int TSV_ROWS = 32;                 // rows (KFAST: right-hand-side columns) per workgroup
 
-struct TrsmTileArgs {
-  double* X;                       // rows x 128, column-major
-  int64_t ldx;
-  const double* linv;              // 128 x 128, column-major, ld 128
-  int32_t slabs;                   // 64-row slabs
+struct TileSolveArgs {
+  double* P;
+  int64_t ld;
+  const double* linv;                        // 128 x 128, column-major, ld 128, zeros above the diagonal
+  const double* L;                           // 128 x 128 diagonal tile of the factor, zeros above the diagonal
+  int64_t ldl;
 };
 
-__global__ __launch_bounds__(512, 1) void trsm_tile_kernel(TrsmTileArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const int slab = wu < 4 ? wu : 11 - wu;                 // column slab [16 slab, 16 slab + 16)
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
-  constexpr int KT = TILE / BK;                            // 8 stages of 16
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
-  auto issue = [&](int kt) {
-    double* sa = smem + (size_t)(kt % LSTAGES) * TS_STAGE;
-    double* sb = sa + TS_A;
-    // A: k-row pair wu of the stage (lanes 0-31 / 32-63 = the two k-rows, 64 indices each)
-    {
-      const unsigned voff = ((unsigned)(lane >> 5) * (unsigned)g.ldx + (unsigned)(lane & 31) * 2u) * 8u;
-      const char* ub = reinterpret_cast<const char*>(g.X + row0 + ((int64_t)kt * BK + 2 * wu) * g.ldx);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sa + wu * LDMP), 16, 0, 0);
-    }
-    // Linv^T: element (k, c) = Linv[c + 128 k]: one k-row of 128 indices per wave instruction
+template <bool KFAST>
+__global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* xa = smem;
+  double* ring = smem + TSV_XA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wu >> 2, s4 = wu & 3;
+  const int cc = rg ? 3 - s4 : s4;
+  const int li = lane & 15, lj = lane >> 4;
+  const int64_t i0 = (int64_t)blockIdx.x * TSV_ROWS + rg * 16 + li;      // this lane's row
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
+
+  // stage s of the factor stream: product s / 8 (0, 2: Linv^T; 1: L^T), k-rows 16 (s % 8) ...; element
+  // (k, c) of M^T is M[c + k ldm]: one k-row = 128 contiguous doubles = one DMA wave instruction
+  auto issue = [&](int s) {
+    const int p = s >> 3, kt = s & 7;
+    const double* M = (p == 1) ? g.L : g.linv;
+    const int64_t ldm = (p == 1) ? g.ldl : (int64_t)TILE;
+    double* sb = ring + (size_t)(s % TSV_STAGES) * TSV_STAGE;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int r = 2 * wu + h;                            // k-row of the stage; pair wu, half h
-      const char* ub = reinterpret_cast<const char*>(g.linv + ((int64_t)kt * BK + r) * TILE);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + wu * LDP2 + h * 128), 16, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int kt = 0; kt < LSTAGES - 1; ++kt) issue(kt);
-
-  const int j = lane >> 4;
-  unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDMP + (j >> 1) * 64 + (lane & 15));
-  unsigned laneN = lds_base + 8u * (unsigned)(TS_A + (j & 1) * LDP2 + (j >> 1) * 128 + 16 * slab + (lane & 3));
-
-  double acc[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-
-  for (int kt = 0; kt < KT; ++kt) {
-    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage, LSTAGES - 1 stages in flight
-    if (later >= 2 && LSTAGES >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (later >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + LSTAGES - 1 < KT) issue(kt + LSTAGES - 1);
-    if (kt > slab) continue;                               // Linv[c][k] = 0 for k > c (wave-uniform)
-    const unsigned stoff = (unsigned)((kt % LSTAGES) * TS_STAGE) * 8u;
-    const unsigned aM = laneM + stoff, aN = laneN + stoff;
-    double am[2][4], bn[2][4];
-    asm volatile("" ::: "memory");
-    static_for<0, 4>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-      am[0][t] = lds_read_async<16 * t>(aM);
-    });
-    static_for<0, 4>([&](auto U_) {
-      constexpr int u = decltype(U_)::value;
-      bn[0][u] = lds_read_async<4 * u>(aN);
-    });
-    static_for<0, 4>([&](auto K_) {
-      constexpr int ks = decltype(K_)::value;
-      if constexpr (ks + 1 < 4) {
-        static_for<0, 4>([&](auto T_) {
-          constexpr int t = decltype(T_)::value;
-          am[(ks + 1) & 1][t] = lds_read_async<2 * (ks + 1) * LDMP + 16 * t>(aM);
-        });
-        static_for<0, 4>([&](auto U_) {
-          constexpr int u = decltype(U_)::value;
-          bn[(ks + 1) & 1][u] = lds_read_async<2 * (ks + 1) * LDP2 + 4 * u>(aN);
-        });
-        LDS_WAIT(8);
-      } else {
-        LDS_WAIT(0);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[ks & 1][u], am[ks & 1][t], acc[t][u], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  }
-  // in place: the slab's rows were read from global memory by DMA only, the last of it waited for
-  // (vmcnt) by every wave before the barrier of stage 7, which every wave has passed here
-  char* const cub = reinterpret_cast<char*>(g.X + (int64_t)(16 * slab) * g.ldx + row0);
-  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldx + (unsigned)(lane & 15)) * 8u;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldx + t * 16) * 8 + cvoff) = acc[t][u];
-}
-
-int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel) {
-  if (mt <= 0) return 0;
-  const size_t shmem = (size_t)LSTAGES * TS_STAGE * sizeof(double);       // 79 872 B: fits beside ONE 73-KB GEMM workgroup
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&trsm_tile_kernel), shmem));
-  TrsmTileArgs a;
-  a.X = X; a.ldx = ldx; a.linv = linv; a.slabs = mt * 2;
-  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)mt * TILE * TILE * TILE, 0.0);
-  hipLaunchKernelGGL(trsm_tile_kernel, dim3((unsigned)(mt * 2)), dim3(512), shmem, stream, a);
-  if (prof_kernel >= 0) prof_end(ctx, stream);
-  LPGP_HIP(hipGetLastError());
-  return 0;
-}
-
-// =========================================================================================
-// Tile step of the forward substitution, IN PLACE:   V[0:128, cols] <- Linv * V[0:128, cols]
-// (Linv: 128 x 128 lower triangular tile inverse; V: 128 rows of a column-major block of
-// right-hand sides).  The latency twin of trsm_tile_kernel: a workgroup of eight waves owns 64
-// right-hand-side columns and all 128 rows (it reads exactly the region it overwrites), wave =
-// 64 x 16 slab (row half mh, column slab ns), Linv streamed as [k/2][2][128] stages, V as the
-// swizzled k-fastest image of gemm64.  Rows [0, 64) need only k < 64: the waves of the upper row
-// half skip the matrix work of stages 4-7, and the halves are dealt so that every SIMD holds one
-// wave of each.
-// =========================================================================================
-struct TrsvTileArgs {
-  double* V;                       // 128 x ncols, column-major, leading dimension ldv
-  int64_t ldv;
-  const double* linv;
-};
-
-__global__ __launch_bounds__(512, 1) void trsv_tile_kernel(TrsvTileArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  const int b0 = wu & 1, b1 = (wu >> 1) & 1, b2 = wu >> 2;
-  const int mh = b2 ^ b0, ns = 2 * b1 + b0;               // rows [64 mh, 64 mh + 64), columns [16 ns, 16 ns + 16)
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
-  constexpr int KT = TILE / BK;
-  const int64_t col0 = (int64_t)blockIdx.x * 64;
-  constexpr int TV_A = 8 * LDP2;                           // Linv stage: 16 k-rows of 128 row indices
-  constexpr int TV_B = 1024;                               // V stage: 64 columns x 16 k, swizzled K image
-  constexpr int TV_STAGE = TV_A + TV_B;
-
-  auto issue = [&](int kt) {
-    double* sa = smem + (size_t)(kt % LSTAGES) * TV_STAGE;
-    double* sb = sa + TV_A;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                          // Linv: element (i, k) at linv[i + 128 k]
       const int r = 2 * wu + h;
-      const char* ub = reinterpret_cast<const char*>(g.linv + ((int64_t)kt * BK + r) * TILE);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sa + wu * LDP2 + h * 128), 16, 0, 0);
-    }
-    {                                                      // V: 8 columns x 16 k per wave (dma_tile64<true>, q = wu)
-      const unsigned row8 = (unsigned)(lane >> 3);
-      const unsigned c = ((unsigned)lane & 7u) ^ ((((unsigned)wu << 2) + ((unsigned)lane >> 4)) & 7u);
-      const unsigned voff = (c * 2u + row8 * (unsigned)g.ldv) * 8u;
-      const char* ub = reinterpret_cast<const char*>(g.V + (int64_t)kt * BK + (col0 + (int64_t)wu * 8) * g.ldv);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sb + wu * 128), 16, 0, 0);
+      const char* ub = reinterpret_cast<const char*>(M + ((int64_t)kt * 16 + r) * ldm);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + r * TSV_LDB), 16, 0, 0);
     }
   };
-#pragma unroll
-  for (int kt = 0; kt < LSTAGES - 1; ++kt) issue(kt);
 
-  const int j = lane >> 4;
-  const unsigned laneM = lds_base + 8u * (unsigned)((j & 1) * LDP2 + (j >> 1) * 128 + 64 * mh + (lane & 15));
-  const unsigned laneNb = lds_base + 8u * (unsigned)(TV_A + frag64_lane_n<true>(lane, ns));
-
-  double acc[4][4];
+  // own fragments of A (fragment u = cc + 4 q: element (row, column 4u + lj))
+  double a[8], x[8];
+  double* const pbase = KFAST ? g.P + i0 * g.ld + (4 * cc + lj) : g.P + i0 + (int64_t)(4 * cc + lj) * g.ld;
+  const int64_t pstep = KFAST ? 16 : 16 * g.ld;                            // fragment q -> q + 1: 16 columns on
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int q = 0; q < 8; ++q) a[q] = pbase[q * pstep];
+  issue(0);
+  issue(1);
+  double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;            // fragment q of this wave: xown[q * 256]
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-
-  for (int kt = 0; kt < KT; ++kt) {
-    const int later = KT - 1 - kt;                        // 3 DMA instructions per wave and stage, LSTAGES - 1 stages in flight
-    if (later >= 2 && LSTAGES >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (later >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + LSTAGES - 1 < KT) issue(kt + LSTAGES - 1);
-    if (mh == 0 && kt >= 4) continue;                      // Linv[i][k] = 0 for k > i (wave-uniform)
-    const unsigned stoff = (unsigned)((kt % LSTAGES) * TV_STAGE) * 8u;
-    const unsigned aM = laneM + stoff, aN = laneNb + stoff;
-    double am[2][4], bn[2][4];
-    asm volatile("" ::: "memory");
-    static_for<0, 4>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-      am[0][t] = lds_read_async<16 * t>(aM);
-    });
-    static_for<0, 4>([&](auto U_) {
-      constexpr int u = decltype(U_)::value;
-      bn[0][u] = lds_read_async<frag64_imm_n<true>(0, u)>(aN);
-    });
-    static_for<0, 4>([&](auto K_) {
-      constexpr int ks = decltype(K_)::value;
-      if constexpr (ks + 1 < 4) {
-        static_for<0, 4>([&](auto T_) {
-          constexpr int t = decltype(T_)::value;
-          am[(ks + 1) & 1][t] = lds_read_async<2 * (ks + 1) * LDP2 + 16 * t>(aM);
-        });
-        static_for<0, 4>([&](auto U_) {
-          constexpr int u = decltype(U_)::value;
-          bn[(ks + 1) & 1][u] = lds_read_async<frag64_imm_n<true>(ks + 1, u)>(aN);
-        });
-        LDS_WAIT(8);
-      } else {
-        LDS_WAIT(0);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[ks & 1][u], am[ks & 1][t], acc[t][u], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
+  for (int q = 0; q < 8; ++q) {
+    xown[q * 256] = a[q];
+    x[q] = 0.0;
   }
-  // in place: the 128 x 64 block was read by DMA only, all of it waited for before the barrier of
-  // stage 7, which every wave has passed here
-  char* const cub = reinterpret_cast<char*>(g.V + (col0 + 16 * ns) * g.ldv + 64 * mh);
-  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldv + (unsigned)(lane & 15)) * 8u;
+  const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
+  const unsigned nlane = lds_base + 8u * (unsigned)(TSV_XA + lj * TSV_LDB + (lane & 3) + 4 * cc);
+
+  // dst[q] += sum over k-steps g <= u of (operand fragment g from xa) x (factor fragment (g, u)), u = cc + 4 q
+  auto run_product = [&](auto P_, double(&dst)[8]) {
+    constexpr int prod = decltype(P_)::value;
+    static_for<0, 8>([&](auto KT_) {
+      constexpr int kt = decltype(KT_)::value;
+      constexpr int s = prod * 8 + kt;
+      // this wave's DMA pieces of stage s have landed (two per stage; stage s + 1 may be in flight) ...
+      if constexpr (s + 1 < TSV_NSTAGE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                     // ... everybody's have, stage s - 1 is consumed, xa of this product is written
+      if constexpr (s + 2 < TSV_NSTAGE) issue(s + 2);
+      const unsigned aN = nlane + (unsigned)((s % TSV_STAGES) * TSV_STAGE) * 8u;
+      double mf[2], nf[2][8];
+      asm volatile("" ::: "memory");
+      mf[0] = lds_read_async<(4 * kt) * 64>(mlane);
+      static_for<kt, 8>([&](auto Q_) {
+        constexpr int q = decltype(Q_)::value;
+        nf[0][q] = lds_read_async<16 * q>(aN);
+      });
+      static_for<0, 4>([&](auto K_) {
+        constexpr int ks = decltype(K_)::value;
+        if constexpr (ks + 1 < 4) {
+          mf[(ks + 1) & 1] = lds_read_async<(4 * kt + ks + 1) * 64>(mlane);
+          static_for<kt, 8>([&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            nf[(ks + 1) & 1][q] = lds_read_async<(ks + 1) * 4 * TSV_LDB + 16 * q>(aN);
+          });
+          lds_wait_n<9 - kt>();
+        } else {
+          lds_wait_n<0>();
+        }
+        static_for<kt, 8>([&](auto Q_) {
+          constexpr int q = decltype(Q_)::value;
+          dst[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(nf[ks & 1][q], mf[ks & 1], dst[q], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+
+  run_product(std::integral_constant<int, 0>{}, x);          // x = X0 = A Linv^T
+  __syncthreads();                                            // nobody reads the fragments of A any more
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int q = 0; q < 8; ++q) xown[q * 256] = -x[q];
+  run_product(std::integral_constant<int, 1>{}, a);          // a = R = A - X0 L^T
+  __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldv + t * 16) * 8 + cvoff) = acc[t][u];
+  for (int q = 0; q < 8; ++q) xown[q * 256] = a[q];
+  run_product(std::integral_constant<int, 2>{}, x);          // x = X0 + R Linv^T
+  // in place: this workgroup read exactly the 32 rows it overwrites, all of them before the first barrier
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pbase[q * pstep] = x[q];
 }
 
-// V (128 rows x nt*128 columns, column-major ldv) <- linv * V in place
-int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel) {
-  if (nt <= 0) return 0;
-  const size_t shmem = (size_t)LSTAGES * (8 * LDP2 + 1024) * sizeof(double);       // 76 800 B: fits beside ONE 73-KB GEMM workgroup
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&trsv_tile_kernel), shmem));
-  TrsvTileArgs a;
-  a.V = V; a.ldv = ldv; a.linv = linv;
-  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, 2.0 * (double)nt * TILE * TILE * TILE, 0.0);
-  hipLaunchKernelGGL(trsv_tile_kernel, dim3((unsigned)(nt * 2)), dim3(512), shmem, stream, a);
+template <bool KFAST>
+static int launch_tile_solve(lpgp_ctx* ctx, hipStream_t stream, double* P, int64_t ld, const double* linv, const double* L,
+                             int64_t ldl, int64_t rows, int prof_kernel) {
+  if (rows <= 0) return 0;
+  const size_t shmem = (size_t)(TSV_XA + TSV_STAGES * TSV_STAGE) * sizeof(double);   // 84 992 B
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&tile_solve_kernel<KFAST>), shmem));
+  TileSolveArgs a;
+  a.P = P; a.ld = ld; a.linv = linv; a.L = L; a.ldl = ldl;
+  // algorithmic flops: the triangular solve itself (rows x 128^2), not the three products that form it
+  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, (double)rows * TILE * TILE, 0.0);
+  hipLaunchKernelGGL(tile_solve_kernel<KFAST>, dim3((unsigned)(rows / TSV_ROWS)), dim3(512), shmem, stream, a);
   if (prof_kernel >= 0) prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;
+}
+
+// X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place
+int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
+                     int mt, int prof_kernel) {
+  return launch_tile_solve<false>(ctx, stream, X, ldx, linv, L, ldl, (int64_t)mt * TILE, prof_kernel);
+}
+
+// V (128 rows x nt*128 columns, column-major ldv) <- L^{-1} V in place
+int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
+                     int nt, int prof_kernel) {
+  return launch_tile_solve<true>(ctx, stream, V, ldv, linv, L, ldl, (int64_t)nt * TILE, prof_kernel);
 }
 
 template <bool TA, bool TB, int TRI>

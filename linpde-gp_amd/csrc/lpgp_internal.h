@@ -75,7 +75,6 @@ struct lpgp_ctx {
   double chain_us_tile = 115.0, solve_chain_us_tile = 115.0, chain_us_fixed = 80.0;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int dist_merged_update = 1;      // distributed factorisation: one ownership-filtered update launch per panel (0: one launch per owned panel)
-  int trsm_slab = 1;               // panel triangular solves by trsm_tile_kernel (0: one 128x128x128 tile per workgroup)
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
@@ -212,10 +211,14 @@ struct GemmArgs {
   unsigned long long* timeline = nullptr; // diagnostic builds: per-workgroup life cycle + hardware id
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
-// X (mt*128 rows x 128, column-major ldx) <- X * linv^T in place, linv a 128 x 128 lower-triangular tile inverse
-// V (128 rows x nt*128 columns, column-major ldv) <- linv * V in place (tile step of the forward substitution)
-int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, int nt, int prof_kernel);
-int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, int mt, int prof_kernel);
+// Tile solves with one step of iterative refinement (gemm.hip: tile_solve_kernel); L = the 128 x 128 diagonal
+// tile of the factor (leading dimension ldl, zeros above the diagonal), linv its explicit inverse (ld 128):
+// X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place
+// V (128 rows x nt*128 columns, column-major ldv) <- L^{-1} V in place (tile step of the forward substitution)
+int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
+                     int nt, int prof_kernel);
+int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
+                     int mt, int prof_kernel);
 
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);

@@ -322,13 +322,11 @@ static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t
   return g;
 }
 
-// X (mt tiles of rows x one tile column) <- X * linv^T, in place
-static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, double* X, int64_t ld, const double* linv, int mt) {
-  if (ctx->trsm_slab) return launch_trsm_tile(ctx, st, X, ld, linv, mt, LPGP_K_TRSM);
-  GemmArgs g;
-  g.A = X; g.B = linv; g.C = X; g.lda = ld; g.ldb = TILE; g.ldc = ld;
-  g.mt = mt; g.nt = 1; g.k = TILE; g.alpha = 1.0; g.beta = 0.0; g.tri = 0;
-  return launch_gemm(ctx, st, 0, 0, g, LPGP_K_TRSM);
+// X (mt tiles of rows x one tile column) <- X * Ljj^{-T}, in place; Ljj = diagonal tile jt of the factor
+static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int jt, double* X, int mt) {
+  const int64_t ld = mat->cap;
+  return launch_trsm_tile(ctx, st, X, ld, mat->linv + (int64_t)jt * TILE * TILE, mat->a + (int64_t)jt * TILE * (ld + 1), ld, mt,
+                          LPGP_K_TRSM);
 }
 
 // Factor tile columns [c0, cl) (all rows down to T) right-looking by panels of nb columns with a
@@ -370,7 +368,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
       if (jt + 1 < T) {
         double* X = dj + tb;     // rows below, same tile column
-        LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
+        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, T - jt - 1));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
@@ -460,7 +458,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
       for (int jt = p0; jt < p1; ++jt) {
         double* X = rows + (int64_t)jt * tb * ld;
-        LPGP_TRY(panel_trsm(ctx, sP, X, ld, mat->linv + (int64_t)jt * tb * tb, mnew));
+        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, mnew));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
@@ -620,7 +618,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
       for (int jt = p0; jt < p1; ++jt) {
         double* X = rows + (int64_t)jt * tb * ld;
-        LPGP_TRY(panel_trsm(ctx, sP, X, ld, mat->linv + (int64_t)jt * tb * tb, mnew));
+        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, mnew));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
@@ -673,7 +671,7 @@ int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T
         LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
         if (jt + 1 < T) {
           double* X = dj + tb;
-          LPGP_TRY(panel_trsm(ctx, sP, X, ld, linv, T - jt - 1));
+          LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, T - jt - 1));
           if (jt + 1 < p1)
             LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
                                  mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
@@ -794,12 +792,8 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
     const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
     for (int jt = p0; jt < p1; ++jt) {
       double* Vj = v + (int64_t)jt * tb;
-      if (ctx->trsm_slab)
-        LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)jt * tb * tb, mtl, LPGP_K_TRSM));
-      else
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
-                             mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
-                             LPGP_K_TRSM));
+      LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)jt * tb * tb, a + (int64_t)jt * tb * (ld + 1), ld, mtl,
+                                LPGP_K_TRSM));
       if (jt + 1 < p1)
         LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
                              mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, ldv,
@@ -849,6 +843,8 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   return 0;
 }
 
+static int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols);
+
 // V <- L^{-T} V (backward substitution), same layout.
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
   const int T = (int)T64;
@@ -857,14 +853,23 @@ int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, i
   const int nbt = (int)(ctx->nb / TILE);
   const double* a = mat->a;
   hipStream_t st = ctx->s_main;
+  void* sp = nullptr;
+  const size_t sbytes = (size_t)TILE * (size_t)m_pad * sizeof(double);
+  if (pool_alloc(ctx, &sp, sbytes, nullptr) != 0) return -1;
+  double* S = (double*)sp;
+  struct Release { lpgp_ctx* c; void* p; size_t b; ~Release() { pool_free(c, p, b); } } release{ctx, sp, sbytes};   // reuse is stream-ordered
   for (int p1 = T; p1 > 0;) {
     const int p0 = (p1 - nbt > 0) ? p1 - nbt : 0;
     for (int jt = p1 - 1; jt >= p0; --jt) {
       double* Vj = v + (int64_t)jt * tb;
-      // x_jt = Linv_jt^T y_jt
-      LPGP_TRY(launch_gemm(ctx, st, 1, 1,
-                           mk(mat->linv + (int64_t)jt * tb * tb, tb, Vj, ldv, Vj, ldv, 1, mtl, TILE, 1.0, 0.0, 0),
-                           LPGP_K_TRSM));
+      // x_jt = L_jj^{-T} y_jt with one refinement step (see tile_solve_kernel): S = Linv^T y;  y <- y - L^T S;
+      // S <- S + Linv^T y;  y <- S.  (Not a hot path: `gram.solve(B)` / lpgp_potrs only.)
+      const double* linv = mat->linv + (int64_t)jt * tb * tb;
+      const double* Ljj = a + (int64_t)jt * tb * (ld + 1);
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(linv, tb, Vj, ldv, S, tb, 1, mtl, TILE, 1.0, 0.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(Ljj, ld, S, tb, Vj, ldv, 1, mtl, TILE, -1.0, 1.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(linv, tb, Vj, ldv, S, tb, 1, mtl, TILE, 1.0, 1.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(copy2d(st, Vj, ldv, S, tb, tb, m_pad));
       if (jt > p0)
         LPGP_TRY(launch_gemm(ctx, st, 1, 1,
                              mk(a + (int64_t)jt * tb + (int64_t)p0 * tb * ld, ld, Vj, ldv,
@@ -884,43 +889,86 @@ int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, i
 // ---------------------------------------------------------------------------------------
 // single right-hand side: representer weights  w = L^{-T} L^{-1} r   (_conditional.py:44,108)
 // One fused launch per 128-row tile: every workgroup first forms the solution of the tile
-// from the explicit tile inverse (128x128 matvec, L2 resident), then applies it to its own
-// slice of the remaining right-hand side.  x and b are distinct vectors, so no workgroup
-// reads what another one writes inside a launch.
+// from the explicit tile inverse (128x128 matvec, L2 resident) with ONE step of iterative refinement
+// against the diagonal tile of the factor (x0 = Linv b, x = x0 + Linv (b - L x0): a product with the
+// explicit inverse alone has a backward error of cond(L_tile) eps, see tile_solve_kernel in gemm.hip), then
+// applies it to its own slice of the remaining right-hand side.  x and b are distinct vectors, so no
+// workgroup reads what another one writes inside a launch.
 // ---------------------------------------------------------------------------------------
-// 128x128 matvec with the tile inverse, 512 threads: out[r] = sum_c M[c*128 + r] * in[c]
-__device__ __forceinline__ void tile_matvec(const double* __restrict__ M, const double* sin, double* part, double* out_g,
-                                            double* out_s, int t) {
+// 128x128 matvec, 512 threads: returns (M sin)[t] for t < 128 (M[r + c ldm]); part: 512 doubles of LDS
+__device__ __forceinline__ double tile_mv(const double* __restrict__ M, int64_t ldm, const double* sin, double* part, int t) {
   const int r = t & 127, qd = t >> 7;
   double acc = 0.0;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) acc = fma(M[(32 * qd + c) * TILE + r], sin[32 * qd + c], acc);
+  for (int c = 0; c < 32; ++c) acc = fma(M[(int64_t)(32 * qd + c) * ldm + r], sin[32 * qd + c], acc);
   part[t] = acc;
   __syncthreads();
-  if (t < TILE) {
-    const double v = (part[t] + part[t + 128]) + (part[t + 256] + part[t + 384]);
-    if (out_g) out_g[t] = v;
-    if (out_s) out_s[t] = v;
+  double v = 0.0;
+  if (t < TILE) v = (part[t] + part[t + 128]) + (part[t + 256] + part[t + 384]);
+  __syncthreads();
+  return v;
+}
+// transposed 128x128 matvec, 8 waves: sout[c] = sum_r M[r + c ldm] sin[r]  (valid after the trailing barrier)
+__device__ __forceinline__ void tile_mv_t(const double* __restrict__ M, int64_t ldm, const double* sin, double* sout, int t) {
+  const int lane = t & 63, w = t >> 6;
+  double acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double* Mc = M + (int64_t)(w * 16 + j) * ldm;
+    acc[j] = Mc[lane] * sin[lane] + Mc[lane + 64] * sin[lane + 64];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double a = acc[j];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) sout[w * 16 + j] = a;
+  }
+  __syncthreads();
+}
+// x = L^{-1} b (TRANS: L^{-T} b) for one tile, refined once; sb: right-hand side in LDS (128), s1 / s2: 128 doubles of
+// LDS scratch each, part: 512.  On return s1 holds x (all threads may read it after the call).
+template <bool TRANS>
+__device__ __forceinline__ void tile_solve_vec(const double* __restrict__ linv, const double* __restrict__ Lt, int64_t ldl,
+                                               const double* sb, double* s1, double* s2, double* part, int t) {
+  if (!TRANS) {
+    const double x0 = tile_mv(linv, TILE, sb, part, t);
+    if (t < TILE) s1[t] = x0;
+    __syncthreads();
+    const double lx = tile_mv(Lt, ldl, s1, part, t);
+    if (t < TILE) s2[t] = sb[t] - lx;
+    __syncthreads();
+    const double dx = tile_mv(linv, TILE, s2, part, t);
+    if (t < TILE) s1[t] = x0 + dx;
+    __syncthreads();
+  } else {
+    tile_mv_t(linv, TILE, sb, s1, t);                 // x0
+    tile_mv_t(Lt, ldl, s1, s2, t);                    // L^T x0
+    if (t < TILE) s2[t] = sb[t] - s2[t];
+    __syncthreads();
+    tile_mv_t(linv, TILE, s2, part, t);               // correction
+    if (t < TILE) s1[t] += part[t];
+    __syncthreads();
   }
 }
 
-// x_0 = Linv_0 b_0
-__global__ __launch_bounds__(512) void trsv_fwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ b,
-                                                             double* __restrict__ x) {
-  __shared__ double sb[TILE], part[512];
+// x_0 = L_00^{-1} b_0
+__global__ __launch_bounds__(512) void trsv_fwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ Lt, int64_t ld,
+                                                             const double* __restrict__ b, double* __restrict__ x) {
+  __shared__ double sb[TILE], s1[TILE], s2[TILE], part[512];
   const int t = threadIdx.x;
   if (t < TILE) sb[t] = b[t];
   __syncthreads();
-  tile_matvec(linv, sb, part, x, nullptr, t);
+  tile_solve_vec<false>(linv, Lt, ld, sb, s1, s2, part, t);
+  if (t < TILE) x[t] = s1[t];
 }
 
 // step k: b[rows > tile k] -= L[rows, tile k] * x_k; the workgroup that owns tile k+1 then
-// forms x_{k+1} = Linv_{k+1} b_{k+1} (its right-hand side is final after this update).
+// forms x_{k+1} = L_{k+1,k+1}^{-1} b_{k+1} (its right-hand side is final after this update).
 __global__ __launch_bounds__(512) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t ld,
                                                              const double* __restrict__ linv_next,
                                                              double* __restrict__ b, double* __restrict__ x,
                                                              int64_t k0) {
-  __shared__ double sy[TILE], sb[TILE], part[512];
+  __shared__ double sy[TILE], sb[TILE], s1[TILE], s2[TILE], part[512];
   const int t = threadIdx.x, r = t & 127, qd = t >> 7;
   if (t < TILE) sy[t] = x[k0 + t];
   __syncthreads();
@@ -938,42 +986,27 @@ __global__ __launch_bounds__(512) void trsv_fwd_step_kernel(const double* __rest
   }
   if (blockIdx.x != 0) return;
   __syncthreads();
-  tile_matvec(linv_next, sb, part, x + k0 + TILE, nullptr, t);
+  tile_solve_vec<false>(linv_next, L + (k0 + TILE) * (ld + 1), ld, sb, s1, s2, part, t);
+  if (t < TILE) x[k0 + TILE + t] = s1[t];
 }
 
-// transposed 128x128 matvec, 8 waves: out[c] = sum_r M[c*128 + r] * in[r]
-__device__ __forceinline__ void tile_matvec_t(const double* __restrict__ M, const double* sin, double* out_g, int t) {
-  const int lane = t & 63, w = t >> 6;
-  double acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int c = w * 16 + j;
-    acc[j] = M[c * TILE + lane] * sin[lane] + M[c * TILE + lane + 64] * sin[lane + 64];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double a = acc[j];
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-    if (lane == 0) out_g[w * 16 + j] = a;
-  }
-}
-
-// x_last = Linv_last^T y_last
-__global__ __launch_bounds__(512) void trsv_bwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ y,
-                                                             double* __restrict__ x) {
-  __shared__ double sy[TILE];
+// x_last = L_last^{-T} y_last
+__global__ __launch_bounds__(512) void trsv_bwd_head_kernel(const double* __restrict__ linv, const double* __restrict__ Lt, int64_t ld,
+                                                             const double* __restrict__ y, double* __restrict__ x) {
+  __shared__ double sy[TILE], s1[TILE], s2[TILE], part[TILE];
   const int t = threadIdx.x;
   if (t < TILE) sy[t] = y[t];
   __syncthreads();
-  tile_matvec_t(linv, sy, x, t);
+  tile_solve_vec<true>(linv, Lt, ld, sy, s1, s2, part, t);
+  if (t < TILE) x[t] = s1[t];
 }
 
 // step k (descending): y[c] -= L[tile k rows, c]^T x_k for 128 columns c per workgroup; the
-// workgroup that owns tile k-1 (the last one) then forms x_{k-1} = Linv_{k-1}^T y_{k-1}.
+// workgroup that owns tile k-1 (the last one) then forms x_{k-1} = L_{k-1,k-1}^{-T} y_{k-1}.
 __global__ __launch_bounds__(512) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t ld,
                                                              const double* __restrict__ linv_prev,
                                                              double* __restrict__ y, double* __restrict__ x, int64_t k0) {
-  __shared__ double sx[TILE], sy[TILE];
+  __shared__ double sx[TILE], sy[TILE], s1[TILE], s2[TILE], part[TILE];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < TILE) sx[t] = x[k0 + t];
   __syncthreads();
@@ -996,7 +1029,8 @@ __global__ __launch_bounds__(512) void trsv_bwd_step_kernel(const double* __rest
   }
   if (c0 + TILE != k0) return;                         // not the owner of tile k-1
   __syncthreads();
-  tile_matvec_t(linv_prev, sy, x + c0, t);
+  tile_solve_vec<true>(linv_prev, L + c0 * (ld + 1), ld, sy, s1, s2, part, t);
+  if (t < TILE) x[c0 + t] = s1[t];
 }
 
 // x <- L^{-1} b on `st` (padded length T*128, device); b is consumed as the running right-hand side
@@ -1005,7 +1039,7 @@ int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T64, dou
   const int64_t ld = mat->cap;
   const double* a = mat->a;
   auto linv = [&](int k) { return (const double*)(mat->linv + (int64_t)k * TILE * TILE); };
-  hipLaunchKernelGGL(trsv_fwd_head_kernel, dim3(1), dim3(512), 0, st, linv(0), (const double*)b, x);
+  hipLaunchKernelGGL(trsv_fwd_head_kernel, dim3(1), dim3(512), 0, st, linv(0), a, ld, (const double*)b, x);
   for (int k = 0; k + 1 < T; ++k)
     hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(T - k - 1), dim3(512), 0, st, a, ld, linv(k + 1), b, x,
                        (int64_t)k * TILE);
@@ -1024,7 +1058,7 @@ int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp)
   int rc = solve_vec_fwd(ctx, st, mat, T64, v, tmp);
   if (rc != 0) return rc;
   // backward: L^T v = tmp  (tmp is consumed as the running right-hand side)
-  hipLaunchKernelGGL(trsv_bwd_head_kernel, dim3(1), dim3(512), 0, st, linv(T - 1),
+  hipLaunchKernelGGL(trsv_bwd_head_kernel, dim3(1), dim3(512), 0, st, linv(T - 1), a + (int64_t)(T - 1) * TILE * (ld + 1), ld,
                      (const double*)(tmp + (int64_t)(T - 1) * TILE), v + (int64_t)(T - 1) * TILE);
   for (int k = T - 1; k >= 1; --k)
     hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k), dim3(512), 0, st, a, ld, linv(k - 1), tmp, v, (int64_t)k * TILE);

@@ -419,15 +419,16 @@ def test_gemm(ctx: Context, ta: int, tb: int, lower_only: int, alpha: float, A: 
     return Cm, ms.value
 
 
-def test_tile_step(ctx: Context, which: int, slab: bool, XV: np.ndarray, Linv: np.ndarray):
-    """In-place tile step on host buffers (`lpgp_test_tile_step`): which = 0: X (rows x 128) <- X Linv^T,
-    which = 1: V (128 x cols) <- Linv V.  Returns (result, milliseconds)."""
+def test_tile_step(ctx: Context, which: int, XV: np.ndarray, L: np.ndarray, Linv: np.ndarray):
+    """In-place refined tile solve on host buffers (`lpgp_test_tile_step`): which = 0: X (rows x 128) <- X L^{-T},
+    which = 1: V (128 x cols) <- L^{-1} V.  Returns (result, milliseconds)."""
     XV = np.asfortranarray(XV, dtype=np.double).copy(order="F")
-    Linv = np.asfortranarray(Linv, dtype=np.double)
+    L = np.asfortranarray(np.tril(L), dtype=np.double)
+    Linv = np.asfortranarray(np.tril(Linv), dtype=np.double)
     n = XV.shape[0] if which == 0 else XV.shape[1]
     ms = C.c_double(0.0)
     pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_tile_step(ctx._h, which, int(bool(slab)), XV.ctypes.data_as(pd), n, Linv.ctypes.data_as(pd),
+    check(lib.lpgp_test_tile_step(ctx._h, which, XV.ctypes.data_as(pd), n, L.ctypes.data_as(pd), Linv.ctypes.data_as(pd),
                                   C.byref(ms)), "lpgp_test_tile_step")
     return XV, ms.value
 

@@ -109,7 +109,7 @@ def _load() -> C.CDLL:
     sig("lpgp_test_gemm", C.c_int, vp, i32, i32, i32, i64, i64, i64, dbl, pd, i64, pd, i64, dbl, pd, i64, i32, pd)
     sig("lpgp_test_potrf_tile", C.c_int, vp, pd, pd, C.POINTER(i32))
     sig("lpgp_debug_tile_xcc", C.c_int, vp, C.POINTER(i32), i32)
-    sig("lpgp_test_tile_step", C.c_int, vp, i32, i32, pd, i64, pd, pd)
+    sig("lpgp_test_tile_step", C.c_int, vp, i32, pd, i64, pd, pd, pd)
     sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
     sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
     return lib

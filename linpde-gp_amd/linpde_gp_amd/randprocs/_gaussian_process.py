@@ -103,7 +103,7 @@ class _GramOperator:
 
     @property
     def shape(self):
-        n = self._cgp._state.mat.n
+        n = sum(ob.points.n for ob in self._cgp._blocks)
         return (n, n)
 
     def solve(self, B):

@@ -155,28 +155,32 @@ def test_matrix_free_product_throughput(ctx):
 
 
 @pytest.mark.parametrize("which,n", [(0, 128), (0, 640), (0, 16896), (1, 128), (1, 1152), (1, 4224)])
-def test_tile_step_slab_kernels(which, n):
-    """The in-place slab kernels of the panel chain (`trsm_tile_kernel`: X <- X Linv^T on n rows) and of
-    the forward substitution (`trsv_tile_kernel`: V <- Linv V on n right-hand sides) against NumPy and
-    against the same product on the general GEMM kernel; Linv lower triangular with garbage above the
-    diagonal (the kernels skip the stages beyond the diagonal instead of multiplying by zero)."""
+@pytest.mark.parametrize("cond", [1e1, 1e6])
+def test_tile_solve_refined(which, n, cond):
+    """The in-place tile solves of the panel chain (X <- X L^{-T} on n rows) and of the forward substitution
+    (V <- L^{-1} V on n right-hand sides), `tile_solve_kernel`: a product with the explicit fp64 inverse plus
+    ONE refinement step against the tile itself.  Must be as accurate as a substitution (LAPACK dtrsm) also
+    for an ill-conditioned tile (cond 1e6), where the unrefined product X0 = A Linv^T is ~cond eps off."""
+    import scipy.linalg
     import linpde_gp_amd  # noqa: F401
     from linpde_gp_amd import _engine
     ctx = _engine.default_context()
     rng = np.random.default_rng(100 * which + n % 97)
-    Linv = np.tril(rng.standard_normal((128, 128))) + 4.0 * np.eye(128)
+    # lower-triangular tile with prescribed condition number: Cholesky factor of Q diag(s) Q^T
+    Q, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+    sv = np.logspace(0, -np.log10(cond), 128)
+    L = np.linalg.cholesky((Q * sv**2) @ Q.T)
+    Linv = scipy.linalg.solve_triangular(L, np.eye(128), lower=True)
     XV = rng.standard_normal((n, 128) if which == 0 else (128, n))
-    ref = XV @ Linv.T if which == 0 else Linv @ XV
-    got, ms = _engine.test_tile_step(ctx, which, True, XV, Linv)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
-    via_gemm, ms_g = _engine.test_tile_step(ctx, which, False, XV, Linv)
-    np.testing.assert_allclose(via_gemm, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
-    # entries above the diagonal of Linv must not matter to the slab kernels
-    junk = Linv + np.triu(rng.standard_normal((128, 128)), 1) * 1e6
-    got2, _ = _engine.test_tile_step(ctx, which, True, XV, junk)
-    if which == 1:      # (the upper row half skips k >= 64 entirely; inside a stage the product is dense)
-        np.testing.assert_allclose(got2[:64], (np.tril(junk[:64, :64]) + np.triu(junk[:64, :64], 1)) @ XV[:64], rtol=0,
-                                   atol=1e-6 * np.abs(got2).max())
+    exact = scipy.linalg.solve_triangular(L, XV.T if which == 0 else XV, lower=True)
+    exact = exact.T if which == 0 else exact
+    got, ms = _engine.test_tile_step(ctx, which, XV, L, Linv)
+    # backward error of the solve: residual against the right-hand side, relative to |X||L| -- the measure that is
+    # eps for a substitution and cond * eps for a bare product with the explicit inverse
+    res = (got @ L.T - XV) if which == 0 else (L @ got - XV)
+    scale = (np.abs(got) @ np.abs(L.T)) if which == 0 else (np.abs(L) @ np.abs(got))
+    assert np.max(np.abs(res) / scale) < 2e-14, np.max(np.abs(res) / scale)
+    np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * cond / 1e6 * np.abs(exact).max() + 1e-13 * np.abs(exact).max())
 
 
 @pytest.mark.parametrize("T,world,rank,base", [(20, 2, 1, 0), (23, 3, 0, 2), (37, 4, 3, 1), (9, 8, 5, 3)])
