@@ -620,20 +620,69 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
 // That layout IS the instruction's m-side operand layout for k-step u, so the result fragments of one
 // product are the operand fragments of the next: they are exchanged between the four waves of a group
 // through a 16-KB LDS image `xa[group][fragment][lane]`, never reshuffled.  The triangular factor is
-// streamed through a 3-stage LDS-DMA ring of 16 k-rows x 128 columns (image [k][136]: the four k-rows of a
-// replicated n-side fragment read fall into four different bank groups), 24 stages in all: Linv^T, L^T,
-// Linv^T.  Fragment u needs k-steps g <= u only (lower triangle): stage kt feeds the fragments u >= 4 kt,
+// streamed by LDS-DMA in 24 stages of 16 k-rows (Linv^T, L^T, Linv^T) through a statically scheduled circular
+// buffer (below).  Fragment u needs k-steps g <= u only (lower triangle): stage kt feeds the fragments u >= 4 kt,
 // 144 MFMAs per wave and product instead of 256; the fragments of a stage's own diagonal block meet the
 // explicit zeros above the diagonal of Linv / L.  The two groups take their classes in opposite order, so
 // every SIMD holds a wave with 4 cc and one with 4 (3 - cc) columns beyond the stage's diagonal.
-// LDS: 32 KB + 3 x 17 KB = 85 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup.
+// LDS: 32 KB + 52 KB = 84 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup.
 // =========================================================================================
-constexpr int TSV_LDB = 136;                 // B image: row stride in doubles (2 * 136 % 64 == 16)
-constexpr int TSV_STAGE = 16 * TSV_LDB;      // doubles per stage
-constexpr int TSV_STAGES = 3;
 constexpr int TSV_NSTAGE = 24;               // 3 products x 8 stages of 16 k
 constexpr int TSV_XA = 2 * 32 * 64;          // doubles: two row groups x 32 fragments x 64 lanes
 constexpr int TSV_ROWS = 32;                 // rows (KFAST: right-hand-side columns) per workgroup
+constexpr int TSV_RING = 6656;               // doubles: byte-granular ring of factor stages (52 KB)
+
+// Stage s = (product s / 8, k-rows 16 kt .. 16 kt + 15, kt = s % 8) holds only the columns the lower triangle
+// needs, c >= 16 kt: 16 rows of 128 - 16 kt doubles at a row stride of 136 - 16 kt (2 * stride % 64 is 16 or 48:
+// the four k-rows of a replicated n-side fragment read fall into four different bank groups).  The stages are
+// placed in ONE circular buffer by a schedule computed at compile time (the whole stage loop is unrolled):
+// at the top of stage s, right behind its barrier, every following stage that fits beside the stages still in
+// use is issued.  The kernel is bound by the latency of these loads, not by their bytes or the matrix work
+// (measured with three fixed 17-KB slots, two in flight: 18 us for one wave of workgroups against 6 us of
+// MFMA time): what counts is bytes in flight per byte to fetch, and the trimmed stages put 4-5 of them in
+// flight in the same 52 KB.
+constexpr int tsv_stride(int s) { return 136 - 16 * (s % 8); }
+constexpr int tsv_size(int s) { return 16 * tsv_stride(s); }
+struct TsvSched {
+  int off[TSV_NSTAGE] = {};        // ring offset of stage s (doubles)
+  int iss_lo[TSV_NSTAGE + 1] = {}; // stages [iss_lo[t], iss_hi[t]) are issued at time t: t = 0 before the loop,
+  int iss_hi[TSV_NSTAGE + 1] = {}; // t = s + 1 at the top of stage s (behind its barrier)
+  int wait[TSV_NSTAGE] = {};       // vmcnt at the top of stage s: this wave's DMA instructions of later stages in flight
+};
+constexpr TsvSched tsv_make_sched() {
+  TsvSched S;
+  int next = 0, head = 0;
+  for (int t = 0; t <= TSV_NSTAGE; ++t) {
+    const int live_lo = t == 0 ? 0 : t - 1;          // stages >= live_lo are in use or in flight
+    S.iss_lo[t] = next;
+    while (next < TSV_NSTAGE) {
+      const int sz = tsv_size(next);
+      int o = head;
+      if (o + sz > TSV_RING) o = 0;
+      bool ok = true;
+      for (int l = live_lo; l < next; ++l)
+        if (o < S.off[l] + tsv_size(l) && S.off[l] < o + sz) ok = false;
+      if (!ok) break;
+      S.off[next] = o;
+      head = o + sz;
+      ++next;
+    }
+    S.iss_hi[t] = next;
+    if (t < TSV_NSTAGE) {
+      // stage t must have been issued by now (the ring holds any single stage)
+      S.wait[t] = 2 * (next - (t + 1));
+    }
+  }
+  return S;
+}
+constexpr TsvSched TSV_SCHED = tsv_make_sched();
+static_assert(TSV_SCHED.iss_hi[TSV_NSTAGE] == TSV_NSTAGE, "tile solve: a stage was never issued");
+constexpr bool tsv_sched_ok() {
+  for (int s = 0; s < TSV_NSTAGE; ++s)
+    if (TSV_SCHED.iss_hi[s] < s + 1 || TSV_SCHED.wait[s] < 0 || TSV_SCHED.wait[s] > 62) return false;   // issued before it is awaited
+  return true;
+}
+static_assert(tsv_sched_ok(), "tile solve: broken stage schedule");
 
 struct TileSolveArgs {
   double* P;
@@ -649,6 +698,16 @@ __device__ __forceinline__ void lds_wait_n() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+template <int N>
+__device__ __forceinline__ void vm_wait_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Workgroup barrier WITHOUT the fence of __syncthreads(): hipcc turns that fence into s_waitcnt vmcnt(0) whenever
+// LDS-DMA is in flight (a DMA writes LDS), which would serialise the stage prefetch.  What a barrier of this
+// kernel needs is waited for explicitly: the wave's own LDS reads / writes (lgkmcnt) here, its DMA pieces of the
+// stage about to be read by the counted vmcnt wait in front of it.
+#define TSV_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <bool KFAST>
 __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
@@ -663,37 +722,47 @@ __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
   const int64_t i0 = (int64_t)blockIdx.x * TSV_ROWS + rg * 16 + li;      // this lane's row
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
 
-  // stage s of the factor stream: product s / 8 (0, 2: Linv^T; 1: L^T), k-rows 16 (s % 8) ...; element
-  // (k, c) of M^T is M[c + k ldm]: one k-row = 128 contiguous doubles = one DMA wave instruction
-  auto issue = [&](int s) {
-    const int p = s >> 3, kt = s & 7;
+  // stage s of the factor stream: product s / 8 (0, 2: Linv^T; 1: L^T); element (k, c) of M^T is M[c + k ldm]:
+  // one k-row from column 16 kt on = up to 128 contiguous doubles = one DMA wave instruction (lanes beyond the
+  // row are masked off), two rows per wave
+  auto issue = [&](auto S_) {
+    constexpr int s = decltype(S_)::value;
+    constexpr int p = s / 8, kt = s % 8, len = 128 - 16 * kt, stride = tsv_stride(s);
     const double* M = (p == 1) ? g.L : g.linv;
     const int64_t ldm = (p == 1) ? g.ldl : (int64_t)TILE;
-    double* sb = ring + (size_t)(s % TSV_STAGES) * TSV_STAGE;
+    double* sb = ring + TSV_SCHED.off[s];
+    if (2 * lane < len) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = 2 * wu + h;
-      const char* ub = reinterpret_cast<const char*>(M + ((int64_t)kt * 16 + r) * ldm);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + r * TSV_LDB), 16, 0, 0);
+      for (int h = 0; h < 2; ++h) {
+        const int r = 2 * wu + h;
+        const char* ub = reinterpret_cast<const char*>(M + 16 * kt + ((int64_t)kt * 16 + r) * ldm);
+        __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + r * stride), 16, 0, 0);
+      }
     }
   };
-
-  // own fragments of A (fragment u = cc + 4 q: element (row, column 4u + lj))
+  // own fragments of A (fragment u = cc + 4 q: element (row, column 4u + lj)); loaded BEFORE the first factor
+  // stages are requested: vector-memory operations return in order, so the wait for these fragments must not
+  // include the stages
   double a[8], x[8];
   double* const pbase = KFAST ? g.P + i0 * g.ld + (4 * cc + lj) : g.P + i0 + (int64_t)(4 * cc + lj) * g.ld;
   const int64_t pstep = KFAST ? 16 : 16 * g.ld;                            // fragment q -> q + 1: 16 columns on
 #pragma unroll
   for (int q = 0; q < 8; ++q) a[q] = pbase[q * pstep];
-  issue(0);
-  issue(1);
+  asm volatile("" ::: "memory");
+  issue(std::integral_constant<int, 0>{});        // full rows: no lane mask, no branch
   double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;            // fragment q of this wave: xown[q * 256]
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     xown[q * 256] = a[q];
     x[q] = 0.0;
   }
+  // (behind the use of a[]: hipcc waits vmcnt(0) at the first use of a loaded value that follows a lane-masked
+  //  branch, i.e. it would wait for these stages too)
+  asm volatile("" ::: "memory");
+  static_for<1, TSV_SCHED.iss_hi[0]>(issue);
   const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
-  const unsigned nlane = lds_base + 8u * (unsigned)(TSV_XA + lj * TSV_LDB + (lane & 3) + 4 * cc);
+  const unsigned nlane = lds_base + 8u * (unsigned)(TSV_XA + lj * 136 + (lane & 3) + 4 * cc);
+  const unsigned lj128 = (unsigned)lj * 128u;                              // bytes a row stride shrinks per kt, times lj
 
   // dst[q] += sum over k-steps g <= u of (operand fragment g from xa) x (factor fragment (g, u)), u = cc + 4 q
   auto run_product = [&](auto P_, double(&dst)[8]) {
@@ -701,18 +770,17 @@ __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
     static_for<0, 8>([&](auto KT_) {
       constexpr int kt = decltype(KT_)::value;
       constexpr int s = prod * 8 + kt;
-      // this wave's DMA pieces of stage s have landed (two per stage; stage s + 1 may be in flight) ...
-      if constexpr (s + 1 < TSV_NSTAGE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                     // ... everybody's have, stage s - 1 is consumed, xa of this product is written
-      if constexpr (s + 2 < TSV_NSTAGE) issue(s + 2);
-      const unsigned aN = nlane + (unsigned)((s % TSV_STAGES) * TSV_STAGE) * 8u;
+      constexpr int stride = tsv_stride(s);
+      vm_wait_n<TSV_SCHED.wait[s]>();      // this wave's DMA pieces of stage s have landed ...
+      TSV_BARRIER();                     // ... everybody's have, stage s - 1 is consumed, xa of this product is written
+      static_for<TSV_SCHED.iss_lo[s + 1], TSV_SCHED.iss_hi[s + 1]>(issue);
+      const unsigned aN = nlane + (unsigned)TSV_SCHED.off[s] * 8u - (unsigned)kt * lj128;
       double mf[2], nf[2][8];
       asm volatile("" ::: "memory");
       mf[0] = lds_read_async<(4 * kt) * 64>(mlane);
       static_for<kt, 8>([&](auto Q_) {
         constexpr int q = decltype(Q_)::value;
-        nf[0][q] = lds_read_async<16 * q>(aN);
+        nf[0][q] = lds_read_async<16 * (q - kt)>(aN);
       });
       static_for<0, 4>([&](auto K_) {
         constexpr int ks = decltype(K_)::value;
@@ -720,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
           mf[(ks + 1) & 1] = lds_read_async<(4 * kt + ks + 1) * 64>(mlane);
           static_for<kt, 8>([&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
-            nf[(ks + 1) & 1][q] = lds_read_async<(ks + 1) * 4 * TSV_LDB + 16 * q>(aN);
+            nf[(ks + 1) & 1][q] = lds_read_async<(ks + 1) * 4 * stride + 16 * (q - kt)>(aN);
           });
           lds_wait_n<9 - kt>();
         } else {
@@ -736,11 +804,11 @@ __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
   };
 
   run_product(std::integral_constant<int, 0>{}, x);          // x = X0 = A Linv^T
-  __syncthreads();                                            // nobody reads the fragments of A any more
+  TSV_BARRIER();                                            // nobody reads the fragments of A any more
 #pragma unroll
   for (int q = 0; q < 8; ++q) xown[q * 256] = -x[q];
   run_product(std::integral_constant<int, 1>{}, a);          // a = R = A - X0 L^T
-  __syncthreads();
+  TSV_BARRIER();
 #pragma unroll
   for (int q = 0; q < 8; ++q) xown[q * 256] = a[q];
   run_product(std::integral_constant<int, 2>{}, x);          // x = X0 + R Linv^T
@@ -753,7 +821,7 @@ template <bool KFAST>
 static int launch_tile_solve(lpgp_ctx* ctx, hipStream_t stream, double* P, int64_t ld, const double* linv, const double* L,
                              int64_t ldl, int64_t rows, int prof_kernel) {
   if (rows <= 0) return 0;
-  const size_t shmem = (size_t)(TSV_XA + TSV_STAGES * TSV_STAGE) * sizeof(double);   // 84 992 B
+  const size_t shmem = (size_t)(TSV_XA + TSV_RING) * sizeof(double);   // 86 016 B
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&tile_solve_kernel<KFAST>), shmem));
   TileSolveArgs a;
   a.P = P; a.ld = ld; a.linv = linv; a.L = L; a.ldl = ldl;
