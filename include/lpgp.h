@@ -72,21 +72,32 @@ int  lpgp_sync(lpgp_ctx* ctx);                       /* hipDeviceSynchronize */
 int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
- * Panels of the blocked Cholesky (nb columns) are owned cyclically by rank (a 1 x P
- * block-cyclic process grid); the owner factors a panel and broadcasts it (ncclBroadcast)
- * while every rank applies it to the columns it owns.  Received panels are kept, so every
- * rank ends with the full factor and prediction needs no further communication.  Rank 0
- * creates the id, the caller ships the 128 bytes to the other ranks (any control plane),
- * every rank then calls lpgp_dist_init before its first lpgp_gram_assemble.               */
+ * Pr x Pc process grid (rank = r * Pc + c), 2-D block-cyclic tiles: tile (i, j) of the padded matrix lives on
+ * rank ((i / 4) % Pr, (j / 4) % Pc) (blocks of nb = 512 rows / columns) and ONLY there -- the factor is sharded,
+ * never replicated (only its nb x nb diagonal blocks and the tile inverses are kept everywhere).  Assembly is local
+ * (every rank evaluates the tiles it owns).  The rows below a factored panel travel from the Pr ranks of its process
+ * column to every rank by point-to-point sends posted as one RCCL group (direct peer copies over the xGMI mesh);
+ * every rank then updates its own tiles.  Solves stream the factor panel by panel against right-hand sides that
+ * are sharded by column (csrc/dist.hip).
+ * Rank 0 creates the id, the caller ships the 128 bytes to the other ranks (any control plane), every rank then
+ * calls lpgp_dist_init before its first lpgp_mat_create.  lpgp_dist_set_grid (optional, before lpgp_dist_init /
+ * lpgp_dist_init_host, the same on every rank) fixes Pr x Pc; the default is Pr = world, Pc = 1: on the
+ * full mesh of xGMI links every link then carries 1 / world of a panel.
+ * All lpgp_* calls that touch a distributed matrix are COLLECTIVE: every rank makes them in the same order.   */
 int  lpgp_dist_unique_id(char* out128);
+int  lpgp_dist_set_grid(lpgp_ctx* ctx, int32_t pr, int32_t pc);
 int  lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128);
 int  lpgp_dist_info(lpgp_ctx* ctx, int32_t* rank, int32_t* world);
-/* Bring-up / test transport: the same distributed factorisation with every panel staged through
- * the host and handed to a caller-supplied exchange (op 0: broadcast `bytes` bytes of buf from
- * rank `root`; op 1: element-wise max all-reduce of one int32 in buf; return 0 on success) instead
- * of RCCL.  Ranks may then share ONE GPU (RCCL refuses that), which is how tests/test_gpu_dist.py
- * runs 2- and 3-rank jobs on the single-GPU box.  All arithmetic still runs on the device; it is
- * not a data path of the product (bench.py never selects it).                               */
+int  lpgp_dist_grid(lpgp_ctx* ctx, int32_t* pr, int32_t* pc);
+/* bytes this rank has sent / received in panel exchanges since lpgp_init (or the last call with reset != 0);
+ * the time inside them is profiling slot LPGP_K_COMM                                                        */
+int  lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, int32_t reset);
+/* Bring-up / test transport: the same distributed algorithms with every message staged through the host and
+ * handed to a caller-supplied exchange (op 0: broadcast `bytes` bytes of buf from rank `root`; op 1: element-wise
+ * max all-reduce of one int32 in buf; return 0 on success) instead of RCCL.  Ranks may then share ONE GPU (RCCL
+ * refuses that), which is how tests/test_gpu_dist.py runs 2-, 3- and 4-rank jobs (2 x 2 grid included) on the
+ * single-GPU box.  All arithmetic still runs on the device; it is not a data path of the product (bench.py never
+ * selects it).                                                                                              */
 typedef int (*lpgp_host_exchange_fn)(void* user, int32_t op, void* buf, int64_t bytes, int32_t root);
 int  lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user);
 
@@ -217,7 +228,8 @@ enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing u
                       LPGP_K_SYRK_AHEAD = 8 /* look-ahead half of the trailing update (next panel's columns) */,
                       LPGP_K_ASSEMBLE_GRID = 9 /* tensor-grid (Kronecker) expansion kernels; LPGP_K_ASSEMBLE = per-entry kernel */,
                       LPGP_K_PANEL = 10 /* fused panel factorisation / fused substitution tile steps */,
-                      LPGP_K_COUNT = 11 };
+                      LPGP_K_COMM = 11 /* multi-GPU panel exchanges (bytes = sent + received by this rank) */,
+                      LPGP_K_COUNT = 12 };
 /* mask: bit k enables HIP-event bracketing of kernel id k (0 = off, -1 = all)          */
 int  lpgp_profile_enable(lpgp_ctx* ctx, int32_t mask);
 int  lpgp_profile_reset(lpgp_ctx* ctx);
@@ -227,6 +239,12 @@ int  lpgp_profile_get(lpgp_ctx* ctx, int32_t kernel_id, double* ms, int64_t* lau
                       double* flops, double* bytes);
 
 /* ---- raw kernels for unit tests / microbenchmarks (device work on host buffers) ----- */
+/* HOST replay of the tile enumeration of a distributed trailing update (no GPU needed): the local tiles of rank
+ * (my_r, my_c) of a pr x pc grid in rows [row_lo, T) x columns [col_lo, T) (GLOBAL tile indices, blocks of nbt tiles)
+ * that lie on or below the diagonal, in launch order.  out (capacity cap pairs): (global tile row, global tile column)
+ * per list entry; returns the number of tiles (< 0: error).                                          */
+int  lpgp_test_stair_enumerate(int32_t pr, int32_t pc, int32_t my_r, int32_t my_c, int32_t nbt, int32_t T,
+                               int32_t row_lo, int32_t col_lo, int32_t* out, int64_t cap);
 /* C(m x n, col-major ldc) = beta*C + alpha * op(A) op(B); ta/tb: 0 => operand stored with
  * its non-contracted index fastest, 1 => contracted index (k) fastest.                  */
 int  lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only,

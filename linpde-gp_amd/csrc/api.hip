@@ -61,9 +61,11 @@ int prof_collect(lpgp_ctx* ctx) {
 // ---------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------
-__global__ void set_identity_kernel(double* a, int64_t ld, int64_t from, int64_t to) {
+__global__ void set_identity_kernel(double* a, int64_t ld, int64_t from, int64_t to, Layout2D lay) {
   int64_t i = from + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < to) a[i * (ld + 1)] = 1.0;
+  if (i >= to) return;
+  const int64_t lr = cyc_local(lay.rows, i), lc = cyc_local(lay.cols, i);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] = 1.0;
 }
 
 // out[j] = sum_i K[i + j*ld] * (w ? w[i] : K[i + j*ld])   over i < rows; one block per column
@@ -184,11 +186,18 @@ void pool_free(lpgp_ctx* ctx, void* p, size_t bytes) {
   ctx->pool.push_back({p, bytes});
 }
 
-__global__ void clear_rows_kernel(double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc) {
-  // zero the strip rows [r0, r0+nr) x cols [c0, c0+nc)
+__global__ void clear_rows_kernel(double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc, Layout2D lay) {
+  // zero the strip rows [r0, r0+nr) x cols [c0, c0+nc) of the GLOBAL padded matrix (the part this rank owns)
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t c = blockIdx.y;
-  if (i < nr && c < nc) a[(r0 + i) + (c0 + c) * ld] = 0.0;
+  int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (i >= nr || c >= nc) return;
+  const int64_t lr = cyc_local(lay.rows, r0 + i), lc = cyc_local(lay.cols, c0 + c);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] = 0.0;
+}
+static void launch_clear_rows(hipStream_t st, double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc, const Layout2D& lay) {
+  if (nr <= 0 || nc <= 0) return;
+  const unsigned gy = (unsigned)(nc < 65535 ? nc : 65535), gz = (unsigned)((nc + 65534) / 65535);
+  hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((nr + 255) / 256), gy, gz), dim3(256), 0, st, a, ld, r0, nr, c0, nc, lay);
 }
 
 static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
@@ -201,42 +210,56 @@ static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
   return 0;
 }
 
-static size_t mat_bytes_a(int64_t cap) { return (size_t)cap * cap * sizeof(double); }
+// layout of the matrix of this context: identity on a single GPU, the rank's share of the Pr x Pc grid otherwise
+static Layout2D mat_layout(const lpgp_ctx* ctx) { return ctx->distributed() ? ctx->layout() : Layout2D(); }
+static int64_t local_rows(const lpgp_ctx* ctx, int64_t padded) { return (int64_t)cyc_before(mat_layout(ctx).rows, (int)(padded / TILE)) * TILE; }
+static int64_t local_cols(const lpgp_ctx* ctx, int64_t padded) { return (int64_t)cyc_before(mat_layout(ctx).cols, (int)(padded / TILE)) * TILE; }
+
+static size_t mat_bytes_a(const lpgp_mat* m) { return (size_t)m->lr_cap * m->lc_cap * sizeof(double); }
 static size_t mat_bytes_l(int64_t cap) { return (size_t)cap * TILE * sizeof(double); }
 static size_t mat_bytes_w(int64_t cap) { return (size_t)2 * cap * sizeof(double); }   // w | r
+static size_t mat_bytes_d(const lpgp_ctx* ctx, int64_t cap) { return (size_t)round_up(cap, ctx->nb) * ctx->nb * sizeof(double); }
 
 static void mat_release(lpgp_ctx* ctx, lpgp_mat* mat) {
-  pool_free(ctx, mat->a, mat_bytes_a(mat->cap));
+  pool_free(ctx, mat->a, mat_bytes_a(mat));
   pool_free(ctx, mat->linv, mat_bytes_l(mat->cap));
   pool_free(ctx, mat->w, mat_bytes_w(mat->cap));
-  mat->a = mat->linv = mat->w = nullptr;
+  if (mat->dblk) pool_free(ctx, mat->dblk, mat_bytes_d(ctx, mat->cap));
+  mat->a = mat->linv = mat->w = mat->dblk = nullptr;
 }
 
 static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
-  // (re)allocate to `cap` (multiple of TILE) keeping the content of the first mat->pn rows/cols.
+  // (re)allocate to `cap` (multiple of TILE) keeping the content of the first mat->pn rows/cols (of this rank's
+  // share: the local index of a tile does not depend on the capacity).
   // Invariant kept for every buffer handed out: nothing is assumed about the lower triangle
   // of logical blocks (assembly overwrites it) nor about tiles above the diagonal (never
   // read); the padding strips of a block are cleared in lpgp_mat_add_block.
-  void *na = nullptr, *nl = nullptr, *nw = nullptr;
-  int rc = pool_alloc(ctx, &na, mat_bytes_a(cap), nullptr);
+  const Layout2D lay = mat_layout(ctx);
+  int64_t lr = local_rows(ctx, cap), lc = local_cols(ctx, cap);
+  if (lr < TILE) lr = TILE;
+  if (lc < TILE) lc = TILE;
+  lpgp_mat fresh_dims;
+  fresh_dims.lr_cap = lr; fresh_dims.lc_cap = lc;
+  void *na = nullptr, *nl = nullptr, *nw = nullptr, *nd = nullptr;
+  int rc = pool_alloc(ctx, &na, mat_bytes_a(&fresh_dims), nullptr);
   if (rc == 0) rc = pool_alloc(ctx, &nl, mat_bytes_l(cap), nullptr);
   if (rc == 0) rc = pool_alloc(ctx, &nw, mat_bytes_w(cap), nullptr);
+  if (rc == 0 && ctx->distributed()) rc = pool_alloc(ctx, &nd, mat_bytes_d(ctx, cap), nullptr);
   if (rc != 0) return rc;
-  if (mat->a && mat->pn > 0) {
-    LPGP_HIP(hipMemcpy2DAsync(na, (size_t)cap * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
-                              (size_t)mat->pn * sizeof(double), (size_t)mat->pn, hipMemcpyDeviceToDevice,
-                              ctx->s_main));
-    LPGP_HIP(hipMemcpyAsync(nl, mat->linv, (size_t)mat->pn * TILE * sizeof(double), hipMemcpyDeviceToDevice,
+  const int64_t pn_all = mat->hidden.empty() ? mat->pn : mat->hidden.back().poff + mat->hidden.back().pn;
+  if (mat->a && pn_all > 0) {
+    const int64_t lru = local_rows(ctx, pn_all), lcu = local_cols(ctx, pn_all);
+    if (lru > 0 && lcu > 0)
+      LPGP_HIP(hipMemcpy2DAsync(na, (size_t)lr * sizeof(double), mat->a, (size_t)mat->lr_cap * sizeof(double),
+                                (size_t)lru * sizeof(double), (size_t)lcu, hipMemcpyDeviceToDevice, ctx->s_main));
+    LPGP_HIP(hipMemcpyAsync(nl, mat->linv, (size_t)pn_all * TILE * sizeof(double), hipMemcpyDeviceToDevice,
                             ctx->s_main));
-    LPGP_HIP(hipMemcpyAsync(nw, mat->w, (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+    LPGP_HIP(hipMemcpyAsync(nw, mat->w, (size_t)pn_all * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+    if (nd) LPGP_HIP(hipMemcpyAsync(nd, mat->dblk, mat_bytes_d(ctx, pn_all), hipMemcpyDeviceToDevice, ctx->s_main));
     // padding columns of the existing blocks must stay zero in the rows added by the growth
     for (const auto& b : mat->blocks) {
       const int64_t padc = b.pn - b.n;
-      if (padc > 0) {
-        const int64_t r0 = mat->pn, nr = cap - mat->pn;
-        hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((nr + 255) / 256), (unsigned)padc), dim3(256), 0,
-                           ctx->s_main, (double*)na, cap, r0, nr, b.poff + b.n, padc);
-      }
+      if (padc > 0) launch_clear_rows(ctx->s_main, (double*)na, lr, pn_all, cap - pn_all, b.poff + b.n, padc, lay);
     }
   }
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
@@ -244,7 +267,10 @@ static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
   mat->a = (double*)na;
   mat->linv = (double*)nl;
   mat->w = (double*)nw;
+  mat->dblk = (double*)nd;
   mat->cap = cap;
+  mat->lr_cap = lr;
+  mat->lc_cap = lc;
   mat->has_r = 0;            // the residual segment is addressed relative to cap
   return 0;
 }
@@ -377,6 +403,8 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipFree(ctx->d_info);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->d_panel[i]) (void)hipFree(ctx->d_panel[i]);
   if (ctx->nccl_comm) (void)ncclCommDestroy((ncclComm_t)ctx->nccl_comm);
   for (auto& b : ctx->pool) (void)hipFree(b.p);
   ctx->pool.clear();
@@ -412,9 +440,6 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   if (std::strcmp(key, "nb") == 0) {
     LPGP_CHECK(value >= TILE && value % TILE == 0, "nb must be a positive multiple of %d", TILE);
     ctx->nb = value;
-  } else if (std::strcmp(key, "test_assemble_as") == 0) {      // world * 1000 + rank, 0 = off (tests only)
-    ctx->test_own_world = (int)(value / 1000);
-    ctx->test_own_rank = (int)(value % 1000);
   } else if (std::strcmp(key, "small_tiles_max") == 0) {
     ctx->small_tiles_max = (int)value;
   } else if (std::strcmp(key, "chain_us_tile") == 0) {
@@ -423,8 +448,6 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->solve_chain_us_tile = (double)value;
   } else if (std::strcmp(key, "chain_us_fixed") == 0) {
     ctx->chain_us_fixed = (double)value;
-  } else if (std::strcmp(key, "dist_merged_update") == 0) {
-    ctx->dist_merged_update = (int)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
@@ -461,9 +484,43 @@ int lpgp_dist_unique_id(char* out128) {
   return 0;
 }
 
+// default process grid for `world` ranks: Pr = world, Pc = 1.  On the full mesh of xGMI links (every GPU a direct
+// link to every other) a gathered panel of S bytes costs a link S / Pr: a tall grid keeps
+// every link at 1 / world of the panel, shares the panel triangular solve among all ranks and needs no row exchange.
+static void choose_grid(lpgp_ctx* ctx, int world) {
+  if (ctx->grid_set && ctx->pr * ctx->pc == world) return;
+  ctx->pr = world;
+  ctx->pc = 1;
+}
+
+int lpgp_dist_set_grid(lpgp_ctx* ctx, int32_t pr, int32_t pc) {
+  LPGP_CHECK(ctx && pr >= 1 && pc >= 1 && pr <= 8 && pc <= 8, "lpgp_dist_set_grid: bad grid %d x %d", pr, pc);
+  LPGP_CHECK(!ctx->distributed(), "lpgp_dist_set_grid: call before lpgp_dist_init");
+  ctx->pr = pr;
+  ctx->pc = pc;
+  ctx->grid_set = 1;
+  return 0;
+}
+
+int lpgp_dist_grid(lpgp_ctx* ctx, int32_t* pr, int32_t* pc) {
+  LPGP_CHECK(ctx != nullptr, "lpgp_dist_grid: null context");
+  if (pr) *pr = ctx->pr;
+  if (pc) *pc = ctx->pc;
+  return 0;
+}
+
+int lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, int32_t reset) {
+  LPGP_CHECK(ctx != nullptr, "lpgp_dist_stats: null context");
+  if (bytes_sent) *bytes_sent = ctx->comm_bytes_sent;
+  if (bytes_received) *bytes_received = ctx->comm_bytes_recv;
+  if (reset) ctx->comm_bytes_sent = ctx->comm_bytes_recv = 0.0;
+  return 0;
+}
+
 int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128) {
   LPGP_CHECK(ctx && uid128 && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init: bad argument");
   LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init: already initialised");
+  LPGP_CHECK(!ctx->grid_set || ctx->pr * ctx->pc == world, "lpgp_dist_init: grid %d x %d does not match %d ranks", ctx->pr, ctx->pc, world);
   LPGP_HIP(hipSetDevice(ctx->device));
   ncclUniqueId id;
   std::memcpy(&id, uid128, 128);
@@ -473,6 +530,7 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
   ctx->nccl_comm = comm;
   ctx->rank = rank;
   ctx->world = world;
+  choose_grid(ctx, world);
   return 0;
 }
 
@@ -480,10 +538,12 @@ int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_ex
   LPGP_CHECK(ctx && fn && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init_host: bad argument");
   LPGP_DEVICE(ctx);
   LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init_host: already initialised");
+  LPGP_CHECK(!ctx->grid_set || ctx->pr * ctx->pc == world, "lpgp_dist_init_host: grid %d x %d does not match %d ranks", ctx->pr, ctx->pc, world);
   ctx->host_xfer = fn;
   ctx->host_xfer_user = user;
   ctx->rank = rank;
   ctx->world = world;
+  choose_grid(ctx, world);
   return 0;
 }
 
@@ -567,14 +627,12 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   if (pad > 0) {
     // identity tail of the block: zero the pad rows (all columns up to the block end) and the
     // pad columns (all rows down to the capacity), then ones on the diagonal
+    const Layout2D lay = mat_layout(ctx);
     const int64_t r0 = b.poff + b.n;
-    hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((pad + 255) / 256), (unsigned)(b.poff + b.pn)), dim3(256),
-                       0, ctx->s_main, mat->a, mat->cap, r0, pad, (int64_t)0, b.poff + b.pn);
-    const int64_t nr = mat->cap - r0;
-    hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((nr + 255) / 256), (unsigned)pad), dim3(256), 0,
-                       ctx->s_main, mat->a, mat->cap, r0, nr, r0, pad);
+    launch_clear_rows(ctx->s_main, mat->a, mat->lr_cap, r0, pad, 0, b.poff + b.pn, lay);
+    launch_clear_rows(ctx->s_main, mat->a, mat->lr_cap, r0, mat->cap - r0, r0, pad, lay);
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, ctx->s_main, mat->a,
-                       mat->cap, r0, r0 + pad);
+                       mat->lr_cap, r0, r0 + pad, lay);
     LPGP_HIP(hipGetLastError());
   }
   mat->blocks.push_back(b);
@@ -640,7 +698,7 @@ int lpgp_mat_clone(lpgp_ctx* ctx, const lpgp_mat* src, int32_t nblocks, lpgp_mat
   lpgp_mat* m = nullptr;
   int rc = lpgp_mat_create(ctx, pn, &m);
   if (rc != 0) return rc;
-  hipError_t e = hipMemcpy2DAsync(m->a, (size_t)m->cap * sizeof(double), src->a, (size_t)src->cap * sizeof(double),
+  hipError_t e = hipMemcpy2DAsync(m->a, (size_t)m->lr_cap * sizeof(double), src->a, (size_t)src->lr_cap * sizeof(double),
                                   (size_t)pn * sizeof(double), (size_t)pn, hipMemcpyDeviceToDevice, ctx->s_main);
   if (e == hipSuccess)
     e = hipMemcpyAsync(m->linv, src->linv, (size_t)pn * TILE * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main);
@@ -680,11 +738,9 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   // distributed factorisation: a rank assembles only the columns of the panels it will factor
   // (the others arrive as factored panels); columns that are already factored (cross blocks of
   // a block append) are needed by every rank
-  OwnFilter own;
-  own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
-  if (ctx->test_own_world > 1) { own.world = ctx->test_own_world; own.rank = ctx->test_own_rank; }
-  rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->cap,
-                       Bi.poff, Bj.poff, sym ? 1 : 0, own);
+  // multi-GPU: a rank evaluates exactly the tiles it owns (2-D block-cyclic), zero communication
+  rc = launch_assemble(ctx, ctx->s_main, desc, X0->x, X0->n, X0->n_pad, Xc->x, Xc->n, Xc->n_pad, mat->a, mat->lr_cap,
+                       Bi.poff, Bj.poff, sym ? 1 : 0, mat_layout(ctx));
   return rc;       // asynchronous: consumers are ordered behind it on the main stream
 }
 
@@ -716,11 +772,8 @@ int lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups
   const size_t wd = kron_work_doubles(D, n0d, n1d);
   void* work = nullptr;
   if (pool_alloc(ctx, &work, wd * sizeof(double), nullptr) != 0) return -1;
-  OwnFilter own;
-  own.world = ctx->world; own.rank = ctx->rank; own.from = mat->pn_fact; own.width = ctx->nb;
-  if (ctx->test_own_world > 1) { own.world = ctx->test_own_world; own.rank = ctx->test_own_rank; }
-  int rc = launch_assemble_kron(ctx, ctx->s_main, kd, ngroups, f0, n0d, f1, n1d, (double*)work, wd, mat->a, mat->cap,
-                                Bi.poff, Bj.poff, sym ? 1 : 0, own);
+  int rc = launch_assemble_kron(ctx, ctx->s_main, kd, ngroups, f0, n0d, f1, n1d, (double*)work, wd, mat->a, mat->lr_cap,
+                                Bi.poff, Bj.poff, sym ? 1 : 0, mat_layout(ctx));
   pool_free(ctx, work, wd * sizeof(double));       // reuse is ordered behind this launch on the main stream
   return rc;
 }
@@ -737,7 +790,7 @@ int lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_
     LPGP_HIP(hipMemcpyAsync(ctx->d_tmp, v_host, (size_t)B.n * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
     dv = ctx->d_tmp;
   }
-  int rc = launch_add_diag(ctx->s_main, mat->a, mat->cap, B.poff, B.n, dv, scalar);
+  int rc = launch_add_diag(ctx->s_main, mat->a, mat->lr_cap, B.poff, B.n, dv, scalar, mat_layout(ctx));
   if (rc != 0) return rc;
   if (v_host) LPGP_HIP(hipStreamSynchronize(ctx->s_main));     // borrowed host vector, shared scratch
   return 0;
@@ -751,7 +804,7 @@ int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B
   int rc = ensure_tmp(ctx, B.n * B.n);
   if (rc != 0) return rc;
   LPGP_HIP(hipMemcpyAsync(ctx->d_tmp, B_host, (size_t)(B.n * B.n) * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
-  rc = launch_add_dense(ctx->s_main, mat->a, mat->cap, B.poff, B.n, ctx->d_tmp);
+  rc = launch_add_dense(ctx->s_main, mat->a, mat->lr_cap, B.poff, B.n, ctx->d_tmp, mat_layout(ctx));
   if (rc != 0) return rc;
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   return 0;
@@ -766,7 +819,12 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
   const int64_t pn = mat->pn, n = mat->n;
   std::vector<double> tmp((size_t)pn * pn);
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
-  LPGP_HIP(hipMemcpy2D(tmp.data(), (size_t)pn * sizeof(double), mat->a, (size_t)mat->cap * sizeof(double),
+  if (ctx->distributed()) {
+    LPGP_CHECK(what == 1, "lpgp_mat_to_host: only the factor can be collected in a multi-GPU job");
+    int rc = factor_to_host_dist(ctx, mat, tmp.data());      // collective: the factor is streamed to every rank
+    if (rc != 0) return rc;
+  } else
+  LPGP_HIP(hipMemcpy2D(tmp.data(), (size_t)pn * sizeof(double), mat->a, (size_t)mat->lr_cap * sizeof(double),
                        (size_t)pn * sizeof(double), (size_t)pn, hipMemcpyDeviceToHost));
   // tmp is column-major pn x pn: element (r,c) at tmp[r + c*pn]
   for (const auto& bi : mat->blocks)
@@ -791,7 +849,7 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf: a strict prefix of the blocks is in view");
   int32_t h = 0;
   int rc = ctx->distributed()
-               ? potrf_blocked_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
+               ? potrf_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
                : potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
   if (rc != 0) return rc;
   if (info) *info = h;
@@ -813,9 +871,9 @@ int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
   int rc = 0;
   do {
     if (hipMemcpyAsync(dv, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    rc = trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, m_pad) : trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
     if (rc) break;
-    rc = trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    rc = ctx->distributed() ? trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, m_pad) : trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
     if (rc) break;
     if (hipMemcpyAsync(hp.data(), dv, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
     if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
@@ -839,7 +897,22 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
   std::vector<double> hp((size_t)pn);
   scatter_padded(mat, r_host, hp.data());
   LPGP_HIP(hipMemcpyAsync(mat->w, hp.data(), (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
-  rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);
+  if (ctx->distributed()) {
+    // multi-GPU: the factor is streamed; the vector rides as column 0 of a 128-column block on every rank (all
+    // ranks end with the same weights, no further communication)
+    void* pv = nullptr;
+    const size_t vb = (size_t)pn * TILE * sizeof(double);
+    if (pool_alloc(ctx, &pv, vb, nullptr) != 0) return -1;
+    double* dv = (double*)pv;
+    hipError_t e = hipMemsetAsync(dv, 0, vb, ctx->s_main);
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main);
+    rc = e == hipSuccess ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, TILE) : -1;
+    if (rc == 0) rc = trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, TILE);
+    if (rc == 0 && hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) rc = -1;
+    pool_free(ctx, pv, vb);
+  } else {
+    rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);
+  }
   if (rc != 0) return rc;
   LPGP_HIP(hipMemcpyAsync(hp.data(), mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
@@ -933,7 +1006,8 @@ int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
   int rc = rhs_clear_unassembled(ctx, mat, V);
   if (rc != 0) return rc;
-  rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
+  rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad)
+                          : trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
   if (rc != 0) return rc;
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   return 0;
@@ -972,7 +1046,8 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
     double* zcol = K->v + (int64_t)m * K->ld;
     if (via_z)
       LPGP_HIP(hipMemcpyAsync(zcol, mat->r(), (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
-    rc = trsm_lower_blocked(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad);
+    rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad)
+                            : trsm_lower_blocked(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad);
     if (rc != 0) return rc;
     if (via_z) {
       hipLaunchKernelGGL(col_reduce2_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
@@ -1163,12 +1238,6 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
   g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.mt = (int)(m / TILE); g.nt = (int)(n / TILE); g.k = (int)k; g.alpha = alpha; g.beta = beta;
   g.tri = lower_only;
-  if (const char* e = std::getenv("LPGP_TEST_OWN")) {          // "world,rank,base,width": ownership filter of the distributed update
-    int w = 1, r = 0, b = 0, wd = 4;
-    if (lower_only && std::sscanf(e, "%d,%d,%d,%d", &w, &r, &b, &wd) == 4 && w > 1) {
-      g.own_world = w; g.own_rank = r; g.own_base = b; g.own_w = wd;
-    }
-  }
   int rc = launch_gemm(ctx, ts, ta, tb, g, -1);
   if (rc == 0 && hipStreamSynchronize(ts) != hipSuccess) rc = -1;
   if (rc == 0) LPGP_HIP(hipMemcpy(C, dC, (size_t)ldc * n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1190,6 +1259,27 @@ int lpgp_test_gemm(lpgp_ctx* ctx, int32_t ta, int32_t tb, int32_t lower_only, in
   (void)hipFree(dB);
   (void)hipFree(dC);
   return rc;
+}
+
+int lpgp_test_stair_enumerate(int32_t pr, int32_t pc, int32_t my_r, int32_t my_c, int32_t nbt, int32_t T, int32_t row_lo,
+                              int32_t col_lo, int32_t* out, int64_t cap) {
+  LPGP_CHECK(pr >= 1 && pc >= 1 && my_r >= 0 && my_r < pr && my_c >= 0 && my_c < pc && nbt >= 1 && T >= 0 && out, "lpgp_test_stair_enumerate: bad argument");
+  GemmArgs g;
+  g.cyc = 1; g.tri = 1;
+  g.rowc.P = pr; g.rowc.me = my_r; g.rowc.nbt = nbt;
+  g.colc.P = pc; g.colc.me = my_c; g.colc.nbt = nbt;
+  g.rt0 = cyc_before(g.rowc, row_lo);
+  g.ct0 = cyc_before(g.colc, col_lo);
+  g.mt = cyc_before(g.rowc, T) - g.rt0;
+  g.nt = cyc_before(g.colc, T) - g.ct0;
+  g.g0 = col_lo < row_lo ? col_lo : row_lo;
+  if (g.mt <= 0 || g.nt <= 0) return 0;
+  const int n = stair_enumerate_host(g, out, cap);
+  for (int64_t i = 0; i < n && i < cap; ++i) {      // local -> global tile indices
+    out[2 * i] = cyc_l2g(g.rowc, g.rt0 + out[2 * i]);
+    out[2 * i + 1] = cyc_l2g(g.colc, g.ct0 + out[2 * i + 1]);
+  }
+  return n;
 }
 
 int lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info) {

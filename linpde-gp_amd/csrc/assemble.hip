@@ -36,8 +36,7 @@ struct AsmArgs {
   int64_t row_off, col_off;
   int32_t lower_only;           // symmetric diagonal block: skip tiles strictly above diagonal
   int32_t tiles_r, tiles_c;
-  int32_t own_world, own_rank;  // distributed factorisation: only tile columns of panels owned by this rank
-  int64_t own_from, own_width;
+  Layout2D lay;                 // where element (row_off + i, col_off + j) lives on this rank (multi-GPU: only the owned tiles are written)
 };
 
 template <int D>
@@ -47,10 +46,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
   const int tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
   if (a.lower_only && c0 > r0 + AT - 1) return;
-  if (a.own_world > 1) {
-    const int64_t gc = a.col_off + c0;
-    if (gc >= a.own_from && (int)(((gc - a.own_from) / a.own_width) % a.own_world) != a.own_rank) return;
-  }
+  // a 64 x 64 tile lies inside ONE 128-tile of the padded matrix (offsets are multiples of 128): one owner
+  const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
+  if (lrow0 < 0 || lcol0 < 0) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // stage column coordinates
   if (threadIdx.x < AT) {
@@ -76,21 +74,26 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
 #pragma unroll
       for (int e = 0; e < AE; ++e) {
         int64_t c = c0 + cb + e;
-        if (c < a.n1) a.out[(a.row_off + row) + (a.col_off + c) * a.ld] = res[e];
+        if (c < a.n1) a.out[(lrow0 + lane) + (lcol0 + cb + e) * a.ld] = res[e];
       }
     }
   }
 }
 
-__global__ void add_diag_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar) {
+__global__ void add_diag_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar, Layout2D lay) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) a[(off + i) * (ld + 1)] += (v ? v[i] : 0.0) + scalar;
+  if (i >= n) return;
+  const int64_t lr = cyc_local(lay.rows, off + i), lc = cyc_local(lay.cols, off + i);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] += (v ? v[i] : 0.0) + scalar;
 }
 
-__global__ void add_dense_lower_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* b /* n x n C-order */) {
+__global__ void add_dense_lower_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* b /* n x n C-order */,
+                                       Layout2D lay) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;   // row
   int64_t j = blockIdx.y;                                       // col
-  if (i < n && j <= i) a[(off + i) + (off + j) * ld] += b[i * n + j];
+  if (i >= n || j > i) return;
+  const int64_t lr = cyc_local(lay.rows, off + i), lc = cyc_local(lay.cols, off + j);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] += b[i * n + j];
 }
 
 // Copy a lowered descriptor into the next slot of the context's ring (pinned host -> device,
@@ -119,7 +122,7 @@ static int stage_desc(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_des
 int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
-                    const OwnFilter& own) {
+                    const Layout2D& lay) {
   lpgp_ctx::DescSlot* slotp = nullptr;
   int rc_ = stage_desc(ctx, stream, host_desc, &slotp);
   if (rc_ != 0) return rc_;
@@ -128,7 +131,7 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   AsmArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
-  a.own_world = own.world; a.own_rank = own.rank; a.own_from = own.from; a.own_width = own.width;
+  a.lay = lay;
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
@@ -292,8 +295,7 @@ struct KronArgs {
   double* out;
   int64_t ld, row_off, col_off;
   int32_t lower_only, tiles_r, tiles_c;
-  int32_t own_world, own_rank;
-  int64_t own_from, own_width;
+  Layout2D lay;
 };
 
 // NU: compile-time bound on the number of distinct fast-dimension matrices (2, 4, 8 or 16), so
@@ -303,10 +305,8 @@ __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
   const int tr = blockIdx.x % a.tiles_r, tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
   if (a.lower_only && c0 > r0 + AT - 1) return;
-  if (a.own_world > 1) {
-    const int64_t gc = a.col_off + c0;
-    if (gc >= a.own_from && (int)(((gc - a.own_from) / a.own_width) % a.own_world) != a.own_rank) return;
-  }
+  const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
+  if (lrow0 < 0 || lcol0 < 0) return;                 // (one owner per 64 x 64 tile, see assemble_kernel)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t row = r0 + lane;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void kron_expand_kernel(KronArgs a) {
   const double* ufast[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) ufast[u] = a.u[D - 1] + (int64_t)(u < nu ? u : nu - 1) * sfast + roff[D - 1];
-  double* const outp = a.out + (a.row_off + row) + a.col_off * a.ld;
+  double* const outp = a.out + (lrow0 + lane) + (lcol0 - c0) * a.ld;       // column c of the block at outp[c * ld]
   const bool row_ok = row < a.n0;
   double q[NU];                  // weight of each fast-dimension matrix for the current slow column index
   bool fresh = true;
@@ -442,15 +442,16 @@ __global__ __launch_bounds__(256) void kron2_kernel(KronArgs a, int ftr, int ftc
     const int64_t rtile = (int64_t)is * n0f + tr * 64;            // first global row / column of the
     const int64_t ctile = (int64_t)js * n1f + tcf * 32;           // 64 x 32 tile of this pair
     const bool skip = a.lower_only && ctile > rtile + 63;
-    // distributed factorisation: columns of panels owned by other ranks are not written (a tile of
-    // this kernel is not aligned to the panel width, so the owner is decided per column)
-    unsigned mine = 0xffu;
-    if (!skip && a.own_world > 1) {
-      mine = 0;
+    // multi-GPU: a tile of this kernel is not aligned to the 128-tiles of the padded matrix, so ownership is
+    // decided per row (lane) and per column
+    const int64_t lrow = skip ? -1 : cyc_local(a.lay.rows, a.row_off + (int64_t)is * n0f + ifast);
+    unsigned mine = 0;
+    int64_t lcol[8];
+    if (!skip) {
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
-        const int64_t gc = a.col_off + (int64_t)js * n1f + jf0 + x;
-        if (gc < a.own_from || (int)(((gc - a.own_from) / a.own_width) % a.own_world) == a.own_rank) mine |= 1u << x;
+        lcol[x] = cyc_local(a.lay.cols, a.col_off + (int64_t)js * n1f + jf0 + x);
+        if (lcol[x] >= 0) mine |= 1u << x;
       }
     }
     if (!skip && mine != 0) {
@@ -463,13 +464,12 @@ __global__ __launch_bounds__(256) void kron2_kernel(KronArgs a, int ftr, int ftc
 #pragma unroll
         for (int u = 0; u < NU; ++u) q[u] += (uu == u) ? pv : 0.0;
       }
-      double* outp = a.out + (a.row_off + (int64_t)is * n0f + ifast) + (a.col_off + (int64_t)js * n1f + jf0) * a.ld;
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) acc = fma(q[u], vals[u][x], acc);
-        if (row_ok && jf0 + x < n1f && ((mine >> x) & 1u)) outp[(int64_t)x * a.ld] = acc;
+        if (row_ok && lrow >= 0 && jf0 + x < n1f && ((mine >> x) & 1u)) a.out[lrow + lcol[x] * a.ld] = acc;
       }
     }
     if (++is == n0s) {
@@ -493,7 +493,7 @@ static void launch_kron_nu(dim3 grid, hipStream_t stream, const KronArgs& a) {
 int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
                          const double* const* F0, const int64_t* n0d, const double* const* F1, const int64_t* n1d,
                          double* work, size_t work_doubles, double* out, int64_t ld, int64_t row_off,
-                         int64_t col_off, int lower_only, const OwnFilter& own) {
+                         int64_t col_off, int lower_only, const Layout2D& lay) {
   const int D = kd[0].d;
   KronArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -537,7 +537,7 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
     }
   }
   // evaluate the 1-D matrices with the ordinary assembly kernel (D = 1, scale 1, one term)
-  OwnFilter none;
+  const Layout2D none;
   for (int d = 0; d < D; ++d) {
     a.nuniq[d] = (int32_t)keys[d].size();
     a.u[d] = work + dim_off[d];
@@ -563,7 +563,7 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
     }
   }
   a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
-  a.own_world = own.world; a.own_rank = own.rank; a.own_from = own.from; a.own_width = own.width;
+  a.lay = lay;
   a.tiles_r = (int)((a.n0 + AT - 1) / AT);
   a.tiles_c = (int)((a.n1 + AT - 1) / AT);
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
@@ -595,16 +595,17 @@ size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d) {
   return w;
 }
 
-int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar) {
+int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar,
+                    const Layout2D& lay) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ld, off, n, v, scalar);
+  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ld, off, n, v, scalar, lay);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b) {
+int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b, const Layout2D& lay) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(add_dense_lower_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, a, ld, off, n, b);
+  hipLaunchKernelGGL(add_dense_lower_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, a, ld, off, n, b, lay);
   LPGP_HIP(hipGetLastError());
   return 0;
 }

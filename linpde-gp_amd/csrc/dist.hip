@@ -1,0 +1,483 @@
+// Multi-GPU factorisation and solves: one process per GPU, Pr x Pc process grid, 2-D block-cyclic tiles
+// (BASELINE.json north_star "Gram matrix in 2D block-cyclic tiles ... RCCL ... of panel columns
+// over xGMI").
+//
+// STORAGE (sharded, nothing but the diagonal blocks replicated).  Rank (r, c) = r * Pc + c keeps tile (i, j) of the
+// padded matrix iff (i / nbt) % Pr == r and (j / nbt) % Pc == c (blocks of nbt = nb / 128 tiles, nb = 512), as a
+// dense column-major array of its tiles in increasing global order (lpgp_mat::a, leading dimension lr_cap).
+// Assembly writes only owned tiles (Layout2D in the assembly kernels): zero communication, 1 / P of the work.
+// Replicated on every rank: the nb x nb diagonal blocks of the factor (lpgp_mat::dblk) and all tile inverses
+// (lpgp_mat::linv) -- N * nb * 8 bytes (c4: 0.27 + 0.07 GB of a 35 GB factor): they are what every triangular
+// solve of a panel needs, and keeping them removes a latency-critical message from every step of every solve.
+//
+// ONE COMMUNICATION PRIMITIVE: gather_panel -- the rows below a factored panel (kw <= nb columns), which live
+// on the Pr ranks of process column K % Pc, are made available to every rank as one dense panel in global row
+// order.  Each source packs its rows (one strided copy) and pushes the SAME buffer to every other rank with
+// point-to-point sends posted in one RCCL group (ncclSend / ncclRecv): direct peer-to-peer copies over the xGMI
+// links of the full mesh, all links of a source busy at once, no ring.  Per panel a link carries S / Pr bytes
+// (S = panel bytes), with Pc = 1 that is S / P -- the reason the default grid is P x 1 (see choose_grid).  A
+// receiver unpacks the Pr pieces into the dense panel (one strided copy per piece).
+//
+// FACTORISATION, per panel K (right-looking): the owner of the diagonal block factors it (tile Cholesky chain on
+// kw <= 4 tiles) and broadcasts block + tile inverses to everyone; the Pr ranks of the panel's process column
+// solve their rows against it (refined tile solves, gemm.hip) -- the panel triangular solve runs Pr-fold
+// parallel; gather_panel; every rank updates ITS tiles of the trailing matrix straight from the gathered panel:
+// local tile (tr, tc) stands for global tiles (gr, gc) and reads panel rows gr and gc (cyclic tile maps in
+// gemm_f64_kernel), valid iff gr >= gc -- a staircase, enumerated densely and XCD-balanced like the triangle
+// (map_tile_stair).  A block append (t_done > 0) first runs the same step for every OLD panel with the solve and
+// the update restricted to the new rows (the old panel is gathered from its owners' storage).
+// Look-ahead: the update of the next panel's own columns and that panel's factorisation, solve and gather run
+// on the panel stream while the update stream still applies the current panel to the rest.
+//
+// SOLVES stream the factor: right-hand sides are sharded by COLUMN over all P ranks (prediction points,
+// `ConditionalGaussianProcess.predict`), every rank holds all rows of its columns, and panel after panel is
+// gathered from its owners and applied locally -- forward (trsm_lower_dist) or in reverse order for L^T
+// (trsm_lower_t_dist).  No right-hand-side data ever travels; the factor is streamed once per solve at S / Pr
+// per link and never stored replicated.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "lpgp_internal.h"
+
+namespace lpgp {
+
+#define LPGP_NCCL(expr)                                                                    \
+  do {                                                                                     \
+    ncclResult_t _r = (expr);                                                              \
+    if (_r != ncclSuccess) {                                                               \
+      ::lpgp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+      return -3;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int mt, int nt,
+                          int k, double alpha, double beta, int tri) {
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.mt = mt; g.nt = nt; g.k = k; g.alpha = alpha; g.beta = beta;
+  g.tri = tri;
+  return g;
+}
+
+// ---- broadcast of a set of device buffers, each from its own root to every rank ---------------------------------
+struct Piece {
+  int root;
+  double* buf;           // source on the root, destination everywhere else
+  size_t count;          // doubles
+};
+
+static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>& pieces) {
+  if (ctx->world <= 1) return 0;
+  double sent = 0.0, recv = 0.0;
+  for (const auto& p : pieces) {
+    if (p.count == 0) continue;
+    if (p.root == ctx->rank) sent += 8.0 * (double)p.count * (ctx->world - 1);
+    else recv += 8.0 * (double)p.count;
+  }
+  ctx->comm_bytes_sent += sent;
+  ctx->comm_bytes_recv += recv;
+  prof_begin(ctx, st, LPGP_K_COMM, 0.0, sent + recv);
+  if (ctx->host_xfer) {
+    // bring-up / test transport: every piece staged through the host and broadcast by the caller's exchange
+    std::vector<double> stage;
+    for (const auto& p : pieces) {
+      if (p.count == 0) continue;
+      if (stage.size() < p.count) stage.resize(p.count);
+      if (p.root == ctx->rank) LPGP_HIP(hipMemcpyAsync(stage.data(), p.buf, p.count * sizeof(double), hipMemcpyDeviceToHost, st));
+      LPGP_HIP(hipStreamSynchronize(st));
+      LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 0, stage.data(), (int64_t)(p.count * sizeof(double)), p.root) == 0,
+                 "host exchange: broadcast from rank %d failed", p.root);
+      if (p.root != ctx->rank) {
+        LPGP_HIP(hipMemcpyAsync(p.buf, stage.data(), p.count * sizeof(double), hipMemcpyHostToDevice, st));
+        LPGP_HIP(hipStreamSynchronize(st));
+      }
+    }
+  } else {
+    ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+    LPGP_NCCL(ncclGroupStart());
+    for (const auto& p : pieces) {
+      if (p.count == 0) continue;
+      if (p.root == ctx->rank) {
+        for (int peer = 0; peer < ctx->world; ++peer)
+          if (peer != ctx->rank) LPGP_NCCL(ncclSend(p.buf, p.count, ncclDouble, peer, comm, st));
+      } else {
+        LPGP_NCCL(ncclRecv(p.buf, p.count, ncclDouble, p.root, comm, st));
+      }
+    }
+    LPGP_NCCL(ncclGroupEnd());
+  }
+  prof_end(ctx, st);
+  return 0;
+}
+
+static int allreduce_max_int(lpgp_ctx* ctx, hipStream_t st, int* h_value) {
+  if (ctx->world <= 1) return 0;
+  if (ctx->host_xfer) {
+    LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, h_value, (int64_t)sizeof(int), 0) == 0, "host exchange: all-reduce failed");
+    return 0;
+  }
+  int* d = ctx->d_info;
+  LPGP_HIP(hipMemcpyAsync(d, h_value, sizeof(int), hipMemcpyHostToDevice, st));
+  LPGP_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMax, (ncclComm_t)ctx->nccl_comm, st));
+  LPGP_HIP(hipMemcpyAsync(h_value, d, sizeof(int), hipMemcpyDeviceToHost, st));
+  LPGP_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---- panel gather -------------------------------------------------------------------------------------------------
+// rows of `src` (ntiles tiles of 128 rows, the source member's tiles l0, l0 + 1, ... in ITS local order) -> rows of
+// the dense panel in global order: local tile l0 + i of member `c.me` is global tile cyc_l2g(c, l0 + i)
+__global__ __launch_bounds__(256) void unpack_piece_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
+                                                            int64_t lds, Cyc c, int l0, int g_lo, int64_t rows) {
+  const int64_t col = blockIdx.y;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (r >= rows) return;
+  const int i = (int)(r / TILE);
+  const int64_t gr = (int64_t)(cyc_l2g(c, l0 + i) - g_lo) * TILE + (r - (int64_t)i * TILE);
+  *reinterpret_cast<double2*>(dst + col * ldd + gr) = *reinterpret_cast<const double2*>(src + col * lds + r);
+}
+
+static int ensure_buf(double** p, size_t* cap, size_t doubles) {
+  if (doubles <= *cap) return 0;
+  if (*p) LPGP_HIP(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  LPGP_HIP(hipMalloc(p, doubles * sizeof(double)));
+  *cap = doubles;
+  return 0;
+}
+
+struct Grid {
+  Cyc R, C;              // this rank's row / column membership
+  int Pr, Pc, my_r, my_c, nbt;
+  Cyc Rof(int r) const { Cyc c = R; c.me = r; return c; }
+};
+static Grid grid_of(const lpgp_ctx* ctx) {
+  Grid g;
+  const Layout2D l = ctx->layout();
+  g.R = l.rows; g.C = l.cols;
+  g.Pr = ctx->pr; g.Pc = ctx->pc; g.my_r = l.rows.me; g.my_c = l.cols.me; g.nbt = l.rows.nbt;
+  return g;
+}
+
+// Make rows [g_lo, T) (global tiles) of tile columns [c0, c1) of the (partly) factored matrix available on every rank
+// as a dense column-major panel `out` (leading dimension (T - g_lo) * 128), global row order.  The columns live on
+// process column pcK = (c0 / nbt) % Pc.  Collective; everything is enqueued on `st`.
+static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out) {
+  const int rows_t = T - g_lo;
+  if (rows_t <= 0) return 0;
+  const int64_t ldo = (int64_t)rows_t * TILE, cols = (int64_t)(c1 - c0) * TILE;
+  const int pcK = (c0 / G.nbt) % G.Pc;
+  const int64_t ld = mat->lr_cap;
+  // piece of row member r: its local tiles [l0_r, l1_r)
+  std::vector<int> l0(G.Pr), nt(G.Pr);
+  size_t total = 0;
+  for (int r = 0; r < G.Pr; ++r) {
+    const Cyc cr = G.Rof(r);
+    l0[r] = cyc_before(cr, g_lo);
+    nt[r] = cyc_before(cr, T) - l0[r];
+    total += (size_t)nt[r] * TILE * cols;
+  }
+  LPGP_TRY(ensure_buf(&ctx->d_pack, &ctx->pack_cap, total));
+  std::vector<Piece> pieces;
+  std::vector<double*> pbuf(G.Pr);
+  size_t off = 0;
+  for (int r = 0; r < G.Pr; ++r) {
+    pbuf[r] = ctx->d_pack + off;
+    off += (size_t)nt[r] * TILE * cols;
+    if (nt[r] == 0) continue;
+    const int root = r * G.Pc + pcK;
+    if (root == ctx->rank) {
+      // own rows: straight from the local matrix into the dense panel below; packed for the peers
+      const double* src = mat->a + (int64_t)l0[r] * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+      if (ctx->world > 1) LPGP_TRY(copy2d(st, pbuf[r], (int64_t)nt[r] * TILE, src, ld, (int64_t)nt[r] * TILE, cols));
+    }
+    pieces.push_back({root, pbuf[r], (size_t)nt[r] * TILE * cols});
+  }
+  LPGP_TRY(bcast_pieces(ctx, st, pieces));
+  for (int r = 0; r < G.Pr; ++r) {
+    if (nt[r] == 0) continue;
+    const int root = r * G.Pc + pcK;
+    const double* src = pbuf[r];
+    int64_t lds = (int64_t)nt[r] * TILE;
+    if (root == ctx->rank && ctx->world <= 1) {
+      src = mat->a + (int64_t)l0[r] * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+      lds = ld;
+    }
+    const int64_t rows = (int64_t)nt[r] * TILE;
+    hipLaunchKernelGGL(unpack_piece_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, out, ldo, src,
+                       lds, G.Rof(r), l0[r], g_lo, rows);
+  }
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// tile (it, jt) of diagonal block K as replicated in mat->dblk (leading dimension nb)
+static inline double* dblk_tile(const lpgp_mat* mat, const Grid& G, int K, int it, int jt) {
+  const int64_t nb = (int64_t)G.nbt * TILE;
+  return mat->dblk + (int64_t)K * nb * nb + (int64_t)it * TILE + (int64_t)jt * TILE * nb;
+}
+
+// Rows [rl0, rl1) (LOCAL tiles of this rank, which is a member of the panel's process column) of tile columns
+// [c0, c1) <- X L_KK^{-T}: kw tile steps {refined tile solve; rank-128 update of the panel columns to the right}
+static int panel_rows_solve(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int c0, int c1, int rl0, int rl1) {
+  const int mt = rl1 - rl0;
+  if (mt <= 0) return 0;
+  const int64_t ld = mat->lr_cap, nb = (int64_t)G.nbt * TILE;
+  const int K = c0 / G.nbt, b0 = c0 - K * G.nbt;
+  double* X = mat->a + (int64_t)rl0 * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+  for (int j = 0; j < c1 - c0; ++j) {
+    double* Xj = X + (int64_t)j * TILE * ld;
+    LPGP_TRY(launch_trsm_tile(ctx, st, Xj, ld, mat->linv + (int64_t)(c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mt,
+                              LPGP_K_TRSM));
+    if (j + 1 < c1 - c0)
+      LPGP_TRY(launch_gemm(ctx, st, 0, 0,
+                           mk(Xj, ld, dblk_tile(mat, G, K, b0 + j + 1, b0 + j), nb, Xj + (int64_t)TILE * ld, ld, mt, c1 - c0 - j - 1, TILE,
+                              -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+  }
+  return 0;
+}
+
+// The update of this rank's tiles by a gathered panel: local tile rows [rt0, LTr) x local tile columns [ct0, ct1),
+// valid where global row tile >= global column tile; `panel` holds global tile rows g0 ... (leading dimension ldp)
+static int update_local(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, const double* panel, int64_t ldp, int g0, int K128,
+                        int rt0, int rt1, int ct0, int ct1, int prof) {
+  if (rt1 <= rt0 || ct1 <= ct0) return 0;
+  const int64_t ld = mat->lr_cap;
+  GemmArgs g = mk(panel, ldp, panel, ldp, mat->a + (int64_t)rt0 * TILE + (int64_t)ct0 * TILE * ld, ld, rt1 - rt0, ct1 - ct0, K128, -1.0, 1.0,
+                  1);
+  g.cyc = 1;
+  g.rowc = G.R; g.colc = G.C;
+  g.rt0 = rt0; g.ct0 = ct0; g.g0 = g0;
+  return launch_gemm(ctx, st, 0, 0, g, prof);
+}
+
+// Factor the diagonal block of panel [c0, c1) (owner only, in its local storage), copy it into the replicated
+// dblk / keep its tile inverses in linv; then broadcast both to every rank.
+static int factor_diag_block(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1) {
+  const int K = c0 / G.nbt, b0 = c0 - K * G.nbt, kw = c1 - c0;
+  const int64_t ld = mat->lr_cap, nb = (int64_t)G.nbt * TILE;
+  const int owner = ((K % G.Pr) * G.Pc) + (K % G.Pc);
+  if (owner == ctx->rank) {
+    double* D = mat->a + (int64_t)cyc_before(G.R, c0) * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+    for (int j = 0; j < kw; ++j) {
+      double* dj = D + (int64_t)j * TILE * (ld + 1);
+      double* linv = mat->linv + (int64_t)(c0 + j) * TILE * TILE;
+      LPGP_TRY(launch_potrf_tile(ctx, st, dj, ld, linv, ctx->d_info, (c0 + j) * TILE));
+      if (j + 1 < kw) {
+        double* X = dj + TILE;
+        LPGP_TRY(launch_trsm_tile(ctx, st, X, ld, linv, dj, ld, kw - j - 1, LPGP_K_TRSM));
+        LPGP_TRY(launch_gemm(ctx, st, 0, 0, mk(X, ld, X, ld, dj + (int64_t)TILE * (ld + 1), ld, kw - j - 1, kw - j - 1, TILE, -1.0, 1.0, 2),
+                             LPGP_K_SYRK_PANEL));
+      }
+    }
+    LPGP_TRY(copy2d(st, dblk_tile(mat, G, K, b0, b0), nb, D, ld, (int64_t)kw * TILE, (int64_t)kw * TILE));
+    // a panel that starts inside its block (block append at a boundary that is not a multiple of nb): the block's
+    // rows of this panel x the block's OLD columns were solved by the append phase (they are rows below an old
+    // panel) and belong to the replicated diagonal block as well
+    if (b0 > 0)
+      LPGP_TRY(copy2d(st, dblk_tile(mat, G, K, b0, 0), nb, D - (int64_t)b0 * TILE * ld, ld, (int64_t)kw * TILE, (int64_t)b0 * TILE));
+  }
+  if (ctx->world > 1) {
+    // the whole block K (an earlier, partial panel of the same block is identical everywhere) and the tile
+    // inverses of the block's tile columns that exist
+    const int t0 = K * G.nbt, t1 = std::min(T, (K + 1) * G.nbt);
+    std::vector<Piece> pieces;
+    pieces.push_back({owner, mat->dblk + (int64_t)K * nb * nb, (size_t)(nb * nb)});
+    pieces.push_back({owner, mat->linv + (int64_t)t0 * TILE * TILE, (size_t)(t1 - t0) * TILE * TILE});
+    LPGP_TRY(bcast_pieces(ctx, st, pieces));
+  }
+  (void)T;
+  return 0;
+}
+
+static int ensure_panel(lpgp_ctx* ctx, int which, size_t doubles) { return ensure_buf(&ctx->d_panel[which], &ctx->panel_cap[which], doubles); }
+
+// Factor tile columns [t_done, T) of the distributed matrix; columns [0, t_done) already hold L.
+int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
+  const int T = (int)T64, t_done = (int)t_done64;
+  const Grid G = grid_of(ctx);
+  hipStream_t sP = ctx->s_main, sU = ctx->s_upd_all;
+  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
+  const int LTr = cyc_before(G.R, T), LTc = cyc_before(G.C, T);
+  const bool la = ctx->lookahead != 0;
+
+  // panels in order: every old panel (block append: solve + update of the new rows only), then the new ones
+  struct Panel { int c0, c1; bool fresh; };
+  std::vector<Panel> panels;
+  if (t_done > 0 && T > t_done)
+    for (int c0 = 0; c0 < t_done;) {
+      const int c1 = std::min(t_done, (c0 / G.nbt + 1) * G.nbt);
+      panels.push_back({c0, c1, false});
+      c0 = c1;
+    }
+  for (int c0 = t_done; c0 < T;) {
+    const int c1 = std::min(T, (c0 / G.nbt + 1) * G.nbt);
+    panels.push_back({c0, c1, true});
+    c0 = c1;
+  }
+  // rows a panel step touches: everything below the panel for a fresh panel, the new rows only for an old one
+  auto row_lo = [&](const Panel& p) { return p.fresh ? p.c1 : t_done; };
+
+  // Panel step, part 1 (panel stream): diagonal block, rows below, gather into panel buffer `which`
+  auto panel_part = [&](const Panel& p, int which) -> int {
+    const int pcK = (p.c0 / G.nbt) % G.Pc;
+    if (p.fresh) LPGP_TRY(factor_diag_block(ctx, sP, mat, G, T, p.c0, p.c1));
+    if (p.c1 >= T) return 0;
+    if (G.my_c == pcK) LPGP_TRY(panel_rows_solve(ctx, sP, mat, G, p.c0, p.c1, cyc_before(G.R, row_lo(p)), LTr));
+    LPGP_TRY(ensure_panel(ctx, which, (size_t)(T - p.c1) * TILE * (size_t)(p.c1 - p.c0) * TILE));
+    return gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, ctx->d_panel[which]);
+  };
+
+  bool have_upd = false;
+  for (size_t i = 0; i < panels.size(); ++i) {
+    const Panel& p = panels[i];
+    const int which = (int)(i & 1);
+    if (i == 0) {
+      // the panel buffer about to be written was last read by the update two panels ago -- none yet
+      LPGP_TRY(panel_part(p, which));
+    }
+    if (p.c1 >= T) break;
+    const double* panel = ctx->d_panel[which];
+    const int64_t ldp = (int64_t)(T - p.c1) * TILE;
+    const int K128 = (p.c1 - p.c0) * TILE;
+    const int rt0 = cyc_before(G.R, row_lo(p));
+    const int ct0 = cyc_before(G.C, p.c1);
+    if (!la || i + 1 >= panels.size()) {
+      LPGP_TRY(update_local(ctx, sP, mat, G, panel, ldp, p.c1, K128, rt0, LTr, ct0, LTc, LPGP_K_SYRK));
+      if (i + 1 < panels.size()) LPGP_TRY(panel_part(panels[i + 1], which ^ 1));
+      continue;
+    }
+    // look-ahead: (a) the next panel's own columns first, on the panel stream, followed at once by that panel's
+    // factorisation / solve / gather; (b) everything to the right of it meanwhile on the update stream
+    const Panel& q = panels[i + 1];
+    const int cta = cyc_before(G.C, q.c0), ctb = cyc_before(G.C, q.c1);      // local columns of the next panel (empty off its process column)
+    hipEvent_t evp = ctx->ev_panel[i & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));                                       // panel p is gathered
+    if (have_upd) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(i + 1) & 1], 0));   // (a)'s columns were last written by the previous (b)
+    LPGP_TRY(update_local(ctx, sP, mat, G, panel, ldp, p.c1, K128, rt0, LTr, cta, ctb, LPGP_K_SYRK_AHEAD));
+    LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+    LPGP_TRY(update_local(ctx, sU, mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, LPGP_K_SYRK));
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sU));
+    have_upd = true;
+    // the next gather writes panel buffer which ^ 1, last read by (b) of panel i - 1: that update has been waited
+    // for above (ev_upd[(i + 1) & 1]) before anything of this step was enqueued on the panel stream
+    LPGP_TRY(panel_part(q, which ^ 1));
+  }
+  if (have_upd) {
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
+  }
+  int h_info = 0;
+  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
+  LPGP_HIP(hipStreamSynchronize(sP));
+  LPGP_TRY(allreduce_max_int(ctx, sP, &h_info));        // a failed pivot is seen by the owner of its diagonal block only
+  if (info) *info = h_info;
+  return 0;
+}
+
+// ---- solves: the factor is streamed, panel by panel, against this rank's columns of the right-hand side ---------
+// V (all T * 128 rows x m_pad columns of THIS rank, column-major, leading dimension ldv) <- L^{-1} V
+int trsm_lower_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
+  const int T = (int)T64;
+  const Grid G = grid_of(ctx);
+  const int mtl = (int)(m_pad / TILE);
+  const int64_t nb = (int64_t)G.nbt * TILE;
+  hipStream_t st = ctx->s_main;
+  for (int c0 = 0; c0 < T;) {
+    const int c1 = std::min(T, (c0 / G.nbt + 1) * G.nbt);
+    const int K = c0 / G.nbt, b0 = c0 - K * G.nbt;
+    // the rows below first: the gather does not depend on this panel's tile steps and travels underneath them
+    if (c1 < T) {
+      LPGP_TRY(ensure_panel(ctx, 0, (size_t)(T - c1) * TILE * (size_t)(c1 - c0) * TILE));
+      LPGP_TRY(gather_panel(ctx, st, mat, G, T, c0, c1, c1, ctx->d_panel[0]));
+    }
+    for (int j = 0; j < c1 - c0; ++j) {
+      double* Vj = v + (int64_t)(c0 + j) * TILE;
+      LPGP_TRY(launch_trsv_tile(ctx, st, Vj, ldv, mat->linv + (int64_t)(c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mtl,
+                                LPGP_K_TRSM));
+      if (j + 1 < c1 - c0)
+        LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+                             mk(dblk_tile(mat, G, K, b0 + j + 1, b0 + j), nb, Vj, ldv, Vj + TILE, ldv, c1 - c0 - j - 1, mtl, TILE, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+    }
+    if (c1 < T)
+      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
+                           mk(ctx->d_panel[0], (int64_t)(T - c1) * TILE, v + (int64_t)c0 * TILE, ldv, v + (int64_t)c1 * TILE, ldv, T - c1, mtl,
+                              (c1 - c0) * TILE, -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+    c0 = c1;
+  }
+  return 0;
+}
+
+// V <- L^{-T} V, same layout: panels in reverse order; x_K = L_KK^{-T} (y_K - L[below, K]^T x_below)
+int trsm_lower_t_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {
+  const int T = (int)T64;
+  const Grid G = grid_of(ctx);
+  const int mtl = (int)(m_pad / TILE);
+  const int64_t nb = (int64_t)G.nbt * TILE, tb = TILE;
+  hipStream_t st = ctx->s_main;
+  void* sp = nullptr;
+  const size_t sbytes = (size_t)TILE * (size_t)m_pad * sizeof(double);
+  if (pool_alloc(ctx, &sp, sbytes, nullptr) != 0) return -1;
+  double* S = (double*)sp;
+  struct Release { lpgp_ctx* c; void* p; size_t b; ~Release() { pool_free(c, p, b); } } release{ctx, sp, sbytes};
+  std::vector<int> starts;
+  for (int c0 = 0; c0 < T; c0 = std::min(T, (c0 / G.nbt + 1) * G.nbt)) starts.push_back(c0);
+  for (int pi = (int)starts.size() - 1; pi >= 0; --pi) {
+    const int c0 = starts[pi], c1 = std::min(T, (c0 / G.nbt + 1) * G.nbt);
+    const int K = c0 / G.nbt, b0 = c0 - K * G.nbt;
+    if (c1 < T) {
+      LPGP_TRY(ensure_panel(ctx, 0, (size_t)(T - c1) * TILE * (size_t)(c1 - c0) * TILE));
+      LPGP_TRY(gather_panel(ctx, st, mat, G, T, c0, c1, c1, ctx->d_panel[0]));
+      // y_K -= L[below, K]^T x_below   (contraction over the rows below)
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1,
+                           mk(ctx->d_panel[0], (int64_t)(T - c1) * TILE, v + (int64_t)c1 * TILE, ldv, v + (int64_t)c0 * TILE, ldv, c1 - c0, mtl,
+                              (T - c1) * TILE, -1.0, 1.0, 0),
+                           LPGP_K_GEMM));
+    }
+    for (int j = c1 - c0 - 1; j >= 0; --j) {
+      double* Vj = v + (int64_t)(c0 + j) * TILE;
+      const double* linv = mat->linv + (int64_t)(c0 + j) * TILE * TILE;
+      const double* Ljj = dblk_tile(mat, G, K, b0 + j, b0 + j);
+      // refined tile step (see trsm_lower_t_blocked): S = Linv^T y;  y <- y - L^T S;  S <- S + Linv^T y;  y <- S
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(linv, tb, Vj, ldv, S, tb, 1, mtl, TILE, 1.0, 0.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(Ljj, nb, S, tb, Vj, ldv, 1, mtl, TILE, -1.0, 1.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(launch_gemm(ctx, st, 1, 1, mk(linv, tb, Vj, ldv, S, tb, 1, mtl, TILE, 1.0, 1.0, 0), LPGP_K_TRSM));
+      LPGP_TRY(copy2d(st, Vj, ldv, S, tb, tb, m_pad));
+      if (j > 0)      // rows of the block above: y_i -= L[j, i]^T x_j  for the tiles i < j of the block
+        LPGP_TRY(launch_gemm(ctx, st, 1, 1,
+                             mk(dblk_tile(mat, G, K, b0 + j, b0), nb, Vj, ldv, v + (int64_t)c0 * TILE, ldv, j, mtl, TILE, -1.0, 1.0, 0),
+                             LPGP_K_GEMM));
+    }
+  }
+  return 0;
+}
+
+// the whole factor, padded, column-major pn x pn on the host of EVERY rank (tests, `gram.cholesky()`)
+int factor_to_host_dist(lpgp_ctx* ctx, lpgp_mat* mat, double* out) {
+  const int T = (int)(mat->pn / TILE);
+  const int64_t pn = mat->pn;
+  const Grid G = grid_of(ctx);
+  hipStream_t st = ctx->s_main;
+  std::fill(out, out + (size_t)pn * pn, 0.0);
+  for (int c0 = 0; c0 < T;) {
+    const int c1 = std::min(T, (c0 / G.nbt + 1) * G.nbt);
+    // rows from the panel's own first tile on (the diagonal block included: gathered like any other rows)
+    LPGP_TRY(ensure_panel(ctx, 0, (size_t)(T - c0) * TILE * (size_t)(c1 - c0) * TILE));
+    LPGP_TRY(gather_panel(ctx, st, mat, G, T, c0, c1, c0, ctx->d_panel[0]));
+    LPGP_HIP(hipStreamSynchronize(st));
+    const int64_t rows = (int64_t)(T - c0) * TILE;
+    LPGP_HIP(hipMemcpy2D(out + (int64_t)c0 * TILE * (pn + 1), (size_t)pn * sizeof(double), ctx->d_panel[0], (size_t)rows * sizeof(double),
+                         (size_t)rows * sizeof(double), (size_t)(c1 - c0) * TILE, hipMemcpyDeviceToHost));
+    c0 = c1;
+  }
+  return 0;
+}
+
+}  // namespace lpgp

@@ -174,24 +174,41 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 // on SYRK n x n x 512: n = 16384 51.2 -> 51.9, 12288 48.1 -> 49.9, 6144 49.2 -> 51.0 TFLOP/s,
 // rectangular shapes unchanged; scratch/dense_ab.py.)
 constexpr int BAND = 8;
-// ownership filter of the distributed factorisation (see GemmArgs): number of owned columns among
-// the local tile columns [0, n), and the o-th owned column
-__host__ __device__ __forceinline__ int own_first(const GemmArgs& g) {       // first owned local column
-  return ((g.own_rank - g.own_base) % g.own_world + g.own_world) % g.own_world * g.own_w;
+// Distributed trailing update (GemmArgs::cyc): number of valid local tile columns of local tile row r -- the
+// columns whose global tile index does not exceed the row's (non-decreasing in r: a staircase).
+__host__ __device__ __forceinline__ int stair_nc(const GemmArgs& g, int r) {
+  const int gr = cyc_l2g(g.rowc, g.rt0 + r);
+  const int n = cyc_before(g.colc, gr + 1) - g.ct0;
+  return n < 0 ? 0 : (n > g.nt ? g.nt : n);
 }
-__host__ __device__ __forceinline__ int own_count(const GemmArgs& g, int n) {
-  const int f = own_first(g);
-  if (n <= f) return 0;
-  const int span = g.own_world * g.own_w, m = n - f;
-  const int full = m / span, rem = m - full * span;
-  return full * g.own_w + (rem < g.own_w ? rem : g.own_w);
+// tiles of band b (tile rows r0 .. r0 + R - 1): column-major over the valid (row, column) pairs
+__host__ __device__ __forceinline__ int stair_band_count(const GemmArgs& g, int r0, int R) {
+  int acc = 0;
+  for (int i = 0; i < R; ++i) acc += stair_nc(g, r0 + i);
+  return acc;
 }
-__host__ __device__ __forceinline__ int own_col(const GemmArgs& g, int o) {
-  return own_first(g) + (o / g.own_w) * g.own_world * g.own_w + o % g.own_w;
+// j-th tile of the band of tile rows r0 .. r0 + R - 1: columns below nc(r0) hold all R rows of the band, a column c
+// beyond holds the rows with nc(r) > c (a suffix of the band: nc is non-decreasing)
+__host__ __device__ __forceinline__ void stair_decode(const GemmArgs& g, int r0, int R, int j, int& r, int& c) {
+  const int cmin = stair_nc(g, r0);
+  if (j < cmin * R) {
+    c = j / R;
+    r = r0 + (j - c * R);
+    return;
+  }
+  int jj = j - cmin * R;
+  for (c = cmin;; ++c) {
+    int rf = r0;                                           // first row of the band that reaches column c
+    while (stair_nc(g, rf) <= c) ++rf;
+    const int cnt = r0 + R - rf;
+    if (jj < cnt) {
+      r = rf + jj;
+      return;
+    }
+    jj -= cnt;
+  }
 }
-__host__ __device__ __forceinline__ bool own_is(const GemmArgs& g, int c) {
-  return (g.own_base + c / g.own_w) % g.own_world == g.own_rank;
-}
+
 template <bool TRI>
 __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr, int& tc) {
   const int xcd = v & 7, q = v >> 3;
@@ -219,25 +236,8 @@ __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr
     r = r0 + (j - c * R);
   } else {
     const int cfull = (r0 + 1 < g.nt) ? r0 + 1 : g.nt;       // columns c <= r0: all R rows valid
-    if (g.own_world > 1) {
-      // only owned columns: the full ones by ordinal, the (at most 7) columns inside the band's
-      // diagonal triangle one by one
-      const int nfull = own_count(g, cfull);
-      if (j < nfull * R) {
-        const int o = j / R;
-        c = own_col(g, o);
-        r = r0 + (j - o * R);
-      } else {
-        int jj = j - nfull * R, t = 0;
-        for (;; ++t) {
-          const int cc = r0 + 1 + t;
-          if (!own_is(g, cc)) continue;
-          if (jj < R - 1 - t) break;
-          jj -= R - 1 - t;
-        }
-        c = r0 + 1 + t;
-        r = c + jj;
-      }
+    if (g.cyc) {
+      stair_decode(g, r0, R, j, r, c);
     } else if (j < cfull * R) {
       c = j / R;
       r = r0 + (j - c * R);
@@ -300,8 +300,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   for (int ks = 0; ks < 4; ++ks) laneM[ks] = lds_base + 8u * frag_lane_m<TA>(lane, wm, TA ? ks : 0);
   const unsigned laneN = lds_base + (unsigned)(2 * STAGE) * 8u + 8u * frag_lane_n<TB>(lane, wn);
 
-  dma_tile<TA>(g.A, g.lda, (int64_t)tr * BM, 0, lane, wu, sA);
-  dma_tile<TB>(g.B, g.ldb, (int64_t)tc * BN, 0, lane, wu, sB);
+  // operand rows: the tile's own row / column -- or, in the distributed update, the rows of the gathered panel
+  // that belong to the GLOBAL tiles this local tile stands for
+  int64_t aidx = (int64_t)tr * BM, bidx = (int64_t)tc * BN;
+  if (TRI != 0 && g.cyc) {
+    aidx = (int64_t)(cyc_l2g(g.rowc, g.rt0 + tr) - g.g0) * BM;
+    bidx = (int64_t)(cyc_l2g(g.colc, g.ct0 + tc) - g.g0) * BN;
+  }
+  dma_tile<TA>(g.A, g.lda, aidx, 0, lane, wu, sA);
+  dma_tile<TB>(g.B, g.ldb, bidx, 0, lane, wu, sB);
 
 #ifdef LPGP_STAMP
   const unsigned long long st_pro0 = __builtin_amdgcn_s_memtime();
@@ -343,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // drain vmcnt early; the last stage harmlessly re-loads its own k-tile)
     {
       const int knext = (kt + 1 < KT ? kt + 1 : kt) * BK;
-      dma_tile<TA>(g.A, g.lda, (int64_t)tr * BM, knext, lane, wu, sA + (cur ^ 1) * STAGE);
-      dma_tile<TB>(g.B, g.ldb, (int64_t)tc * BN, knext, lane, wu, sB + (cur ^ 1) * STAGE);
+      dma_tile<TA>(g.A, g.lda, aidx, knext, lane, wu, sA + (cur ^ 1) * STAGE);
+      dma_tile<TB>(g.B, g.ldb, bidx, knext, lane, wu, sB + (cur ^ 1) * STAGE);
     }
     // 16 chunks of 16 MFMAs per stage (4 k-steps x 4 groups of 4 n-fragments).  Fragments
     // are double-buffered in registers: the LDS reads of chunk c+1 are issued before the
@@ -864,15 +871,13 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     ga.dense = 1;
     ga.nbands = (g.mt + BAND - 1) / BAND;
     if (TRI) {
-      LPGP_CHECK(g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
+      LPGP_CHECK(g.cyc || g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
       int acc = 0;
       for (int b = 0; b < ga.nbands; ++b) {
         ga.band_prefix[b] = acc;
         const int r0 = b * BAND, R = std::min(BAND, g.mt - r0);
-        if (g.own_world > 1) {
-          acc += own_count(g, std::min(r0 + 1, g.nt)) * R;
-          for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t)
-            if (own_is(g, r0 + 1 + t)) acc += R - 1 - t;
+        if (g.cyc) {
+          acc += stair_band_count(g, r0, R);
         } else {
           acc += std::min(r0 + 1, g.nt) * R;
           for (int t = 0; t + 1 < R && r0 + 1 + t < g.nt; ++t) acc += R - 1 - t;
@@ -883,13 +888,13 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     } else {
       ga.ntiles = g.mt * g.nt;
     }
-    if (ga.ntiles == 0) return 0;                    // (ownership filter: nothing owned in this region)
+    if (ga.ntiles == 0) return 0;                    // (distributed update: no valid tile in this rank's region)
     ga.chunk = (ga.ntiles + 7) / 8;
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)(8 * ga.chunk)), dim3(256), shmem, stream, ga);
     LPGP_HIP(hipGetLastError());
     return 0;
   }
-  LPGP_CHECK(g.own_world <= 1, "gemm: the ownership filter needs the dense tile enumeration");
+  LPGP_CHECK(!g.cyc, "gemm: the distributed update needs the dense tile enumeration");
   int nsuper = 0, SS = 64;
   for (int sh = 3; sh >= 0; --sh) {
     const int S = 1 << sh;
@@ -909,6 +914,24 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   return 0;
 }
 
+// Host replay of the staircase enumeration of a distributed update (tests: every valid local tile exactly once):
+// out[2 i], out[2 i + 1] = (local tile row, local tile column) of list index i; returns the number of tiles.
+int stair_enumerate_host(const GemmArgs& g, int32_t* out, int64_t cap) {
+  const int nbands = (g.mt + BAND - 1) / BAND;
+  int64_t n = 0;
+  for (int b = 0; b < nbands; ++b) {
+    const int r0 = b * BAND, R = std::min(BAND, g.mt - r0);
+    const int cnt = stair_band_count(g, r0, R);
+    for (int j = 0; j < cnt; ++j) {
+      int r, c;
+      stair_decode(g, r0, R, j, r, c);
+      if (n < cap) { out[2 * n] = r; out[2 * n + 1] = c; }
+      ++n;
+    }
+  }
+  return (int)n;
+}
+
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel) {
   if (g.mt <= 0 || g.nt <= 0 || g.k <= 0) return 0;
   LPGP_CHECK(g.k % BK == 0, "gemm: k=%d not a multiple of %d", g.k, BK);
@@ -917,14 +940,19 @@ int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArg
   // (not for in-place products X <- X * B: with 64-column tiles another workgroup would still be
   //  reading the columns of X this one overwrites)
   const int64_t tiles = g.tri ? ((int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt) : (int64_t)g.mt * g.nt;
-  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C && g.own_world <= 1;
+  const bool small = tiles <= ctx->small_tiles_max && g.A != g.C && g.B != g.C && !g.cyc;
   if (prof_kernel >= 0) {
     // one profiling slot == one kernel symbol (family)
     if (small) prof_kernel = LPGP_K_GEMM_SMALL;
     else if (g.tri) prof_kernel = g.tri == 2 ? LPGP_K_SYRK_PANEL : (g.tri == 3 ? LPGP_K_SYRK_AHEAD : LPGP_K_SYRK);
     const double m = (double)g.mt * BM, n = (double)g.nt * BN, k = (double)g.k;
     // algorithmic flops: a symmetric update counts the lower trapezoid (m >= n) only
-    const double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
+    double flops = g.tri ? 2.0 * k * (m * n - 0.5 * n * (n - 1.0)) : 2.0 * m * n * k;
+    if (g.tri && g.cyc) {            // distributed update: the staircase of this rank's valid tiles (diagonal tiles count half)
+      double tiles_valid = 0.0;
+      for (int r0 = 0; r0 < g.mt; r0 += BAND) tiles_valid += stair_band_count(g, r0, std::min(BAND, g.mt - r0));
+      flops = 2.0 * k * (double)BM * BN * tiles_valid;
+    }
     prof_begin(ctx, stream, prof_kernel, flops, 0.0);
   }
   int rc;

@@ -15,6 +15,35 @@ namespace lpgp {
 
 constexpr int TILE = 128;          // base tile: potrf_tile block, GEMM block tile, padding unit
 
+// ---- 2-D block-cyclic distribution ------------------------------------------------------
+// Tiles of 128 are dealt in blocks of nbt tiles (nb = 512 columns): global tile g belongs to block g / nbt, owned by
+// member (g / nbt) % P of its process row / column.  A member stores its tiles in increasing global order.
+struct Cyc {
+  int32_t P = 1, me = 0, nbt = 4;
+};
+__host__ __device__ inline int cyc_owner(const Cyc& c, int g) { return (g / c.nbt) % c.P; }
+// number of tiles with global index < g that `me` owns == local index of global tile g if owned
+__host__ __device__ inline int cyc_before(const Cyc& c, int g) {
+  const int B = g / c.nbt, rem = g - B * c.nbt;
+  return ((B + c.P - 1 - c.me) / c.P) * c.nbt + ((B % c.P) == c.me ? rem : 0);
+}
+__host__ __device__ inline int cyc_l2g(const Cyc& c, int l) {
+  const int lb = l / c.nbt;
+  return (lb * c.P + c.me) * c.nbt + (l - lb * c.nbt);
+}
+// global padded index -> local index, or -1 if another member owns it
+__host__ __device__ inline int64_t cyc_local(const Cyc& c, int64_t gi) {
+  if (c.P == 1) return gi;                       // single member: local == global (no divisions on the single-GPU path)
+  const int g = (int)(gi / TILE);
+  if (cyc_owner(c, g) != c.me) return -1;
+  return (int64_t)cyc_before(c, g) * TILE + (gi - (int64_t)g * TILE);
+}
+// where a rank keeps element (row, column) of the global padded matrix: (row cyclic over Pr, column over Pc)
+struct Layout2D {
+  Cyc rows, cols;
+};
+
+
 
 #define LPGP_HIP(expr)                                                              \
   do {                                                                              \
@@ -74,7 +103,6 @@ struct lpgp_ctx {
   // (update-bound) or after the look-ahead half (chain-bound)
   double chain_us_tile = 115.0, solve_chain_us_tile = 115.0, chain_us_fixed = 80.0;
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
-  int dist_merged_update = 1;      // distributed factorisation: one ownership-filtered update launch per panel (0: one launch per owned panel)
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
@@ -92,15 +120,27 @@ struct lpgp_ctx {
   // of a multi-GB Gram matrix costs more than the factorisation of a small problem)
   struct PoolBuf { void* p; size_t bytes; };
   std::vector<PoolBuf> pool;
-  // multi-GPU (one process per GPU): cyclic panel ownership + RCCL panel broadcast
+  // multi-GPU (one process per GPU): Pr x Pc process grid, rank = r * Pc + c; 2-D block-cyclic tiles
   int rank = 0, world = 1;
-  int test_own_world = 0, test_own_rank = 0;   // tests only: ownership filter of the assembly as if (rank, world)
+  int pr = 1, pc = 1;
+  int grid_set = 0;                // lpgp_dist_set_grid called (else a default grid is chosen at init)
+  double comm_bytes_sent = 0.0, comm_bytes_recv = 0.0;
+  hipStream_t s_comm = nullptr;    // panel exchange (RCCL point-to-point group calls)
+  hipEvent_t ev_comm[2] = {nullptr, nullptr};
   void* nccl_comm = nullptr;       // ncclComm_t
   lpgp_host_exchange_fn host_xfer = nullptr;   // test transport (lpgp_dist_init_host): panels staged through the host
   void* host_xfer_user = nullptr;
   bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr; }
-  double* d_pack = nullptr;        // packed panel staging for the broadcast
+  double* d_pack = nullptr;        // packed panel pieces: [own piece | pieces received from the other sources]
   size_t pack_cap = 0;             // doubles
+  double* d_panel[2] = {nullptr, nullptr};   // gathered panel, dense, global row order (double-buffered for the look-ahead)
+  size_t panel_cap[2] = {0, 0};    // doubles
+  lpgp::Layout2D layout() const {
+    lpgp::Layout2D l;
+    l.rows.P = pr; l.rows.me = rank / pc; l.rows.nbt = (int32_t)(nb / lpgp::TILE);
+    l.cols.P = pc; l.cols.me = rank % pc; l.cols.nbt = (int32_t)(nb / lpgp::TILE);
+    return l;
+  }
   // kernels whose dynamic-LDS attribute has been raised on THIS context's device (the attribute is
   // per device, a process-wide flag would skip it for a second context on another GPU)
   std::vector<const void*> lds_attr_done;
@@ -129,8 +169,11 @@ struct lpgp_block {
 
 struct lpgp_mat {
   lpgp_ctx* ctx;
-  int64_t cap;                     // padded capacity (multiple of TILE) == leading dimension
-  double* a;                       // device cap x cap column-major (lower part meaningful)
+  int64_t cap;                     // padded capacity of the GLOBAL matrix (multiple of TILE); single GPU: == leading dimension
+  int64_t lr_cap = 0, lc_cap = 0;  // rows / columns of this rank's share (== cap on a single GPU); lr_cap is the leading dimension of a
+  double* dblk = nullptr;          // multi-GPU only: the nb x nb diagonal blocks of the factor, replicated on every rank:
+                                   //   block K at dblk + K * nb * nb, column-major, leading dimension nb
+  double* a;                       // device lr_cap x lc_cap column-major (lower part meaningful): this rank's tiles
   double* linv;                    // device (cap/TILE) tiles of TILE x TILE: inverse of each diagonal tile of L
   double* w;                       // device 2*cap: [representer weights | residual r] (padded layout)
   std::vector<lpgp_block> blocks;  // blocks of the current VIEW (lpgp_mat_set_view): a leading run of the observation blocks
@@ -203,14 +246,19 @@ struct GemmArgs {
   int32_t ntiles = 0, chunk = 0, nbands = 0;
   static constexpr int MAXB = 192; // bands of 8 tile rows: 1536 tile rows = 196 608 matrix rows (> 288 GB of fp64)
   int32_t band_prefix[MAXB + 1];   // triangular shapes only: tiles before band b
-  // distributed factorisation (triangular shapes, dense enumeration): only the tile columns of the
-  // panels this rank owns are enumerated -- local tile column c belongs to panel own_base + c / own_w,
-  // owned if that is congruent to own_rank modulo own_world (own_world <= 1: every column)
-  int32_t own_world = 1, own_rank = 0, own_base = 0, own_w = 4;
+  // distributed trailing update (cyc != 0, triangular shapes, dense enumeration): C is a region of this rank's
+  // LOCAL tiles -- local tile row tr / column tc stand for the global tiles gr = cyc_l2g(rowc, rt0 + tr) and
+  // gc = cyc_l2g(colc, ct0 + tc) -- and both operands are rows of ONE dense panel in global row order that
+  // starts at global tile g0: A tile = A + (gr - g0) * 128, B tile = B + (gc - g0) * 128.  A tile is valid iff
+  // gr >= gc: a staircase, enumerated band by band like the triangle (map_tile_stair in gemm.hip).
+  int32_t cyc = 0;
+  Cyc rowc, colc;
+  int32_t rt0 = 0, ct0 = 0, g0 = 0;
   unsigned long long* stamps = nullptr;   // diagnostic builds (-DLPGP_STAMP) only
   unsigned long long* timeline = nullptr; // diagnostic builds: per-workgroup life cycle + hardware id
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
+int stair_enumerate_host(const GemmArgs& g, int32_t* out, int64_t cap);
 // Tile solves with one step of iterative refinement (gemm.hip: tile_solve_kernel); L = the 128 x 128 diagonal
 // tile of the factor (leading dimension ldl, zeros above the diagonal), linv its explicit inverse (ld 128):
 // X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place
@@ -225,34 +273,36 @@ int debug_tile_xcc(int32_t* out8, int reset);
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base);
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
-int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
+// dist.hip: Pr x Pc block-cyclic factorisation and panel-streaming solves
+int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
+int trsm_lower_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
+int trsm_lower_t_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
+int factor_to_host_dist(lpgp_ctx* ctx, lpgp_mat* mat, double* out_padded /* pn x pn column-major */);
+int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols);
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp);
 int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T, double* b, double* x);
 
 // assemble.hip ----------------------------------------------------------------------------
-// own_*: column ownership filter of the distributed factorisation: 64-wide tile columns whose
-// padded column index c >= own_from belong to panel (c - own_from) / own_width, owned by rank
-// panel % own_world; tiles of other ranks are skipped (own_world <= 1: no filter).
-struct OwnFilter {
-  int32_t world = 1, rank = 0;
-  int64_t from = 0, width = 512;
-};
+// Every assembly kernel writes element (row_off + i, col_off + j) of the GLOBAL padded matrix to where `lay` keeps
+// it on this rank -- or not at all if another rank owns it (single GPU: the identity layout).
 int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
-                    const OwnFilter& own = OwnFilter());
+                    const Layout2D& lay = Layout2D());
 int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
                          const double* const* F0, const int64_t* n0d, const double* const* F1, const int64_t* n1d,
                          double* work, size_t work_doubles, double* out, int64_t ld, int64_t row_off,
-                         int64_t col_off, int lower_only, const OwnFilter& own);
+                         int64_t col_off, int lower_only, const Layout2D& lay);
 size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d);
 constexpr int MV_RHS = 4;         // right-hand sides per pass of the matrix-free product (== MV_R in assemble.hip)
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
                   double* part, int splits, double* out);
-int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar);
-int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b);
+int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar,
+                    const Layout2D& lay = Layout2D());
+int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b,
+                     const Layout2D& lay = Layout2D());
 
 }  // namespace lpgp

@@ -15,8 +15,6 @@
 #include <climits>
 #include <cstdlib>
 
-#include <rccl/rccl.h>
-
 #include "lpgp_internal.h"
 
 namespace lpgp {
@@ -547,20 +545,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------
-// Distributed factorisation, one process per GPU.  Process grid 1 x P:
-// panel i (nb columns, counted from the first unfactored tile) is owned by rank i % P.
-//   owner:      factors the panel (same kernels as above), packs  [L panel | tile inverses]
-//               and broadcasts it (ncclBroadcast over xGMI);
-//   every rank: unpacks received panels in place (so it ends with the FULL factor and all
-//               tile inverses -> triangular solves and prediction need no communication) and
-//               applies the rank-nb update only to the panel columns it owns.
-// Look-ahead: the owner of panel k+1 updates that panel's columns first on the panel stream,
-// factors and broadcasts it while its update stream (and everybody else's) still applies
-// panel k.  The only collective is the panel broadcast; message size (T-p0)*128*nb*8 B
-// (c4: up to 272 MB), total received per rank ~ 4 N^2 bytes.
-// ---------------------------------------------------------------------------------------
-// column-major rows x cols block copy (rows a multiple of 128): pack / unpack of a panel.
+// column-major rows x cols block copy (rows even): pack / unpack of panels, small 2-D copies.
 // (hipMemcpy2DAsync device-to-device ran at ~0.1 TB/s here: 1.1 ms per panel at N = 34k.)
 __global__ __launch_bounds__(256) void copy2d_kernel(double* __restrict__ dst, int64_t ldd,
                                                       const double* __restrict__ src, int64_t lds, int64_t rows) {
@@ -569,203 +554,14 @@ __global__ __launch_bounds__(256) void copy2d_kernel(double* __restrict__ dst, i
   if (r < rows)
     *reinterpret_cast<double2*>(dst + c * ldd + r) = *reinterpret_cast<const double2*>(src + c * lds + r);
 }
-static int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) {
+int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 0;
-  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, dst, ldd,
-                     src, lds, rows);
+  for (int64_t c0 = 0; c0 < cols; c0 += 65535) {          // grid.y limit
+    const int64_t nc = cols - c0 < 65535 ? cols - c0 : 65535;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)nc), dim3(256), 0, st, dst + c0 * ldd, ldd,
+                       src + c0 * lds, lds, rows);
+  }
   LPGP_HIP(hipGetLastError());
-  return 0;
-}
-
-static int ensure_pack(lpgp_ctx* ctx, size_t doubles) {
-  if (doubles <= ctx->pack_cap) return 0;
-  if (ctx->d_pack) LPGP_HIP(hipFree(ctx->d_pack));
-  ctx->d_pack = nullptr;
-  ctx->pack_cap = 0;
-  LPGP_HIP(hipMalloc(&ctx->d_pack, doubles * sizeof(double)));
-  ctx->pack_cap = doubles;
-  return 0;
-}
-
-#define LPGP_NCCL(expr)                                                                    \
-  do {                                                                                     \
-    ncclResult_t _r = (expr);                                                              \
-    if (_r != ncclSuccess) {                                                               \
-      ::lpgp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
-      return -3;                                                                           \
-    }                                                                                      \
-  } while (0)
-
-int potrf_blocked_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
-  const int T = (int)T64, t_done = (int)t_done64;
-  const int64_t ld = mat->cap;
-  double* a = mat->a;
-  const int nbt = (int)(ctx->nb / TILE);
-  const int64_t tb = TILE;
-  const int P = ctx->world, me = ctx->rank;
-  ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
-  hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
-  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
-  auto owner_of = [&](int p0) { return ((p0 - t_done) / nbt) % P; };
-  std::vector<double> host_stage;                  // test transport only
-
-  // ---- phase A (append): every rank pushes the new rows through the factored columns
-  //      (replicated: n_new * n_old^2 flops), but updates only the new columns it owns ----
-  if (t_done > 0 && T > t_done) {
-    const int mnew = T - t_done;
-    double* rows = a + (int64_t)t_done * tb;
-    for (int p0 = 0; p0 < t_done; p0 += nbt) {
-      const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
-      for (int jt = p0; jt < p1; ++jt) {
-        double* X = rows + (int64_t)jt * tb * ld;
-        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, mnew));
-        if (jt + 1 < p1)
-          LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                               mk(X, ld, a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld,
-                                  rows + (int64_t)(jt + 1) * tb * ld, ld, mnew, p1 - jt - 1, TILE, -1.0, 1.0, 0),
-                               LPGP_K_GEMM));
-      }
-      const int K = (p1 - p0) * TILE;
-      double* Xp = rows + (int64_t)p0 * tb * ld;
-      if (p1 < t_done)
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                             mk(Xp, ld, a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld,
-                                rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
-                             LPGP_K_GEMM));
-      if (ctx->dist_merged_update && ctx->dense_tiles) {   // owned panels of the new region: one filtered launch
-        const double* Xq = a + (int64_t)t_done * tb + (int64_t)p0 * tb * ld;
-        GemmArgs g = mk(Xq, ld, Xq, ld, a + (int64_t)t_done * tb * (ld + 1), ld, T - t_done, T - t_done, K, -1.0, 1.0, 1);
-        g.own_world = P;
-        g.own_rank = me;
-        g.own_base = 0;
-        g.own_w = nbt;
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0, g, LPGP_K_SYRK));
-      } else
-      for (int q0 = t_done; q0 < T; q0 += nbt) {           // owned panels of the new region
-        if (owner_of(q0) != me) continue;
-        const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
-        const double* Xq = a + (int64_t)q0 * tb + (int64_t)p0 * tb * ld;
-        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                             mk(Xq, ld, Xq, ld, a + (int64_t)q0 * tb * (ld + 1), ld, T - q0, q1 - q0, K, -1.0, 1.0, 1),
-                             LPGP_K_SYRK));
-      }
-    }
-  }
-
-  // ---- phase B ----
-  int it = 0;
-  bool have_upd_event = false;
-  for (int p0 = t_done; p0 < T; p0 += nbt, ++it) {
-    const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
-    const int own = owner_of(p0);
-    const int rows = (T - p0) * TILE, cols = (p1 - p0) * TILE;
-    const size_t cnt = (size_t)rows * cols + (size_t)(p1 - p0) * TILE * TILE;
-    LPGP_TRY(ensure_pack(ctx, cnt));
-    double* pk = ctx->d_pack;
-    double* panel = a + (int64_t)p0 * tb * (ld + 1);
-    double* linv0 = mat->linv + (int64_t)p0 * tb * tb;
-    if (own == me) {
-      for (int jt = p0; jt < p1; ++jt) {
-        double* dj = a + (int64_t)jt * tb * (ld + 1);
-        double* linv = mat->linv + (int64_t)jt * tb * tb;
-        LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
-        if (jt + 1 < T) {
-          double* X = dj + tb;
-          LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, T - jt - 1));
-          if (jt + 1 < p1)
-            LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                                 mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
-                                    p1 - jt - 1, TILE, -1.0, 1.0, 2),
-                                 LPGP_K_SYRK_PANEL));
-        }
-      }
-      LPGP_TRY(copy2d(sP, pk, rows, panel, ld, rows, cols));
-      LPGP_HIP(hipMemcpyAsync(pk + (size_t)rows * cols, linv0, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
-                              hipMemcpyDeviceToDevice, sP));
-    }
-    if (ctx->host_xfer) {
-      // test transport: D2H on the owner, the caller's exchange, H2D on the receivers
-      if (host_stage.size() < cnt) host_stage.resize(cnt);
-      if (own == me) LPGP_HIP(hipMemcpyAsync(host_stage.data(), pk, cnt * sizeof(double), hipMemcpyDeviceToHost, sP));
-      LPGP_HIP(hipStreamSynchronize(sP));
-      LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 0, host_stage.data(), (int64_t)(cnt * sizeof(double)), own) == 0,
-                 "host exchange: broadcast of panel %d failed", it);
-      if (own != me) {
-        LPGP_HIP(hipMemcpyAsync(pk, host_stage.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sP));
-        LPGP_HIP(hipStreamSynchronize(sP));          // host_stage is reused by the next panel
-      }
-    } else {
-      LPGP_NCCL(ncclBroadcast(pk, pk, cnt, ncclDouble, own, comm, sP));
-    }
-    static const bool selftest = std::getenv("LPGP_DIST_SELFTEST") != nullptr;
-    if (own == me && selftest) {
-      // single-GPU test of the receive path: forget the panel (NaN bytes), then unpack it like a receiver
-      LPGP_HIP(hipMemset2DAsync(panel, (size_t)ld * sizeof(double), 0xFF, (size_t)rows * sizeof(double), (size_t)cols, sP));
-      LPGP_HIP(hipMemsetAsync(linv0, 0xFF, (size_t)(p1 - p0) * TILE * TILE * sizeof(double), sP));
-    }
-    if (own != me || selftest) {
-      LPGP_TRY(copy2d(sP, panel, ld, pk, rows, rows, cols));
-      LPGP_HIP(hipMemcpyAsync(linv0, pk + (size_t)rows * cols, (size_t)(p1 - p0) * TILE * TILE * sizeof(double),
-                              hipMemcpyDeviceToDevice, sP));
-    }
-    if (p1 >= T) break;
-    const int K = cols;
-    // (a) look-ahead: the owner of the next panel brings its columns up to date on the panel stream
-    const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
-    if (owner_of(p1) == me) {
-      if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
-      const double* P1 = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;
-      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                           mk(P1, ld, P1, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 1),
-                           LPGP_K_SYRK));
-    }
-    // (b) is released when (a) is complete (see potrf_blocked)
-    hipEvent_t evp = ctx->ev_panel[it & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));
-    // (b) the other owned panels on the update stream
-    LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
-    if (ctx->dist_merged_update && ctx->dense_tiles && p2 < T) {
-      // ONE launch over the lower triangle from p2 on, enumerating only the tile columns of the
-      // panels this rank owns (a launch per owned panel -- (T - q0) x 4 tiles each, one after the
-      // other on the update stream -- leaves a partly filled last round per panel: with P = 2 a rank
-      // owns every other panel, 20 launches of ~1.3 rounds per step at N = 20k)
-      const double* Pq = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
-      GemmArgs g = mk(Pq, ld, Pq, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, T - p2, K, -1.0, 1.0, 1);
-      g.own_world = P;
-      g.own_rank = me;
-      g.own_base = ((p2 - t_done) / nbt) % P;
-      g.own_w = nbt;
-      LPGP_TRY(launch_gemm(ctx, sU, 0, 0, g, LPGP_K_SYRK));
-    } else
-    for (int q0 = p2; q0 < T; q0 += nbt) {
-      if (owner_of(q0) != me) continue;
-      const int q1 = (q0 + nbt < T) ? q0 + nbt : T;
-      const double* Pq = a + (int64_t)q0 * tb + (int64_t)p0 * tb * ld;
-      LPGP_TRY(launch_gemm(ctx, sU, 0, 0,
-                           mk(Pq, ld, Pq, ld, a + (int64_t)q0 * tb * (ld + 1), ld, T - q0, q1 - q0, K, -1.0, 1.0, 1),
-                           LPGP_K_SYRK));
-    }
-    LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
-    have_upd_event = true;
-    // the pack buffer is reused by the next broadcast: the panel stream must not overwrite it while
-    // this rank's unpack is still running -- both are on sP, in order.
-  }
-  LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
-  LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
-  int h_info = 0;
-  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
-  LPGP_HIP(hipStreamSynchronize(sP));
-  // a failed pivot is detected by the panel's owner only: agree on it (max over ranks)
-  if (ctx->host_xfer) {
-    LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, &h_info, (int64_t)sizeof(int), 0) == 0, "host exchange: all-reduce failed");
-  } else {
-    int* d = ctx->d_info;
-    LPGP_HIP(hipMemcpyAsync(d, &h_info, sizeof(int), hipMemcpyHostToDevice, sP));
-    LPGP_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMax, comm, sP));
-    LPGP_HIP(hipMemcpyAsync(&h_info, d, sizeof(int), hipMemcpyDeviceToHost, sP));
-    LPGP_HIP(hipStreamSynchronize(sP));
-  }
-  if (info) *info = h_info;
   return 0;
 }
 
@@ -842,8 +638,6 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   }
   return 0;
 }
-
-static int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols);
 
 // V <- L^{-T} V (backward substitution), same layout.
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_t ldv, int64_t m_pad) {

@@ -26,18 +26,26 @@ class Context:
         self.device = int(device)
         self.rank, self.world, self.comm = 0, 1, None
 
-    def dist_init(self, comm, transport: str = "rccl") -> None:
+    def dist_init(self, comm, transport: str = "rccl", grid: "tuple[int, int] | None" = None) -> None:
         """Join a one-process-per-GPU job.  `comm` is the control plane (`_dist.Comm`).
-        transport "rccl" (the product path): rank 0 creates the RCCL unique id, everybody receives
-        it, then `ncclCommInitRank`; panels travel by `ncclBroadcast` over xGMI.  transport "host"
-        (bring-up / tests): panels are staged through the host and exchanged over the control
-        plane, so that several ranks may share one GPU.  From here on `GramMatrix.assemble/potrf`
-        run the distributed factorisation (cyclic panel ownership, replicated factor)."""
+        `grid` = (Pr, Pc) process grid of the 2-D block-cyclic tile distribution (rank = r * Pc + c); default:
+        $LPGP_GRID ("2x4") or the library's choice (Pr = world, Pc = 1, see lpgp.h).
+        transport "rccl" (the product path): rank 0 creates the RCCL unique id, everybody receives it, then
+        `ncclCommInitRank`; panels travel as grouped point-to-point sends over xGMI.  transport "host"
+        (bring-up / tests): the same messages staged through the host and exchanged over the control plane, so
+        that several ranks may share one GPU.  From here on every call on a `GramMatrix` is collective."""
         if transport not in ("rccl", "host"):
             raise ValueError("transport must be 'rccl' or 'host'")
         if comm.world == 1 and not os.environ.get("LPGP_FORCE_RCCL") and transport == "rccl":
             self.comm = comm
             return
+        if grid is None and os.environ.get("LPGP_GRID"):
+            a, b = os.environ["LPGP_GRID"].lower().split("x")
+            grid = (int(a), int(b))
+        if grid is not None:
+            if grid[0] * grid[1] != comm.world:
+                raise ValueError(f"grid {grid[0]} x {grid[1]} does not match {comm.world} ranks")
+            check(lib.lpgp_dist_set_grid(self._h, int(grid[0]), int(grid[1])), "lpgp_dist_set_grid")
         if transport == "host":
             def exchange(_user, op, buf, nbytes, root):
                 try:
@@ -57,14 +65,35 @@ class Context:
                   "lpgp_dist_init_host")
             self.rank, self.world, self.comm = comm.rank, comm.world, comm
             return
-        uid = None
+        # every rank leaves the bring-up in step, also when it fails: rank 0 broadcasts (ok, id-or-error), and the
+        # outcome of ncclCommInitRank is agreed on before anybody raises (a rank that raised alone would leave the
+        # others blocked in their first collective)
+        msg = None
         if comm.rank == 0:
             buf = C.create_string_buffer(128)
-            check(lib.lpgp_dist_unique_id(buf), "lpgp_dist_unique_id")
-            uid = buf.raw
-        uid = comm.bcast(uid)
-        check(lib.lpgp_dist_init(self._h, comm.rank, comm.world, uid), "lpgp_dist_init")
+            rc = lib.lpgp_dist_unique_id(buf)
+            msg = (True, buf.raw) if rc == 0 else (False, lib.lpgp_last_error().decode(errors="replace"))
+        ok, payload = comm.bcast(msg)
+        if not ok:
+            raise _lib.LpgpError(f"lpgp_dist_unique_id failed on rank 0: {payload}")
+        rc = lib.lpgp_dist_init(self._h, comm.rank, comm.world, payload)
+        err = "" if rc == 0 else lib.lpgp_last_error().decode(errors="replace")
+        results = comm.allgather((rc == 0, err))
+        if not all(o for o, _ in results):
+            raise _lib.LpgpError("lpgp_dist_init failed: " + "; ".join(f"rank {r}: {e}" for r, (o, e) in enumerate(results) if not o))
         self.rank, self.world, self.comm = comm.rank, comm.world, comm
+
+    @property
+    def grid(self) -> "tuple[int, int]":
+        a, b = C.c_int32(), C.c_int32()
+        check(lib.lpgp_dist_grid(self._h, C.byref(a), C.byref(b)), "lpgp_dist_grid")
+        return a.value, b.value
+
+    def dist_stats(self, reset: bool = False) -> dict:
+        """Bytes this rank sent / received in panel exchanges (seconds inside them: `profile_get()["comm"]`)."""
+        s, r = C.c_double(), C.c_double()
+        check(lib.lpgp_dist_stats(self._h, C.byref(s), C.byref(r), int(bool(reset))), "lpgp_dist_stats")
+        return {"bytes_sent": s.value, "bytes_received": r.value}
 
     def close(self):
         if self._h:

@@ -102,107 +102,178 @@ def test_bench_weak_scaling_sizes():
         assert m == n // 2 and abs(flops(n, m) / (w * flops(128, 64)) - 1.0) < 0.06
 
 
-# ---- model of the distributed factorisation (csrc/potrf.hip: potrf_blocked_dist) ------------
-def _model_potrf_dist(A, t_done, T, nbt, tile, rank, world, bcast):
-    """NumPy mirror of potrf_blocked_dist, step for step: cyclic panel ownership, owner factors
-    + broadcasts, everybody unpacks, only owned panels are updated.  `A` holds valid data only in
-    the (unfactored) columns this rank owns and in the already factored columns."""
+# ---- model of the distributed factorisation (csrc/dist.hip: potrf_dist) ---------------------------------
+def _model_potrf_dist_2d(tiles, dblk, t_done, T, nbt, tb, pr, pc, rank, bcast):
+    """NumPy mirror of potrf_dist, step for step, on a Pr x Pc grid with 2-D block-cyclic tiles: `tiles` maps the
+    GLOBAL tile index (gi, gj), gi >= gj, to a tb x tb array and holds ONLY the tiles this rank owns; `dblk` is the
+    replicated store of diagonal-block tiles.  Per panel: the owner of the diagonal block factors and broadcasts it,
+    the panel's process column solves its rows, the rows below are gathered on every rank (one broadcast per source),
+    every rank updates its own tiles.  A block append runs the old panels first (new rows only)."""
     import numpy as np
     import scipy.linalg as sla
-    tb = tile
-    owner_of = lambda p0: ((p0 - t_done) // nbt) % world
-    # phase A (append): replicated push of the new rows through the old columns
+    my_r, my_c = divmod(rank, pc)
+    own_r = lambda g: (g // nbt) % pr
+    own_c = lambda g: (g // nbt) % pc
+    panels = []
     if t_done > 0 and T > t_done:
-        r0 = t_done * tb
-        for p0 in range(0, t_done, nbt):
-            p1 = min(p0 + nbt, t_done)
-            c0, c1 = p0 * tb, p1 * tb
-            Lpp = np.tril(A[c0:c1, c0:c1])
-            X = sla.solve_triangular(Lpp, A[r0:T * tb, c0:c1].T, lower=True).T
-            A[r0:T * tb, c0:c1] = X
-            if p1 < t_done:
-                A[r0:T * tb, c1:t_done * tb] -= X @ A[c1:t_done * tb, c0:c1].T
-            for q0 in range(t_done, T, nbt):
-                if owner_of(q0) != rank:
+        c0 = 0
+        while c0 < t_done:
+            c1 = min(t_done, (c0 // nbt + 1) * nbt)
+            panels.append((c0, c1, False))
+            c0 = c1
+    c0 = t_done
+    while c0 < T:
+        c1 = min(T, (c0 // nbt + 1) * nbt)
+        panels.append((c0, c1, True))
+        c0 = c1
+    for c0, c1, fresh in panels:
+        K, kw = c0 // nbt, c1 - c0
+        owner = own_r(c0) * pc + own_c(c0)
+        blk0 = K * nbt
+        if fresh:
+            if rank == owner:
+                D = np.zeros((kw * tb, kw * tb))
+                for i in range(kw):
+                    for j in range(i + 1):
+                        D[i * tb:(i + 1) * tb, j * tb:(j + 1) * tb] = tiles[(c0 + i, c0 + j)]
+                Lb = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
+                for i in range(kw):
+                    for j in range(i + 1):
+                        tiles[(c0 + i, c0 + j)] = Lb[i * tb:(i + 1) * tb, j * tb:(j + 1) * tb].copy()
+                # rows of this panel x the OLD columns of the same block (block append inside a block)
+                send = np.stack([tiles[(gi, gj)] for gi in range(c0, c1) for gj in range(blk0, gi + 1)])
+            else:
+                send = np.empty((sum(gi + 1 - blk0 for gi in range(c0, c1)), tb, tb))
+            got = bcast(send, owner)
+            it = iter(got)
+            for gi in range(c0, c1):
+                for gj in range(blk0, gi + 1):
+                    dblk[(gi, gj)] = next(it).copy()
+        if c1 >= T:
+            continue
+        row_lo = c1 if fresh else t_done
+        LKK = np.zeros((kw * tb, kw * tb))
+        for i in range(kw):
+            for j in range(i + 1):
+                LKK[i * tb:(i + 1) * tb, j * tb:(j + 1) * tb] = dblk[(c0 + i, c0 + j)]
+        LKK = np.tril(LKK)
+        if my_c == own_c(c0):
+            for gi in range(row_lo, T):
+                if own_r(gi) != my_r:
                     continue
-                q1 = min(q0 + nbt, T)
-                A[q0 * tb:T * tb, q0 * tb:q1 * tb] -= A[q0 * tb:T * tb, c0:c1] @ A[q0 * tb:q1 * tb, c0:c1].T
-    for p0 in range(t_done, T, nbt):
-        p1 = min(p0 + nbt, T)
-        own = owner_of(p0)
-        c0, c1 = p0 * tb, p1 * tb
-        if own == rank:
-            Lpp = np.linalg.cholesky(A[c0:c1, c0:c1])
-            A[c0:c1, c0:c1] = Lpp
-            if p1 < T:
-                A[c1:T * tb, c0:c1] = sla.solve_triangular(Lpp, A[c1:T * tb, c0:c1].T, lower=True).T
-            pk = np.ascontiguousarray(A[c0:T * tb, c0:c1])
-        else:
-            pk = np.empty((T * tb - c0, c1 - c0))
-        pk = bcast(pk, own)
-        if own != rank:
-            A[c0:T * tb, c0:c1] = pk
-        for q0 in range(p1, T, nbt):
-            if owner_of(q0) != rank:
+                A = np.hstack([tiles[(gi, gj)] for gj in range(c0, c1)])
+                X = sla.solve_triangular(LKK, A.T, lower=True).T
+                for j, gj in enumerate(range(c0, c1)):
+                    tiles[(gi, gj)] = X[:, j * tb:(j + 1) * tb].copy()
+        # gather the rows below the panel: one broadcast per source rank (r', process column of the panel)
+        panel = {}
+        for r in range(pr):
+            rows = [gi for gi in range(c1, T) if own_r(gi) == r]
+            if not rows:
                 continue
-            q1 = min(q0 + nbt, T)
-            A[q0 * tb:T * tb, q0 * tb:q1 * tb] -= A[q0 * tb:T * tb, c0:c1] @ A[q0 * tb:q1 * tb, c0:c1].T
-    return A
+            root = r * pc + own_c(c0)
+            if rank == root:
+                send = np.stack([np.hstack([tiles[(gi, gj)] for gj in range(c0, c1)]) for gi in rows])
+            else:
+                send = np.empty((len(rows), tb, kw * tb))
+            got = bcast(send, root)
+            for gi, P in zip(rows, got):
+                panel[gi] = P
+        for gi in range(row_lo, T):
+            if own_r(gi) != my_r:
+                continue
+            for gj in range(c1, gi + 1):
+                if own_c(gj) == my_c:
+                    tiles[(gi, gj)] = tiles[(gi, gj)] - panel[gi] @ panel[gj].T
+    return tiles
 
 
-def _dist_model_worker(rank, world, gloo_port, q):
+def _dist_model_worker(rank, world, pr, pc, gloo_port, q):
     import numpy as np
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{gloo_port}", rank=rank, world_size=world)
 
     def bcast(arr, root):
-        t = torch.from_numpy(arr)
+        t = torch.from_numpy(np.ascontiguousarray(arr))
         dist.broadcast(t, src=root)
         return t.numpy()
 
     rng = np.random.default_rng(5)               # same matrix on every rank
-    tile, nbt = 8, 2                             # scaled-down tiles; panel = 2 tiles
-    T1, T2 = 5, 12                               # first conditioning: 5 tiles; append up to 12 (ragged vs nbt)
-    n = T2 * tile
+    tb, nbt = 6, 2                               # scaled-down tiles; block = 2 tiles
+    T1, T2, T3 = 5, 12, 15                       # three conditionings; 5 and 12 are NOT block-aligned, 15 is ragged
+    n = T3 * tb
     M = rng.standard_normal((n, n + 10))
     G = M @ M.T + 0.5 * np.eye(n)
+    my_r, my_c = divmod(rank, pc)
+    mine = lambda gi, gj: (gi // nbt) % pr == my_r and (gj // nbt) % pc == my_c
+    tiles, dblk = {}, {}
     ok = True
-    for t_done, T in ((0, T1), (T1, T2)):
-        A = np.full((n, n), np.nan) if t_done == 0 else A
-        owner_of = lambda p0: ((p0 - t_done) // nbt) % world
-        # "assemble": unfactored columns only where owned; cross blocks (factored columns) everywhere
-        for p0 in range(t_done, T, nbt):
-            p1 = min(p0 + nbt, T)
-            if owner_of(p0) == rank:
-                A[p0 * tile:T * tile, p0 * tile:p1 * tile] = G[p0 * tile:T * tile, p0 * tile:p1 * tile]
-        if t_done > 0:
-            A[t_done * tile:T * tile, :t_done * tile] = G[t_done * tile:T * tile, :t_done * tile]
-        A = _model_potrf_dist(A, t_done, T, nbt, tile, rank, world, bcast)
-        L = np.tril(A[:T * tile, :T * tile])
-        ref = np.linalg.cholesky(G[:T * tile, :T * tile])
-        ok = ok and bool(np.all(np.isfinite(L))) and float(np.max(np.abs(L - ref))) < 1e-10
+    for t_done, T in ((0, T1), (T1, T2), (T2, T3)):
+        # "assemble": only the tiles this rank owns, only the new block row
+        for gi in range(t_done, T):
+            for gj in range(gi + 1):
+                if mine(gi, gj):
+                    tiles[(gi, gj)] = G[gi * tb:(gi + 1) * tb, gj * tb:(gj + 1) * tb].copy()
+        tiles = _model_potrf_dist_2d(tiles, dblk, t_done, T, nbt, tb, pr, pc, rank, bcast)
+        ref = np.linalg.cholesky(G[:T * tb, :T * tb])
+        for (gi, gj), blk in tiles.items():
+            want = ref[gi * tb:(gi + 1) * tb, gj * tb:(gj + 1) * tb]
+            got = np.tril(blk) if gi == gj else blk
+            ok = ok and bool(np.all(np.isfinite(got))) and float(np.max(np.abs(got - want))) < 1e-9
+        ok = ok and all(mine(gi, gj) for gi, gj in tiles) and len(tiles) == sum(
+            1 for gi in range(T) for gj in range(gi + 1) if mine(gi, gj))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_cholesky_model_gloo(world):
-    """Every rank must end with the FULL factor although it assembled only its own panels
-    (unowned columns start as NaN: reading one before it is received would poison the result),
-    for a fresh factorisation and for a block append with a ragged last panel."""
+@pytest.mark.parametrize("pr,pc", [(2, 1), (1, 2), (2, 2), (3, 1), (2, 3)])
+def test_distributed_cholesky_model_gloo(pr, pc):
+    """The algorithm of csrc/dist.hip on gloo ranks: every rank keeps ONLY its tiles of the 2-D block-cyclic
+    distribution (a rank that read a tile it does not own would raise KeyError) and must end with exactly its share
+    of the factor -- fresh factorisation, then two block appends whose boundaries fall inside a block."""
+    world = pr * pc
     gloo_port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_model_worker, args=(r, world, gloo_port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dist_model_worker, args=(r, world, pr, pc, gloo_port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_staircase_tile_enumeration_of_the_distributed_update():
+    """The trailing update of a rank enumerates its LOCAL tiles on or below the global diagonal -- a staircase --
+    densely (every valid tile exactly once, nothing else), for any grid, block size, region: host replay of
+    gemm.hip's map_tile_dense / stair_decode through the C ABI (no GPU needed) against brute force."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd"))
+    from linpde_gp_amd import _lib
+    cap = 60000
+    out = (C.c_int32 * (2 * cap))()
+    n_cases = 0
+    for pr, pc in [(1, 1), (2, 1), (1, 2), (2, 2), (2, 4), (4, 2), (3, 1), (8, 1), (1, 8), (3, 2)]:
+        for nbt in (1, 4):
+            for T in (1, 5, 13, 37):
+                for rlo, clo in [(0, 0), (3, 3), (7, 2), (T // 2, 1)]:
+                    if rlo > T or clo > T:
+                        continue
+                    for r in range(pr):
+                        for c in range(pc):
+                            n = _lib.lib.lpgp_test_stair_enumerate(pr, pc, r, c, nbt, T, rlo, clo, out, cap)
+                            assert 0 <= n <= cap
+                            got = [tuple(x) for x in np.frombuffer(out, dtype=np.int32, count=2 * n).reshape(n, 2)]
+                            want = {(i, j) for i in range(rlo, T) for j in range(clo, T)
+                                    if (i // nbt) % pr == r and (j // nbt) % pc == c and i >= j}
+                            assert len(got) == len(set(got)) and set(got) == want, (pr, pc, r, c, nbt, T, rlo, clo)
+                            n_cases += 1
+    assert n_cases > 1000
 
 
 def test_predict_sharding_bounds():
