@@ -10,11 +10,12 @@ weights) + prediction (cross-covariance assembly, posterior mean, marginal varia
 Point sets are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 N > 1 (launched by `python -m torch.distributed.run`, env RANK/LOCAL_RANK/WORLD_SIZE/
-MASTER_ADDR/MASTER_PORT): one process per GPU, all ranks factor ONE problem: panels of 512
-columns are owned cyclically by rank and broadcast with RCCL.  The problem
-grows with N so that the algorithmic flops PER GPU stay those of c3 ("scaling": "weak":
-grid side 128 -> 144 / 162 / 182 at 2 / 4 / 8 GPUs, prediction grid side = half of it; c3
-itself is 36 ms of factorisation, far too small to shard).  LPGP_BENCH_STRONG=1 shards c3
+MASTER_ADDR/MASTER_PORT): one process per GPU, all ranks factor ONE problem whose Gram matrix is
+sharded in 2-D block-cyclic tiles over a Pr x Pc process grid ($LPGP_GRID, default Pr = N, Pc = 1); panels
+travel as grouped RCCL point-to-point sends over xGMI, prediction points are sharded over the ranks
+(DESIGN.md §7).  The problem grows with N so that the algorithmic flops PER GPU stay those of c3
+("scaling": "weak": grid side 128 -> 144 / 162 / 182 at 2 / 4 / 8 GPUs, prediction grid side = half of
+it; c3 itself is 33 ms of factorisation, far too small to shard).  LPGP_BENCH_STRONG=1 shards c3
 itself ("strong"); LPGP_BENCH_REPLICAS=1 runs one independent c3 per rank.
 The product path never imports torch; ranks rendezvous over a plain TCP star.
 """
@@ -230,8 +231,14 @@ def main():
         return out_
 
     prof_syrk = profiled(["syrk_trailing"])      # dominant kernel alone: least perturbation
+    ctx.dist_stats(reset=True)
     prof = profiled(True)                        # every kernel (table)
     prof["syrk_trailing"] = prof_syrk["syrk_trailing"]
+    # per-rank communication of the table pass: bytes and seconds inside panel exchanges (HIP events on the stream
+    # the exchange is enqueued on), gathered so that the driver's scaling curve can be read
+    cs = ctx.dist_stats()
+    comm_rows = comm.gather([float(cs["bytes_sent"]) / prof_steps, float(cs["bytes_received"]) / prof_steps,
+                             float(prof["comm"]["ms"]) / args.steps])
 
     if rank != 0:
         comm.close()
@@ -268,11 +275,18 @@ def main():
             "algorithmic_flops_per_step": flops,
             "multi_gpu": ("single GPU" if world == 1 else
                           (dist_note or "independent replicas (one problem per GPU)") if replicas else
-                          f"one problem, panels of 512 columns owned cyclically by {world} ranks (1x{world} grid), "
-                          + ("HOST-STAGED panel broadcast (bring-up transport, not a benchmark configuration)"
-                             if os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host" else "RCCL panel broadcast")
-                          + ", replicated factor, prediction points sharded"
+                          f"one problem, Gram matrix / factor sharded in 2-D block-cyclic tiles (blocks of 512) over a "
+                          f"{ctx.grid[0]} x {ctx.grid[1]} process grid, "
+                          + ("HOST-STAGED panel exchange (bring-up transport, not a benchmark configuration)"
+                             if os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host" else
+                             "panel gather by grouped RCCL point-to-point sends")
+                          + ", prediction points sharded over the ranks, factor streamed for the solves"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
+            "rccl_ranks": 0 if (world == 1 or replicas or os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host") else world,
+            "process_grid": None if (world == 1 or replicas) else list(ctx.grid),
+            "comm_per_rank_per_step": None if (world == 1 or replicas) else [
+                {"rank": r, "bytes_sent": row[0], "bytes_received": row[1], "seconds_in_comm": row[2] * 1e-3}
+                for r, row in enumerate(comm_rows)],
             "device": info["name"].strip(),
         },
         "roofline": {

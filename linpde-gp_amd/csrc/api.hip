@@ -810,6 +810,18 @@ int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B
   return 0;
 }
 
+// A failure inside a collective call on ONE rank (HIP error, failed allocation, RCCL error) would leave the other
+// ranks blocked in their next send / receive for ever: abort the communicator, which makes every pending and later
+// RCCL call on every rank of the job return an error instead.  The context is unusable afterwards.
+static int dist_fail(lpgp_ctx* ctx, int rc) {
+  if (rc != 0 && ctx->nccl_comm && ctx->world > 1) {
+    (void)ncclCommAbort((ncclComm_t)ctx->nccl_comm);
+    ctx->nccl_comm = nullptr;
+    ctx->dist_broken = 1;
+  }
+  return rc;
+}
+
 int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host) {
   LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_to_host: null argument");
   LPGP_DEVICE(ctx);
@@ -821,7 +833,7 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
   if (ctx->distributed()) {
     LPGP_CHECK(what == 1, "lpgp_mat_to_host: only the factor can be collected in a multi-GPU job");
-    int rc = factor_to_host_dist(ctx, mat, tmp.data());      // collective: the factor is streamed to every rank
+    int rc = dist_fail(ctx, factor_to_host_dist(ctx, mat, tmp.data()));      // collective: the factor is streamed to every rank
     if (rc != 0) return rc;
   } else
   LPGP_HIP(hipMemcpy2D(tmp.data(), (size_t)pn * sizeof(double), mat->a, (size_t)mat->lr_cap * sizeof(double),
@@ -848,8 +860,9 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   if (mat->pn_fact == mat->pn) return 0;
   LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf: a strict prefix of the blocks is in view");
   int32_t h = 0;
+  LPGP_CHECK(!ctx->dist_broken, "lpgp_potrf: the communicator was aborted after an earlier failure");
   int rc = ctx->distributed()
-               ? potrf_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h)
+               ? dist_fail(ctx, potrf_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h))
                : potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
   if (rc != 0) return rc;
   if (info) *info = h;
@@ -871,9 +884,9 @@ int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
   int rc = 0;
   do {
     if (hipMemcpyAsync(dv, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, m_pad) : trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, m_pad)) : trsm_lower_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
     if (rc) break;
-    rc = ctx->distributed() ? trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, m_pad) : trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
+    rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, m_pad)) : trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
     if (rc) break;
     if (hipMemcpyAsync(hp.data(), dv, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
     if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
@@ -906,8 +919,8 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
     double* dv = (double*)pv;
     hipError_t e = hipMemsetAsync(dv, 0, vb, ctx->s_main);
     if (e == hipSuccess) e = hipMemcpyAsync(dv, mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main);
-    rc = e == hipSuccess ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, TILE) : -1;
-    if (rc == 0) rc = trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, TILE);
+    rc = dist_fail(ctx, e == hipSuccess ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, TILE) : -1);
+    if (rc == 0) rc = dist_fail(ctx, trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, TILE));
     if (rc == 0 && hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) rc = -1;
     pool_free(ctx, pv, vb);
   } else {
@@ -1006,7 +1019,7 @@ int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
   int rc = rhs_clear_unassembled(ctx, mat, V);
   if (rc != 0) return rc;
-  rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad)
+  rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_dist(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad))
                           : trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
   if (rc != 0) return rc;
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
@@ -1046,7 +1059,7 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
     double* zcol = K->v + (int64_t)m * K->ld;
     if (via_z)
       LPGP_HIP(hipMemcpyAsync(zcol, mat->r(), (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
-    rc = ctx->distributed() ? trsm_lower_dist(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad)
+    rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_dist(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad))
                             : trsm_lower_blocked(ctx, mat, mat->pn / TILE, K->v, K->ld, K->m_pad);
     if (rc != 0) return rc;
     if (via_z) {

@@ -124,13 +124,14 @@ struct lpgp_ctx {
   int rank = 0, world = 1;
   int pr = 1, pc = 1;
   int grid_set = 0;                // lpgp_dist_set_grid called (else a default grid is chosen at init)
+  int dist_broken = 0;             // the communicator was aborted after a failure inside a collective call
   double comm_bytes_sent = 0.0, comm_bytes_recv = 0.0;
   hipStream_t s_comm = nullptr;    // panel exchange (RCCL point-to-point group calls)
   hipEvent_t ev_comm[2] = {nullptr, nullptr};
   void* nccl_comm = nullptr;       // ncclComm_t
   lpgp_host_exchange_fn host_xfer = nullptr;   // test transport (lpgp_dist_init_host): panels staged through the host
   void* host_xfer_user = nullptr;
-  bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr; }
+  bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr || dist_broken; }
   double* d_pack = nullptr;        // packed panel pieces: [own piece | pieces received from the other sources]
   size_t pack_cap = 0;             // doubles
   double* d_panel[2] = {nullptr, nullptr};   // gathered panel, dense, global row order (double-buffered for the look-ahead)

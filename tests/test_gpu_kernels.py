@@ -183,29 +183,3 @@ def test_tile_solve_refined(which, n, cond):
     np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * cond / 1e6 * np.abs(exact).max() + 1e-13 * np.abs(exact).max())
 
 
-@pytest.mark.parametrize("T,world,rank,base", [(20, 2, 1, 0), (23, 3, 0, 2), (37, 4, 3, 1), (9, 8, 5, 3)])
-def test_ownership_filtered_triangular_update(T, world, rank, base, monkeypatch):
-    """The distributed factorisation's update launch: ONE triangular GEMM that enumerates only the tile
-    columns of the panels a rank owns (panel of local tile column c = base + c // 4, owner = panel %
-    world).  Owned columns must carry the rank-k update of the lower triangle, every other tile must be
-    untouched -- including ragged last panels and ranks that own nothing in a band."""
-    import linpde_gp_amd  # noqa: F401
-    from linpde_gp_amd import _engine
-    ctx = _engine.default_context()
-    rng = np.random.default_rng(T * 100 + world)
-    n, k, w = T * 128, 256, 4
-    A = rng.standard_normal((n, k))
-    C0 = np.asfortranarray(rng.standard_normal((n, n)))
-    monkeypatch.setenv("LPGP_TEST_OWN", f"{world},{rank},{base},{w}")
-    C, _ = _engine.test_gemm(ctx, 0, 0, 1, -1.0, A, A, 1.0, C0, k, reps=0)
-    monkeypatch.delenv("LPGP_TEST_OWN")
-    ref = C0 - A @ A.T
-    for c in range(T):
-        cols = slice(c * 128, (c + 1) * 128)
-        owned = (base + c // w) % world == rank
-        want = np.where(np.tril(np.ones((n, n), bool))[:, cols] & owned, ref[:, cols], C0[:, cols])
-        # (tiles above the diagonal are never written; diagonal tiles are written in full)
-        lower = np.tril(np.ones((n, n), bool), 0)[:, cols]
-        np.testing.assert_allclose(C[:, cols][lower], want[lower], rtol=0, atol=1e-10, err_msg=f"tile column {c} owned={owned}")
-        strictly_above_tile = np.triu(np.ones((n, n), bool), 128)[:, cols]
-        assert np.array_equal(C[:, cols][strictly_above_tile], C0[:, cols][strictly_above_tile])
