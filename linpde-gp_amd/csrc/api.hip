@@ -369,6 +369,9 @@ int lpgp_init(int device, lpgp_ctx** out) {
     if (v >= 0 && v % TILE == 0) ctx->nb_solve = v;
   }
   if (const char* e = std::getenv("LPGP_LOOKAHEAD")) ctx->lookahead = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_CHAIN_US_TILE")) ctx->chain_us_tile = std::atof(e);
+  if (const char* e = std::getenv("LPGP_SOLVE_CHAIN_US_TILE")) ctx->solve_chain_us_tile = std::atof(e);
+  if (const char* e = std::getenv("LPGP_CHAIN_US_FIXED")) ctx->chain_us_fixed = std::atof(e);
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);

@@ -647,7 +647,9 @@ constexpr int TSV_RING = 6656;               // doubles: byte-granular ring of f
 // use is issued.  The kernel is bound by the latency of these loads, not by their bytes or the matrix work
 // (measured with three fixed 17-KB slots, two in flight: 18 us for one wave of workgroups against 6 us of
 // MFMA time): what counts is bytes in flight per byte to fetch, and the trimmed stages put 4-5 of them in
-// flight in the same 52 KB.
+// flight in the same 52 KB.  (Measured after that, scratch/tile_solve_time.py with diagnostic builds: 16 us for one
+// wave of workgroups, 14 us with the factor loads removed altogether: what is left is the matrix work itself,
+// 3 x 288 MFMAs per SIMD = 6.8 us, plus launch, the loads of A and 26 barriers.)
 constexpr int tsv_stride(int s) { return 136 - 16 * (s % 8); }
 constexpr int tsv_size(int s) { return 16 * tsv_stride(s); }
 struct TsvSched {

@@ -101,7 +101,7 @@ struct lpgp_ctx {
   // estimated duration of one tile step of the panel chain (factorisation / forward substitution) and of
   // the per-panel rest, in microseconds: decides whether the remainder update is released with the panel
   // (update-bound) or after the look-ahead half (chain-bound)
-  double chain_us_tile = 115.0, solve_chain_us_tile = 115.0, chain_us_fixed = 80.0;
+  double chain_us_tile = 150.0, solve_chain_us_tile = 150.0, chain_us_fixed = 80.0;   // (re-swept after the tile solves got their refinement step: scratch/sweep_chain.sh)
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpgp.so")
+LIB_PATH = os.environ.get("LPGP_LIB", os.path.join(_HERE, "liblpgp.so"))     # $LPGP_LIB: a diagnostic build of the same library
 
 MAXD, MAXT, MAXG = 4, 64, 4
 MATERN_HALFINT, EXPQUAD, MATERN_ISO = 1, 2, 3

@@ -1,9 +1,25 @@
 #!/bin/bash
-# run on the GPU box: rocprofv3 stats + PMC passes of the bench command, then bench itself
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r01_stats gpurun_out/r01_pmc_fetch gpurun_out/r01_pmc_write
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01_stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/r01_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01_pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/r01_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01_pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/r01_pmc_write.log 2>&1
-python3 bench.py --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/bench_r01_c3.json
-tail -c 300 gpurun_out/r01_stats.log
+# Run on the GPU box (gpurun): rocprofv3 kernel stats + PMC passes (separate runs, no other trace domains) of ONE
+# bench command per configuration, then the bench line itself.  Every command that ran is written, verbatim, into
+# gpurun_out/<round>_<tag>/commands.txt, which scratch/summarize_profiles.py copies into the committed summary.
+#   usage: collect_profiles.sh <round, e.g. r02> <tag> <bench args ...>
+set -u
+ROUND=$1; TAG=$2; shift 2
+ARGS="$*"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+D=gpurun_out/${ROUND}_${TAG}
+rm -rf "$D"; mkdir -p "$D"
+run() {   # run <subdir> <rocprofv3 options ...> -- <program ...>; logs the command line exactly as executed
+  local sub=$1; shift
+  echo "$*" >> "$D/commands.txt"
+  "$@" > "$D/$sub.log" 2>&1
+}
+STATS_ARGS="--steps 5 --warmup 2 --no-cpu $ARGS"
+PMC_ARGS="--steps 1 --warmup 0 --no-cpu $ARGS"
+run stats rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -- python3 bench.py $STATS_ARGS
+run pmc_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$D/pmc_fetch" -- python3 bench.py $PMC_ARGS
+run pmc_write rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$D/pmc_write" -- python3 bench.py $PMC_ARGS
+run pmc_mfma rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$D/pmc_mfma" -- python3 bench.py $PMC_ARGS
+echo "python3 bench.py --steps 5 --warmup 2 --no-cpu $ARGS" >> "$D/commands.txt"
+python3 bench.py --steps 5 --warmup 2 --no-cpu $ARGS 2> "$D/bench.err" | tail -1 > "$D/bench.json"
+python3 scratch/summarize_profiles.py "$ROUND" "$TAG"
