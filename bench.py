@@ -162,6 +162,13 @@ def main():
     replicas = bool(int(os.environ.get("LPGP_BENCH_REPLICAS", "0")))
     strong = bool(int(os.environ.get("LPGP_BENCH_STRONG", "0")))
     dist_note = None
+    force_dist = world == 1 and bool(int(os.environ.get("LPGP_BENCH_FORCE_DIST", "0")))
+    if force_dist:
+        # measurement aid: ONE rank through the distributed code path (1 x 1 grid: sharded-storage kernels, panel
+        # gather / unpack, staircase update, panel-streaming solves -- everything but the wire)
+        os.environ["LPGP_FORCE_RCCL"] = "1"
+        ctx.dist_init(comm)
+        dist_note = "single rank through the DISTRIBUTED code path (LPGP_BENCH_FORCE_DIST=1)"
     if world > 1 and not replicas:
         # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be
         # created (on every rank alike), the run degrades to independent replicas and says so.
@@ -182,6 +189,11 @@ def main():
             if rank == 0:
                 sys.stderr.write("bench.py: " + dist_note + "\n")
     info = ctx.device_info()
+    # RCCL prints a version banner through C stdio when a communicator is created; on a pipe it would leave the
+    # buffer only at exit, i.e. AFTER the JSON line.  Push it out now, on every rank.
+    import ctypes
+    _libc = ctypes.CDLL(None)
+    _libc.fflush(None)
 
     n_side, m_side = args.n_side, args.m_side
     weak = world > 1 and not replicas and not strong and (n_side, m_side) == (128, 64)
@@ -273,7 +285,7 @@ def main():
             "m_predict": int(wl.Xtest.shape[0]),
             "noise_var_per_block": [None if o.noise_var is None else float(o.noise_var) for o in wl.observations],
             "algorithmic_flops_per_step": flops,
-            "multi_gpu": ("single GPU" if world == 1 else
+            "multi_gpu": ((dist_note or "single GPU") if world == 1 else
                           (dist_note or "independent replicas (one problem per GPU)") if replicas else
                           f"one problem, Gram matrix / factor sharded in 2-D block-cyclic tiles (blocks of 512) over a "
                           f"{ctx.grid[0]} x {ctx.grid[1]} process grid, "
@@ -325,8 +337,8 @@ def main():
                 "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": p["bytes"] / args.steps,
                 "launches_per_step": p["launches"] / args.steps,
             }
-    if args.workload != "poisson2d":
-        out["metric"] = f"condition+predict fp64 GFLOP/s (algorithmic), {wl.name}"
+    if args.workload != "poisson2d" or wl.n_total != 16896:
+        out["metric"] = f"condition+predict fp64 GFLOP/s (algorithmic), {wl.name} (N_tot={wl.n_total})"
     ref = None
     if not args.no_cpu and world == 1:
         out["cpu_baseline"], ref = cpu_baseline(problems, wl, args.cpu_side)
@@ -335,7 +347,9 @@ def main():
             from oracle import workloads as owl
             ref = owl.run(wl)
         out["parity"] = parity_report(mean, var, ref, wl)
-    print(json.dumps(out))
+    _libc.fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
     comm.close()
 
 

@@ -301,7 +301,8 @@ static int ensure_panel(lpgp_ctx* ctx, int which, size_t doubles) { return ensur
 int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
   const int T = (int)T64, t_done = (int)t_done64;
   const Grid G = grid_of(ctx);
-  hipStream_t sP = ctx->s_main, sU = ctx->s_upd_all;
+  // (b) on the CU-masked update stream: the tile Cholesky of the look-ahead needs a whole CU (potrf.hip)
+  hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
   LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
   const int LTr = cyc_before(G.R, T), LTc = cyc_before(G.C, T);
   const bool la = ctx->lookahead != 0;
@@ -387,30 +388,69 @@ int trsm_lower_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_
   const Grid G = grid_of(ctx);
   const int mtl = (int)(m_pad / TILE);
   const int64_t nb = (int64_t)G.nbt * TILE;
-  hipStream_t st = ctx->s_main;
+  const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
+  hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
+  struct Panel { int c0, c1; };
+  std::vector<Panel> panels;
   for (int c0 = 0; c0 < T;) {
     const int c1 = std::min(T, (c0 / G.nbt + 1) * G.nbt);
-    const int K = c0 / G.nbt, b0 = c0 - K * G.nbt;
-    // the rows below first: the gather does not depend on this panel's tile steps and travels underneath them
-    if (c1 < T) {
-      LPGP_TRY(ensure_panel(ctx, 0, (size_t)(T - c1) * TILE * (size_t)(c1 - c0) * TILE));
-      LPGP_TRY(gather_panel(ctx, st, mat, G, T, c0, c1, c1, ctx->d_panel[0]));
+    panels.push_back({c0, c1});
+    c0 = c1;
+  }
+  // panel stream: gather the rows below panel p into buffer `which` (it does not depend on the tile steps and
+  // travels underneath them), then the tile steps of the panel's own rows
+  auto panel_part = [&](const Panel& p, int which) -> int {
+    const int K = p.c0 / G.nbt, b0 = p.c0 - K * G.nbt, kw = p.c1 - p.c0;
+    if (p.c1 < T) {
+      LPGP_TRY(ensure_panel(ctx, which, (size_t)(T - p.c1) * TILE * (size_t)kw * TILE));
+      LPGP_TRY(gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, ctx->d_panel[which]));
     }
-    for (int j = 0; j < c1 - c0; ++j) {
-      double* Vj = v + (int64_t)(c0 + j) * TILE;
-      LPGP_TRY(launch_trsv_tile(ctx, st, Vj, ldv, mat->linv + (int64_t)(c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mtl,
+    for (int j = 0; j < kw; ++j) {
+      double* Vj = v + (int64_t)(p.c0 + j) * TILE;
+      LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)(p.c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mtl,
                                 LPGP_K_TRSM));
-      if (j + 1 < c1 - c0)
-        LPGP_TRY(launch_gemm(ctx, st, 0, 1,
-                             mk(dblk_tile(mat, G, K, b0 + j + 1, b0 + j), nb, Vj, ldv, Vj + TILE, ldv, c1 - c0 - j - 1, mtl, TILE, -1.0, 1.0, 0),
+      if (j + 1 < kw)
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 1,
+                             mk(dblk_tile(mat, G, K, b0 + j + 1, b0 + j), nb, Vj, ldv, Vj + TILE, ldv, kw - j - 1, mtl, TILE, -1.0, 1.0, 0),
                              LPGP_K_GEMM));
     }
-    if (c1 < T)
-      LPGP_TRY(launch_gemm(ctx, st, 0, 1,
-                           mk(ctx->d_panel[0], (int64_t)(T - c1) * TILE, v + (int64_t)c0 * TILE, ldv, v + (int64_t)c1 * TILE, ldv, T - c1, mtl,
-                              (c1 - c0) * TILE, -1.0, 1.0, 0),
-                           LPGP_K_GEMM));
-    c0 = c1;
+    return 0;
+  };
+  // rows [r0, r1) (global tiles, all below panel p) of V -= L[rows, panel p] V_p, from panel buffer `which`
+  auto update_rows = [&](hipStream_t st, const Panel& p, int which, int r0, int r1) -> int {
+    if (r1 <= r0) return 0;
+    const int64_t ldp = (int64_t)(T - p.c1) * TILE;
+    return launch_gemm(ctx, st, 0, 1,
+                       mk(ctx->d_panel[which] + (int64_t)(r0 - p.c1) * TILE, ldp, v + (int64_t)p.c0 * TILE, ldv, v + (int64_t)r0 * TILE, ldv,
+                          r1 - r0, mtl, (p.c1 - p.c0) * TILE, -1.0, 1.0, 0),
+                       LPGP_K_GEMM);
+  };
+  LPGP_TRY(panel_part(panels[0], 0));
+  bool have_upd = false;
+  for (size_t i = 0; i + 1 < panels.size(); ++i) {
+    const Panel& p = panels[i];
+    const Panel& q = panels[i + 1];
+    const int which = (int)(i & 1);
+    if (!la) {
+      LPGP_TRY(update_rows(sP, p, which, p.c1, T));
+      LPGP_TRY(panel_part(q, which ^ 1));
+      continue;
+    }
+    // look-ahead as in potrf_dist: (a) the next panel's rows on the panel stream, followed by that panel's gather and
+    // tile steps; (b) the rows below meanwhile on the update stream
+    hipEvent_t evp = ctx->ev_panel[i & 1];
+    LPGP_HIP(hipEventRecord(evp, sP));
+    if (have_upd) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(i + 1) & 1], 0));   // (a)'s rows and the next panel buffer: last touched by the previous (b)
+    LPGP_TRY(update_rows(sP, p, which, q.c0, q.c1));
+    LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+    LPGP_TRY(update_rows(sU, p, which, q.c1, T));
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sU));
+    have_upd = true;
+    LPGP_TRY(panel_part(q, which ^ 1));
+  }
+  if (have_upd) {
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
   }
   return 0;
 }
