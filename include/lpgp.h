@@ -261,6 +261,11 @@ int  lpgp_test_potrf_tile(lpgp_ctx* ctx, double* T, double* Linv, int32_t* info)
  * stores them); Linv the fp64 inverse of L.                                                    */
 int  lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, const double* L,
                          const double* Linv, double* ms);
+/* the fused panel step of the forward substitution on host buffers: V (nt * 128 rows x cols, col-major, ld = nt * 128,
+ * cols a multiple of 128) <- Lblk^{-1} V with Lblk the nt x nt tile lower-triangular block (col-major, ld nt * 128, the
+ * diagonal TILES with zeros above their diagonal) and Linv the nt explicit inverses of its diagonal tiles.       */
+int  lpgp_test_panel_solve(lpgp_ctx* ctx, double* V, int32_t nt, int64_t cols, const double* Lblk,
+                           const double* Linv, double* ms);
 /* diagnostics: histogram over the 8 XCDs of where the single workgroup of the tile Cholesky ran
  * since the last reset (the CU reservation of the update streams is built on it)           */
 int  lpgp_debug_tile_xcc(lpgp_ctx* ctx, int32_t* out8, int32_t reset);

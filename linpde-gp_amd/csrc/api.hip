@@ -373,6 +373,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_SOLVE_CHAIN_US_TILE")) ctx->solve_chain_us_tile = std::atof(e);
   if (const char* e = std::getenv("LPGP_CHAIN_US_FIXED")) ctx->chain_us_fixed = std::atof(e);
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_big = v;
@@ -453,6 +454,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->chain_us_fixed = (double)value;
   } else if (std::strcmp(key, "dense_tiles") == 0) {
     ctx->dense_tiles = (int)value;
+  } else if (std::strcmp(key, "fused_solve") == 0) {
+    ctx->fused_solve = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
   } else if (std::strcmp(key, "nb_solve") == 0) {
@@ -1348,6 +1351,37 @@ int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, con
   (void)hipFree(d);
   (void)hipFree(dl);
   (void)hipFree(dt);
+  return rc;
+}
+
+int lpgp_test_panel_solve(lpgp_ctx* ctx, double* V, int32_t nt, int64_t cols, const double* Lblk, const double* Linv, double* ms) {
+  LPGP_CHECK(ctx && V && Lblk && Linv && nt >= 1 && nt <= 4 && cols > 0 && cols % TILE == 0, "lpgp_test_panel_solve: bad argument");
+  LPGP_DEVICE(ctx);
+  const int64_t rows = (int64_t)nt * TILE;
+  double *d = nullptr, *dl = nullptr, *di = nullptr;
+  const size_t vb = (size_t)rows * cols * sizeof(double), lb = (size_t)rows * rows * sizeof(double), ib = (size_t)nt * TILE * TILE * sizeof(double);
+  LPGP_HIP(hipMalloc(&d, vb));
+  LPGP_HIP(hipMalloc(&dl, lb));
+  LPGP_HIP(hipMalloc(&di, ib));
+  LPGP_HIP(hipMemcpy(d, V, vb, hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(dl, Lblk, lb, hipMemcpyHostToDevice));
+  LPGP_HIP(hipMemcpy(di, Linv, ib, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  LPGP_HIP(hipEventCreate(&e0));
+  LPGP_HIP(hipEventCreate(&e1));
+  LPGP_HIP(hipEventRecord(e0, ctx->s_main));
+  int rc = launch_trsv_panel(ctx, ctx->s_main, d, rows, di, dl, rows, nt, (int)(cols / TILE), -1);
+  LPGP_HIP(hipEventRecord(e1, ctx->s_main));
+  LPGP_HIP(hipEventSynchronize(e1));
+  float t = 0.f;
+  LPGP_HIP(hipEventElapsedTime(&t, e0, e1));
+  if (ms) *ms = t;
+  if (rc == 0) LPGP_HIP(hipMemcpy(V, d, vb, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  (void)hipFree(dl);
+  (void)hipFree(di);
   return rc;
 }
 

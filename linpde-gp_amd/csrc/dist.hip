@@ -405,6 +405,9 @@ int trsm_lower_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int64_
       LPGP_TRY(ensure_panel(ctx, which, (size_t)(T - p.c1) * TILE * (size_t)kw * TILE));
       LPGP_TRY(gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, ctx->d_panel[which]));
     }
+    if (ctx->fused_solve && kw <= 4)
+      return launch_trsv_panel(ctx, sP, v + (int64_t)p.c0 * TILE, ldv, mat->linv + (int64_t)p.c0 * TILE * TILE, dblk_tile(mat, G, K, b0, b0), nb,
+                               kw, mtl, LPGP_K_PANEL);
     for (int j = 0; j < kw; ++j) {
       double* Vj = v + (int64_t)(p.c0 + j) * TILE;
       LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)(p.c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mtl,

@@ -104,6 +104,7 @@ struct lpgp_ctx {
   double chain_us_tile = 150.0, solve_chain_us_tile = 150.0, chain_us_fixed = 80.0;   // (re-swept after the tile solves got their refinement step: scratch/sweep_chain.sh)
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
+  int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
   // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,
@@ -268,6 +269,10 @@ int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, 
                      int nt, int prof_kernel);
 int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
                      int mt, int prof_kernel);
+// the whole chain of a panel of the forward substitution in one launch (gemm.hip: panel_solve_kernel): V (nt_rows <= 4
+// tiles of rows, top row at V) <- L_KK^{-1} V; linv: the panel's tile inverses (contiguous), L: its diagonal block
+int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
+                      int nt_rows, int nt_cols, int prof_kernel);
 
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);

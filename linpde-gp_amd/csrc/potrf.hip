@@ -577,8 +577,13 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   // updates) pay earlier than in the factorisation.  Measured (nb_solve = 512 / 768 / 1024 / 2048):
   // c2 (65 tile rows) 9.57 / - / 9.74 / - ms, c3 (132) 55.5 / 55.1 / 56.1 / - ms, c4 (520) 2702 / - / 2671 /
   // 2655 ms.
-  const int64_t nb_auto = T >= 384 ? 2048 : (T >= 96 ? 768 : ctx->nb);
+  // Panels of at most 512 rows run their whole chain -- the tile solves and the in-panel updates between them -- in ONE
+  // launch (panel_solve_kernel, gemm.hip: a workgroup owns 16 or 32 columns through the panel) up to 192 tile rows; beyond,
+  // the longer K of wider panels in the updates is worth more than the shorter chain (c5, 263 tile rows: 311.9 ms with
+  // panels of 768 and per-tile launches, 313.6 with fused panels of 512; scratch/fused_ab.sh)
+  const int64_t nb_auto = T >= 384 ? 2048 : ((ctx->fused_solve && T <= 192) ? 512 : (T >= 96 ? 768 : ctx->nb));
   const int nbt = (int)((ctx->nb_solve > 0 ? ctx->nb_solve : nb_auto) / TILE);
+  const bool fused = ctx->fused_solve && nbt <= 4;
   const double* a = mat->a;
   const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
   hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
@@ -586,6 +591,10 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   int it = 0;
   for (int p0 = 0; p0 < T; p0 += nbt, ++it) {
     const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
+    if (fused)
+      LPGP_TRY(launch_trsv_panel(ctx, sP, v + (int64_t)p0 * tb, ldv, mat->linv + (int64_t)p0 * tb * tb, a + (int64_t)p0 * tb * (ld + 1), ld,
+                                 p1 - p0, mtl, LPGP_K_PANEL));
+    else
     for (int jt = p0; jt < p1; ++jt) {
       double* Vj = v + (int64_t)jt * tb;
       LPGP_TRY(launch_trsv_tile(ctx, sP, Vj, ldv, mat->linv + (int64_t)jt * tb * tb, a + (int64_t)jt * tb * (ld + 1), ld, mtl,

@@ -462,6 +462,23 @@ def test_tile_step(ctx: Context, which: int, XV: np.ndarray, L: np.ndarray, Linv
     return XV, ms.value
 
 
+def test_panel_solve(ctx: Context, V: np.ndarray, Lblk: np.ndarray):
+    """Fused panel step of the forward substitution (`lpgp_test_panel_solve`): V (nt*128 x cols) <- Lblk^{-1} V.
+    Returns (result, milliseconds)."""
+    import scipy.linalg
+    rows, cols = V.shape
+    nt = rows // 128
+    V = np.asfortranarray(V, dtype=np.double).copy(order="F")
+    Lb = np.asfortranarray(np.tril(Lblk), dtype=np.double)
+    Linv = np.concatenate([np.asfortranarray(np.tril(scipy.linalg.solve_triangular(
+        Lb[t * 128:(t + 1) * 128, t * 128:(t + 1) * 128], np.eye(128), lower=True))).reshape(-1, order="F") for t in range(nt)])
+    ms = C.c_double(0.0)
+    pd = C.POINTER(C.c_double)
+    check(lib.lpgp_test_panel_solve(ctx._h, V.ctypes.data_as(pd), nt, cols, Lb.ctypes.data_as(pd),
+                                    np.ascontiguousarray(Linv).ctypes.data_as(pd), C.byref(ms)), "lpgp_test_panel_solve")
+    return V, ms.value
+
+
 def test_potrf_tile(ctx: Context, T: np.ndarray):
     T = np.asfortranarray(T, dtype=np.double).copy(order="F")
     Linv = np.zeros((128, 128), order="F")

@@ -114,6 +114,7 @@ def _load() -> C.CDLL:
     sig("lpgp_test_potrf_tile", C.c_int, vp, pd, pd, C.POINTER(i32))
     sig("lpgp_debug_tile_xcc", C.c_int, vp, C.POINTER(i32), i32)
     sig("lpgp_test_tile_step", C.c_int, vp, i32, pd, i64, pd, pd, pd)
+    sig("lpgp_test_panel_solve", C.c_int, vp, pd, i32, i64, pd, pd, pd)
     sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
     sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
     return lib
@@ -131,7 +132,7 @@ EXPORTED = [
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_profile_enable", "lpgp_profile_reset",
-    "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64",
+    "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_test_panel_solve", "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64",
     "lpgp_probe_hbm_write",
 ]
 

@@ -183,3 +183,25 @@ def test_tile_solve_refined(which, n, cond):
     np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * cond / 1e6 * np.abs(exact).max() + 1e-13 * np.abs(exact).max())
 
 
+
+
+@pytest.mark.parametrize("nt,cols", [(1, 128), (2, 1152), (3, 256), (4, 4224)])
+def test_fused_panel_solve(nt, cols):
+    """`panel_solve_kernel`: the whole chain of a panel of the forward substitution -- nt refined tile solves with the
+    rank-128 updates of the panel rows below in between -- in one launch, against LAPACK's triangular solve with the
+    nt x nt tile block; backward error at the level of a substitution although every tile solve is a product with an
+    explicit inverse (refined once)."""
+    import scipy.linalg
+    import linpde_gp_amd  # noqa: F401
+    from linpde_gp_amd import _engine
+    ctx = _engine.default_context()
+    rng = np.random.default_rng(7 * nt + cols)
+    n = nt * 128
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    L = np.linalg.cholesky((Q * np.logspace(0, -5, n) ** 2) @ Q.T)          # cond(L) = 1e5
+    V = rng.standard_normal((n, cols))
+    got, ms = _engine.test_panel_solve(ctx, V, L)
+    exact = scipy.linalg.solve_triangular(L, V, lower=True)
+    res = np.abs(L @ got - V) / (np.abs(L) @ np.abs(got))
+    assert np.max(res) < 5e-14, np.max(res)
+    np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * np.abs(exact).max())
