@@ -36,6 +36,7 @@
 // per link and never stored replicated.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -97,10 +98,16 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
     }
   } else {
     ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+    LPGP_CHECK(comm != nullptr, "panel exchange: no communicator (aborted after an earlier failure?)");
+    // LPGP_DIST_COLLECTIVE=bcast: one ncclBroadcast per piece instead of the point-to-point group (a fallback to compare
+    // with on the 8-GPU node, which the builder has no access to; RCCL then picks its own ring / tree)
+    static const bool use_bcast = [] { const char* e = std::getenv("LPGP_DIST_COLLECTIVE"); return e && std::string(e) == "bcast"; }();
     LPGP_NCCL(ncclGroupStart());
     for (const auto& p : pieces) {
       if (p.count == 0) continue;
-      if (p.root == ctx->rank) {
+      if (use_bcast) {
+        LPGP_NCCL(ncclBroadcast(p.buf, p.buf, p.count, ncclDouble, p.root, comm, st));
+      } else if (p.root == ctx->rank) {
         for (int peer = 0; peer < ctx->world; ++peer)
           if (peer != ctx->rank) LPGP_NCCL(ncclSend(p.buf, p.count, ncclDouble, peer, comm, st));
       } else {
