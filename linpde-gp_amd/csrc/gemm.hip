@@ -16,6 +16,7 @@
 // super-tile at a time (its 16 operand panels stay in that XCD's L2).
 
 #include "lpgp_internal.h"
+#include "kernel_util.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -41,8 +42,6 @@ constexpr int STAGE = BK * LDM;          // doubles per operand per stage (K ima
 // ~3000 cycles of latency under load and hipcc sinks register loads next to their ds_write
 // (exposing that latency every stage); DMA writes LDS, so it cannot be moved below the
 // stage's first ds_read and stays at the top of the stage.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Addresses are formed as (wave-uniform base) + (32-bit per-lane byte offset) so that hipcc
 // selects the SGPR-base addressing mode: one VGPR of lane offsets instead of a 64-bit
@@ -96,27 +95,6 @@ __device__ __forceinline__ unsigned frag_lane_n(int lane, int w) {
 template <bool T> constexpr int frag_imm_m(int ks, int t) { return T ? t * 256 : ks * 4 * LDM + t * 16; }
 template <bool T> constexpr int frag_imm_n(int ks, int nf) {       // nf = n-fragment 0..15 (4 columns each)
   return T ? nf * 64 + (((ks ^ nf) & 3) << 2) : ks * 4 * LDM + nf * 4;
-}
-
-// LDS read whose completion the COMPILER does not track: with LDS-DMA in flight hipcc turns
-// every wait for a ds_read result into s_waitcnt lgkmcnt(0), which also waits for the
-// prefetch just issued for the next chunk.  The reads are therefore issued from inline asm
-// and retired by hand-counted s_waitcnt lgkmcnt(N) (LDS operations return in order).
-template <int OFF_DOUBLES>
-__device__ __forceinline__ double lds_read_async(unsigned byte_addr) {
-  static_assert(OFF_DOUBLES >= 0 && OFF_DOUBLES * 8 < 65536, "ds_read offset field");
-  double d;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF_DOUBLES * 8));
-  return d;
-}
-#define LDS_WAIT(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
 }
 
 // MFMA shape: measured on MI355X, v_mfma_f64_16x16x4_f64 sustains only ~48 TFLOP/s chip-wide
@@ -605,512 +583,6 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
-}
-
-// =========================================================================================
-// Tile solve with ONE STEP OF ITERATIVE REFINEMENT, in place -- the latency-bound second kernel of
-// every step of the panel chain and the tile step of the multi-RHS forward substitution:
-//   KFAST = false:  X[rows, 0:128] <- X L^{-T}            X(i, c) at P[i + c ld]   (panel rows below a factored tile)
-//   KFAST = true :  V[0:128, cols] <- L^{-1} V, as X = V^T:  X(i, c) at P[c + i ld]   (i = right-hand-side column)
-// with L the 128 x 128 lower-triangular diagonal tile of the factor and Linv its explicit inverse:
-//     X0 = A Linv^T;    R = A - X0 L^T;    X = X0 + R Linv^T.
-// A product with the explicit inverse alone has a backward error of cond(L) eps (Linv L = I + E,
-// |E| ~ cond(L) eps): measured at c3 (cond of the diagonal tiles up to 3e5) the posterior mean was 1.8e-8
-// away from LAPACK's, 65x LAPACK's own distance from the long-double-refined solution
-// (scratch/parity_diag.py, scratch/tileinv_accuracy.py).  The refinement step squares E away: what is
-// left is the rounding of R, i.e. the backward error of a substitution -- at three latency-bound tile
-// products instead of one and no dependent chain of 128 steps.
-//
-// A workgroup of eight waves owns 32 rows: two groups of 16 rows x four waves; wave `cc` of a group owns
-// the output fragments u = cc, cc + 4, ..., cc + 28 (fragment u = columns 4u .. 4u + 3 of the 16 rows, in
-// the accumulator layout of v_mfma_f64_4x4x4_4b_f64: lane -> (row = lane & 15, column 4u + (lane >> 4))).
-// That layout IS the instruction's m-side operand layout for k-step u, so the result fragments of one
-// product are the operand fragments of the next: they are exchanged between the four waves of a group
-// through a 16-KB LDS image `xa[group][fragment][lane]`, never reshuffled.  The triangular factor is
-// streamed by LDS-DMA in 24 stages of 16 k-rows (Linv^T, L^T, Linv^T) through a statically scheduled circular
-// buffer (below).  Fragment u needs k-steps g <= u only (lower triangle): stage kt feeds the fragments u >= 4 kt,
-// 144 MFMAs per wave and product instead of 256; the fragments of a stage's own diagonal block meet the
-// explicit zeros above the diagonal of Linv / L.  The two groups take their classes in opposite order, so
-// every SIMD holds a wave with 4 cc and one with 4 (3 - cc) columns beyond the stage's diagonal.
-// LDS: 32 KB + 52 KB = 84 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup.
-// =========================================================================================
-constexpr int TSV_NSTAGE = 24;               // 3 products x 8 stages of 16 k
-constexpr int TSV_XA = 2 * 32 * 64;          // doubles: two row groups x 32 fragments x 64 lanes
-constexpr int TSV_ROWS = 32;                 // rows (KFAST: right-hand-side columns) per workgroup
-constexpr int TSV_RING = 6656;               // doubles: byte-granular ring of factor stages (52 KB)
-
-// Stage s = (product s / 8, k-rows 16 kt .. 16 kt + 15, kt = s % 8) holds only the columns the lower triangle
-// needs, c >= 16 kt: 16 rows of 128 - 16 kt doubles at a row stride of 136 - 16 kt (2 * stride % 64 is 16 or 48:
-// the four k-rows of a replicated n-side fragment read fall into four different bank groups).  The stages are
-// placed in ONE circular buffer by a schedule computed at compile time (the whole stage loop is unrolled):
-// at the top of stage s, right behind its barrier, every following stage that fits beside the stages still in
-// use is issued.  The kernel is bound by the latency of these loads, not by their bytes or the matrix work
-// (measured with three fixed 17-KB slots, two in flight: 18 us for one wave of workgroups against 6 us of
-// MFMA time): what counts is bytes in flight per byte to fetch, and the trimmed stages put 4-5 of them in
-// flight in the same 52 KB.  (Measured after that, scratch/tile_solve_time.py with diagnostic builds: 16 us for one
-// wave of workgroups, 14 us with the factor loads removed altogether: what is left is the matrix work itself,
-// 3 x 288 MFMAs per SIMD = 6.8 us, plus launch, the loads of A and 26 barriers.)
-constexpr int tsv_stride(int s) { return 136 - 16 * (s % 8); }
-constexpr int tsv_size(int s) { return 16 * tsv_stride(s); }
-struct TsvSched {
-  int off[TSV_NSTAGE] = {};        // ring offset of stage s (doubles)
-  int iss_lo[TSV_NSTAGE + 1] = {}; // stages [iss_lo[t], iss_hi[t]) are issued at time t: t = 0 before the loop,
-  int iss_hi[TSV_NSTAGE + 1] = {}; // t = s + 1 at the top of stage s (behind its barrier)
-  int wait[TSV_NSTAGE] = {};       // vmcnt at the top of stage s: this wave's DMA instructions of later stages in flight
-};
-constexpr TsvSched tsv_make_sched() {
-  TsvSched S;
-  int next = 0, head = 0;
-  for (int t = 0; t <= TSV_NSTAGE; ++t) {
-    const int live_lo = t == 0 ? 0 : t - 1;          // stages >= live_lo are in use or in flight
-    S.iss_lo[t] = next;
-    while (next < TSV_NSTAGE) {
-      const int sz = tsv_size(next);
-      int o = head;
-      if (o + sz > TSV_RING) o = 0;
-      bool ok = true;
-      for (int l = live_lo; l < next; ++l)
-        if (o < S.off[l] + tsv_size(l) && S.off[l] < o + sz) ok = false;
-      if (!ok) break;
-      S.off[next] = o;
-      head = o + sz;
-      ++next;
-    }
-    S.iss_hi[t] = next;
-    if (t < TSV_NSTAGE) {
-      // stage t must have been issued by now (the ring holds any single stage)
-      S.wait[t] = 2 * (next - (t + 1));
-    }
-  }
-  return S;
-}
-constexpr TsvSched TSV_SCHED = tsv_make_sched();
-static_assert(TSV_SCHED.iss_hi[TSV_NSTAGE] == TSV_NSTAGE, "tile solve: a stage was never issued");
-constexpr bool tsv_sched_ok() {
-  for (int s = 0; s < TSV_NSTAGE; ++s)
-    if (TSV_SCHED.iss_hi[s] < s + 1 || TSV_SCHED.wait[s] < 0 || TSV_SCHED.wait[s] > 62) return false;   // issued before it is awaited
-  return true;
-}
-static_assert(tsv_sched_ok(), "tile solve: broken stage schedule");
-
-struct TileSolveArgs {
-  double* P;
-  int64_t ld;
-  const double* linv;                        // 128 x 128, column-major, ld 128, zeros above the diagonal
-  const double* L;                           // 128 x 128 diagonal tile of the factor, zeros above the diagonal
-  int64_t ldl;
-};
-
-template <int N>
-__device__ __forceinline__ void lds_wait_n() {
-  static_assert(N >= 0 && N <= 15, "lgkmcnt field");
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <int N>
-__device__ __forceinline__ void vm_wait_n() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// Workgroup barrier WITHOUT the fence of __syncthreads(): hipcc turns that fence into s_waitcnt vmcnt(0) whenever
-// LDS-DMA is in flight (a DMA writes LDS), which would serialise the stage prefetch.  What a barrier of this
-// kernel needs is waited for explicitly: the wave's own LDS reads / writes (lgkmcnt) here, its DMA pieces of the
-// stage about to be read by the counted vmcnt wait in front of it.
-#define TSV_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <bool KFAST>
-__global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* xa = smem;
-  double* ring = smem + TSV_XA;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wu >> 2, s4 = wu & 3;
-  const int cc = rg ? 3 - s4 : s4;
-  const int li = lane & 15, lj = lane >> 4;
-  const int64_t i0 = (int64_t)blockIdx.x * TSV_ROWS + rg * 16 + li;      // this lane's row
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
-
-  // stage s of the factor stream: product s / 8 (0, 2: Linv^T; 1: L^T); element (k, c) of M^T is M[c + k ldm]:
-  // one k-row from column 16 kt on = up to 128 contiguous doubles = one DMA wave instruction (lanes beyond the
-  // row are masked off), two rows per wave
-  auto issue = [&](auto S_) {
-    constexpr int s = decltype(S_)::value;
-    constexpr int p = s / 8, kt = s % 8, len = 128 - 16 * kt, stride = tsv_stride(s);
-    const double* M = (p == 1) ? g.L : g.linv;
-    const int64_t ldm = (p == 1) ? g.ldl : (int64_t)TILE;
-    double* sb = ring + TSV_SCHED.off[s];
-    if (2 * lane < len) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = 2 * wu + h;
-        const char* ub = reinterpret_cast<const char*>(M + 16 * kt + ((int64_t)kt * 16 + r) * ldm);
-        __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + r * stride), 16, 0, 0);
-      }
-    }
-  };
-  // own fragments of A (fragment u = cc + 4 q: element (row, column 4u + lj)); loaded BEFORE the first factor
-  // stages are requested: vector-memory operations return in order, so the wait for these fragments must not
-  // include the stages
-  double a[8], x[8];
-  double* const pbase = KFAST ? g.P + i0 * g.ld + (4 * cc + lj) : g.P + i0 + (int64_t)(4 * cc + lj) * g.ld;
-  const int64_t pstep = KFAST ? 16 : 16 * g.ld;                            // fragment q -> q + 1: 16 columns on
-#pragma unroll
-  for (int q = 0; q < 8; ++q) a[q] = pbase[q * pstep];
-  asm volatile("" ::: "memory");
-  issue(std::integral_constant<int, 0>{});        // full rows: no lane mask, no branch
-  double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;            // fragment q of this wave: xown[q * 256]
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    xown[q * 256] = a[q];
-    x[q] = 0.0;
-  }
-  // (behind the use of a[]: hipcc waits vmcnt(0) at the first use of a loaded value that follows a lane-masked
-  //  branch, i.e. it would wait for these stages too)
-  asm volatile("" ::: "memory");
-  static_for<1, TSV_SCHED.iss_hi[0]>(issue);
-  const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
-  const unsigned nlane = lds_base + 8u * (unsigned)(TSV_XA + lj * 136 + (lane & 3) + 4 * cc);
-  const unsigned lj128 = (unsigned)lj * 128u;                              // bytes a row stride shrinks per kt, times lj
-
-  // dst[q] += sum over k-steps g <= u of (operand fragment g from xa) x (factor fragment (g, u)), u = cc + 4 q
-  auto run_product = [&](auto P_, double(&dst)[8]) {
-    constexpr int prod = decltype(P_)::value;
-    static_for<0, 8>([&](auto KT_) {
-      constexpr int kt = decltype(KT_)::value;
-      constexpr int s = prod * 8 + kt;
-      constexpr int stride = tsv_stride(s);
-      vm_wait_n<TSV_SCHED.wait[s]>();      // this wave's DMA pieces of stage s have landed ...
-      TSV_BARRIER();                     // ... everybody's have, stage s - 1 is consumed, xa of this product is written
-      static_for<TSV_SCHED.iss_lo[s + 1], TSV_SCHED.iss_hi[s + 1]>(issue);
-      const unsigned aN = nlane + (unsigned)TSV_SCHED.off[s] * 8u - (unsigned)kt * lj128;
-      double mf[2], nf[2][8];
-      asm volatile("" ::: "memory");
-      mf[0] = lds_read_async<(4 * kt) * 64>(mlane);
-      static_for<kt, 8>([&](auto Q_) {
-        constexpr int q = decltype(Q_)::value;
-        nf[0][q] = lds_read_async<16 * (q - kt)>(aN);
-      });
-      static_for<0, 4>([&](auto K_) {
-        constexpr int ks = decltype(K_)::value;
-        if constexpr (ks + 1 < 4) {
-          mf[(ks + 1) & 1] = lds_read_async<(4 * kt + ks + 1) * 64>(mlane);
-          static_for<kt, 8>([&](auto Q_) {
-            constexpr int q = decltype(Q_)::value;
-            nf[(ks + 1) & 1][q] = lds_read_async<(ks + 1) * 4 * stride + 16 * (q - kt)>(aN);
-          });
-          lds_wait_n<9 - kt>();
-        } else {
-          lds_wait_n<0>();
-        }
-        static_for<kt, 8>([&](auto Q_) {
-          constexpr int q = decltype(Q_)::value;
-          dst[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(nf[ks & 1][q], mf[ks & 1], dst[q], 0, 0, 0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-  };
-
-  run_product(std::integral_constant<int, 0>{}, x);          // x = X0 = A Linv^T
-  TSV_BARRIER();                                            // nobody reads the fragments of A any more
-#pragma unroll
-  for (int q = 0; q < 8; ++q) xown[q * 256] = -x[q];
-  run_product(std::integral_constant<int, 1>{}, a);          // a = R = A - X0 L^T
-  TSV_BARRIER();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) xown[q * 256] = a[q];
-  run_product(std::integral_constant<int, 2>{}, x);          // x = X0 + R Linv^T
-  // in place: this workgroup read exactly the 32 rows it overwrites, all of them before the first barrier
-#pragma unroll
-  for (int q = 0; q < 8; ++q) pbase[q * pstep] = x[q];
-}
-
-// =========================================================================================
-// Forward substitution of a WHOLE PANEL of the factor in ONE launch:  V[panel rows, cols] <- L_KK^{-1} V, with
-// L_KK the NT x NT tile diagonal block (NT <= 4: a 512-panel).  The columns of a right-hand side are independent,
-// so a workgroup that owns 32 of them can run the entire panel chain for them without ever meeting another
-// workgroup: NT refined tile solves (the three products of tile_solve_kernel each) with the rank-128 updates of the
-// panel rows below in between -- round 1 / the per-tile path launch {tile solve, update} NT times, 2 NT dependent
-// launches of ~16 + 12 us.  Same machinery as tile_solve_kernel<true> (X = V^T: element (i = column, c = panel row) at
-// V[c + i ldv]; fragments, xa image, LDS-DMA ring with a compile-time schedule); the chain is a static sequence of
-// products, 8 stages each:
-//     for j < NT:   x  = A_j Linv_j^T        (kind 0, triangular: stage kt feeds fragments u >= 4 kt)
-//                   A_j -= x L_jj^T          (kind 1, triangular)      -> residual
-//                   x += A_j Linv_j^T        (kind 2, triangular)      -> X_j
-//                   A_i -= X_j L_ij^T, i > j (kind 3, full tile)
-// with the fragments of all NT tiles of the panel in registers (8 NT doubles per lane).
-// =========================================================================================
-constexpr int psv_nprod(int NT) { return 3 * NT + NT * (NT - 1) / 2; }
-struct PsvProd { int kind, j, i; };
-constexpr PsvProd psv_prod(int NT, int p) {
-  int q = 0;
-  for (int j = 0; j < NT; ++j) {
-    for (int k = 0; k < 3; ++k, ++q)
-      if (q == p) return {k, j, j};
-    for (int i = j + 1; i < NT; ++i, ++q)
-      if (q == p) return {3, j, i};
-  }
-  return {-1, 0, 0};
-}
-constexpr int psv_first_prod(int NT, int j) {          // index of product (kind 0, j)
-  int q = 0;
-  for (int jj = 0; jj < j; ++jj) q += 3 + (NT - 1 - jj);
-  return q;
-}
-template <int NT> constexpr bool psv_tri(int s) { return psv_prod(NT, s / 8).kind != 3; }
-template <int NT> constexpr int psv_stride(int s) { return psv_tri<NT>(s) ? 136 - 16 * (s % 8) : 136; }
-template <int NT> constexpr int psv_size(int s) { return 16 * psv_stride<NT>(s); }
-template <int NT>
-struct PsvSched {
-  static constexpr int NS = 8 * psv_nprod(NT);
-  int off[NS] = {};
-  int iss_lo[NS + 1] = {};
-  int iss_hi[NS + 1] = {};
-  int wait[NS] = {};
-};
-template <int NT>
-constexpr PsvSched<NT> psv_make_sched(int dma_per_stage) {          // same placement rule as tsv_make_sched
-  PsvSched<NT> S;
-  constexpr int NS = PsvSched<NT>::NS;
-  int next = 0, head = 0;
-  for (int t = 0; t <= NS; ++t) {
-    const int live_lo = t == 0 ? 0 : t - 1;
-    S.iss_lo[t] = next;
-    while (next < NS) {
-      const int sz = psv_size<NT>(next);
-      int o = head;
-      if (o + sz > TSV_RING) o = 0;
-      bool ok = true;
-      for (int l = live_lo; l < next; ++l)
-        if (o < S.off[l] + psv_size<NT>(l) && S.off[l] < o + sz) ok = false;
-      if (!ok) break;
-      S.off[next] = o;
-      head = o + sz;
-      ++next;
-    }
-    S.iss_hi[t] = next;
-    if (t < NS) S.wait[t] = dma_per_stage * (next - (t + 1));
-  }
-  return S;
-}
-template <int NT, int RG>
-constexpr bool psv_sched_ok() {
-  constexpr PsvSched<NT> S = psv_make_sched<NT>(4 / RG);
-  if (S.iss_hi[PsvSched<NT>::NS] != PsvSched<NT>::NS) return false;
-  for (int s = 0; s < PsvSched<NT>::NS; ++s)
-    if (S.iss_hi[s] < s + 1 || S.wait[s] < 0 || S.wait[s] > 62) return false;
-  return true;
-}
-
-struct PanelSolveArgs {
-  double* V;                 // top row of the panel: NT * 128 rows x all columns, column-major, leading dimension ldv
-  int64_t ldv;
-  const double* linv;        // tile inverses of the panel's NT diagonal tiles, contiguous (128 x 128 each, ld 128)
-  const double* L;           // the panel's diagonal block of the factor (NT x NT tiles), leading dimension ldl
-  int64_t ldl;
-};
-
-// RG = 16-column groups per workgroup (2: eight waves, 32 columns; 1: four waves, 16 columns -- half the matrix work per
-// workgroup on twice as many, for right-hand-side blocks that would not fill the chip otherwise)
-template <int NT, int RG>
-__global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs g) {
-  static_assert(psv_sched_ok<NT, RG>(), "panel solve: broken stage schedule");
-  constexpr PsvSched<NT> SCH = psv_make_sched<NT>(4 / RG);
-  constexpr int XA = RG * 32 * 64;                       // doubles of the fragment image
-  constexpr int NS = PsvSched<NT>::NS;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* xa = smem;
-  double* ring = smem + XA;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wu >> 2, s4 = wu & 3;
-  const int cc = rg ? 3 - s4 : s4;
-  const int li = lane & 15, lj = lane >> 4;
-  const int64_t i0 = (int64_t)blockIdx.x * (16 * RG) + rg * 16 + li;      // this lane's right-hand-side column
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
-
-  auto issue = [&](auto S_) {
-    constexpr int s = decltype(S_)::value;
-    constexpr PsvProd pd = psv_prod(NT, s / 8);
-    constexpr int kt = s % 8, stride = psv_stride<NT>(s);
-    constexpr bool tri = pd.kind != 3;
-    constexpr int len = tri ? 128 - 16 * kt : 128, col0 = tri ? 16 * kt : 0;
-    // element (k, c) of M^T is M[c + k ldm]
-    const double* M = (pd.kind == 0 || pd.kind == 2) ? g.linv + (int64_t)pd.j * TILE * TILE
-                                                      : g.L + (int64_t)pd.i * TILE + (int64_t)pd.j * TILE * g.ldl;
-    const int64_t ldm = (pd.kind == 0 || pd.kind == 2) ? (int64_t)TILE : g.ldl;
-    double* sb = ring + SCH.off[s];
-    if (2 * lane < len) {
-#pragma unroll
-      for (int h = 0; h < 4 / RG; ++h) {
-        const int r = (4 / RG) * wu + h;
-        const char* ub = reinterpret_cast<const char*>(M + col0 + ((int64_t)kt * 16 + r) * ldm);
-        __builtin_amdgcn_global_load_lds((gptr_t)(ub + (unsigned)lane * 16u), (lptr_t)(sb + r * stride), 16, 0, 0);
-      }
-    }
-  };
-
-  // fragments of the NT tiles of the panel: fragment (t, q) = element (column i0, panel row 128 t + 4 (cc + 4 q) + lj)
-  double a[NT][8], x[8];
-  double* const pbase = g.V + i0 * g.ldv + (4 * cc + lj);
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a[t][q] = pbase[t * TILE + q * 16];
-  asm volatile("" ::: "memory");
-  issue(std::integral_constant<int, 0>{});
-  double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) xown[q * 256] = a[0][q];
-  asm volatile("" ::: "memory");
-  static_for<1, SCH.iss_hi[0]>(issue);
-  const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
-  const unsigned nlane = lds_base + 8u * (unsigned)(XA + lj * 136 + (lane & 3) + 4 * cc);
-  const unsigned lj128 = (unsigned)lj * 128u;
-
-  // dst[q] += sum over the k-steps of (operand fragment from xa) x (factor fragment), product P of the chain
-  auto run_product = [&](auto P_, double(&dst)[8]) {
-    constexpr int prod = decltype(P_)::value;
-    constexpr bool tri = psv_prod(NT, prod).kind != 3;
-    static_for<0, 8>([&](auto KT_) {
-      constexpr int kt = decltype(KT_)::value;
-      constexpr int s = prod * 8 + kt;
-      constexpr int stride = psv_stride<NT>(s);
-      constexpr int q0 = tri ? kt : 0;                       // first fragment this stage feeds
-      vm_wait_n<SCH.wait[s]>();
-      TSV_BARRIER();
-      static_for<SCH.iss_lo[s + 1], SCH.iss_hi[s + 1]>(issue);
-      const unsigned aN = nlane + (unsigned)SCH.off[s] * 8u - (tri ? (unsigned)kt * lj128 : 0u);
-      double mf[2], nf[2][8];
-      asm volatile("" ::: "memory");
-      mf[0] = lds_read_async<(4 * kt) * 64>(mlane);
-      static_for<q0, 8>([&](auto Q_) {
-        constexpr int q = decltype(Q_)::value;
-        nf[0][q] = lds_read_async<16 * (q - q0)>(aN);
-      });
-      static_for<0, 4>([&](auto K_) {
-        constexpr int ks = decltype(K_)::value;
-        if constexpr (ks + 1 < 4) {
-          mf[(ks + 1) & 1] = lds_read_async<(4 * kt + ks + 1) * 64>(mlane);
-          static_for<q0, 8>([&](auto Q_) {
-            constexpr int q = decltype(Q_)::value;
-            nf[(ks + 1) & 1][q] = lds_read_async<(ks + 1) * 4 * stride + 16 * (q - q0)>(aN);
-          });
-          lds_wait_n<9 - q0>();
-        } else {
-          lds_wait_n<0>();
-        }
-        static_for<q0, 8>([&](auto Q_) {
-          constexpr int q = decltype(Q_)::value;
-          dst[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(nf[ks & 1][q], mf[ks & 1], dst[q], 0, 0, 0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-  };
-
-  static_for<0, NT>([&](auto J_) {
-    constexpr int j = decltype(J_)::value;
-    constexpr int p0 = psv_first_prod(NT, j);
-    if constexpr (j > 0) {
-      TSV_BARRIER();                                           // the updates by X_{j-1} have read xa
-#pragma unroll
-      for (int q = 0; q < 8; ++q) xown[q * 256] = a[j][q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) x[q] = 0.0;
-    run_product(std::integral_constant<int, p0>{}, x);         // x = X0 = A_j Linv_j^T
-    TSV_BARRIER();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) xown[q * 256] = -x[q];
-    run_product(std::integral_constant<int, p0 + 1>{}, a[j]);  // a_j = R = A_j - X0 L_jj^T
-    TSV_BARRIER();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) xown[q * 256] = a[j][q];
-    run_product(std::integral_constant<int, p0 + 2>{}, x);     // x = X_j
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a[j][q] = x[q];
-    if constexpr (j + 1 < NT) {
-      TSV_BARRIER();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) xown[q * 256] = -x[q];
-      static_for<j + 1, NT>([&](auto I_) {
-        constexpr int i = decltype(I_)::value;
-        run_product(std::integral_constant<int, p0 + 3 + (i - j - 1)>{}, a[i]);   // A_i -= X_j L_ij^T
-      });
-    }
-  });
-  // in place: this workgroup read exactly the 32 columns of the panel it overwrites, all of them before the first barrier
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) pbase[t * TILE + q * 16] = a[t][q];
-  (void)NS;
-}
-
-template <int NT, int RG>
-static int launch_panel_solve_rg(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
-  const size_t shmem = (size_t)(RG * 32 * 64 + TSV_RING) * sizeof(double);
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG>), shmem));
-  hipLaunchKernelGGL((panel_solve_kernel<NT, RG>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
-  LPGP_HIP(hipGetLastError());
-  return 0;
-}
-template <int NT>
-static int launch_panel_solve_nt(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
-  // 16-column workgroups while that many do not exceed two per CU: half the chain time per panel
-  if (cols / 16 <= 2 * (int64_t)ctx->cus) return launch_panel_solve_rg<NT, 1>(ctx, stream, a, cols);
-  return launch_panel_solve_rg<NT, 2>(ctx, stream, a, cols);
-}
-
-// V (nt_rows <= 4 tiles of rows x nt_cols * 128 columns, column-major ldv) <- L_KK^{-1} V in place, L_KK the panel's diagonal block
-int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
-                      int nt_rows, int nt_cols, int prof_kernel) {
-  if (nt_cols <= 0 || nt_rows <= 0) return 0;
-  LPGP_CHECK(nt_rows <= 4, "panel solve: at most 4 tile rows per panel (got %d)", nt_rows);
-  PanelSolveArgs a;
-  a.V = V; a.ldv = ldv; a.linv = linv; a.L = L; a.ldl = ldl;
-  const int64_t cols = (int64_t)nt_cols * TILE;
-  // algorithmic flops of the triangular solve of the panel: cols x (nt_rows * 128)^2
-  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, (double)cols * (double)(nt_rows * TILE) * (double)(nt_rows * TILE), 0.0);
-  int rc;
-  switch (nt_rows) {
-    case 1: rc = launch_panel_solve_nt<1>(ctx, stream, a, cols); break;
-    case 2: rc = launch_panel_solve_nt<2>(ctx, stream, a, cols); break;
-    case 3: rc = launch_panel_solve_nt<3>(ctx, stream, a, cols); break;
-    default: rc = launch_panel_solve_nt<4>(ctx, stream, a, cols); break;
-  }
-  if (prof_kernel >= 0) prof_end(ctx, stream);
-  return rc;
-}
-
-template <bool KFAST>
-static int launch_tile_solve(lpgp_ctx* ctx, hipStream_t stream, double* P, int64_t ld, const double* linv, const double* L,
-                             int64_t ldl, int64_t rows, int prof_kernel) {
-  if (rows <= 0) return 0;
-  const size_t shmem = (size_t)(TSV_XA + TSV_RING) * sizeof(double);   // 86 016 B
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&tile_solve_kernel<KFAST>), shmem));
-  TileSolveArgs a;
-  a.P = P; a.ld = ld; a.linv = linv; a.L = L; a.ldl = ldl;
-  // algorithmic flops: the triangular solve itself (rows x 128^2), not the three products that form it
-  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, (double)rows * TILE * TILE, 0.0);
-  hipLaunchKernelGGL(tile_solve_kernel<KFAST>, dim3((unsigned)(rows / TSV_ROWS)), dim3(512), shmem, stream, a);
-  if (prof_kernel >= 0) prof_end(ctx, stream);
-  LPGP_HIP(hipGetLastError());
-  return 0;
-}
-
-// X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place
-int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
-                     int mt, int prof_kernel) {
-  return launch_tile_solve<false>(ctx, stream, X, ldx, linv, L, ldl, (int64_t)mt * TILE, prof_kernel);
-}
-
-// V (128 rows x nt*128 columns, column-major ldv) <- L^{-1} V in place
-int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
-                     int nt, int prof_kernel) {
-  return launch_tile_solve<true>(ctx, stream, V, ldv, linv, L, ldl, (int64_t)nt * TILE, prof_kernel);
 }
 
 template <bool TA, bool TB, int TRI>
