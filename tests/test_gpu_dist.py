@@ -120,3 +120,74 @@ def _run_ranks(world, grid, workload, nb, port):
 ])
 def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port)
+
+
+CHAIN = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine
+from oracle import covfuncs as ocf, gp as ogp
+comm = _dist.Comm.from_env()
+ctx = _engine.default_context()
+ctx.set_option("nb", 128)
+ctx.dist_init(comm, transport="host", grid=%(grid)r)
+cf = lp.randprocs.covfuncs
+okern, ident = [(1.0, [("expquad", 1.0)])], ocf.identity(1)
+prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+rng = np.random.default_rng(3)
+X1, Y1 = rng.uniform(-1, 1, (300, 1)), rng.normal(size=300)          # three blocks of 128 over the ranks
+X2, Y2 = np.array([[0.31], [-0.62]]), np.array([0.1, 0.2])
+noise = lp.randvars.Normal(np.zeros(300), 1e-2 * np.eye(300))
+u1 = prior.condition_on_observations(Y1, X1, b=noise)
+p1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
+Xt = np.linspace(-1, 1, 9)[:, None]
+rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+# a failed conditioning (duplicated point, negative noise) raises on EVERY rank and is rolled back everywhere
+try:
+    u1.condition_on_observations(np.zeros(3), np.array([[0.2], [0.2], [0.5]]), b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+    raise SystemExit("not positive definite, but no LinAlgError")
+except np.linalg.LinAlgError:
+    pass
+m, v = u1.predict(Xt)
+assert rel(m, p1.mean(Xt)) < 1e-8 and np.max(np.abs(v - p1.var(Xt))) < 1e-9
+u2 = u1.condition_on_observations(Y2, X2)
+p2 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2), ogp.ObsBlock(X2, ident, Y2)])
+m2, v2 = u2.predict(Xt)
+assert rel(m2, p2.mean(Xt)) < 1e-8 and np.max(np.abs(v2 - p2.var(Xt))) < 1e-9
+# the earlier posterior is still served (view on the leading blocks of the sharded factor), and the later one again
+m, v = u1.predict(Xt)
+assert rel(m, p1.mean(Xt)) < 1e-8 and np.max(np.abs(v - p1.var(Xt))) < 1e-9
+np.testing.assert_allclose(u1.representer_weights, p1.weights, rtol=1e-6, atol=1e-8)
+m2, v2 = u2.predict(Xt)
+assert rel(m2, p2.mean(Xt)) < 1e-8
+# a prediction set smaller than the job: every rank predicts all of it
+m3 = u2.mean(Xt[:1])
+assert abs(m3[0] - p2.mean(Xt[:1])[0]) < 1e-8
+print("CHAIN", comm.rank, "ok", flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("grid,port", [((2, 1), 29771), ((2, 2), 29781)])
+def test_multi_rank_views_rollback_and_small_prediction_sets(grid, port):
+    """On a sharded factor: a failed conditioning raises on every rank and is rolled back, an earlier posterior of the
+    chain keeps working after a later conditioning (view), prediction sets smaller than the job are not sharded."""
+    world = grid[0] * grid[1]
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
+    env.pop("LOCAL_RANK", None)
+    procs = [subprocess.Popen([sys.executable, "-c", CHAIN % {"root": ROOT, "grid": grid}], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
+        assert f"CHAIN {r} ok" in so
