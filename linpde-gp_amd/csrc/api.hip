@@ -374,6 +374,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_US_FIXED")) ctx->chain_us_fixed = std::atof(e);
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_GEMM_BAND")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ctx->gemm_band = v; }
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_big = v;

@@ -151,7 +151,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int v, int& tr, int&
 // hands a triangular super-tile on the diagonal -- 36 tiles -- to an XCD with 64 slots; measured
 // on SYRK n x n x 512: n = 16384 51.2 -> 51.9, 12288 48.1 -> 49.9, 6144 49.2 -> 51.0 TFLOP/s,
 // rectangular shapes unchanged; scratch/dense_ab.py.)
-constexpr int BAND = 8;
+constexpr int BAND = 8;                  // default band height (GemmArgs::band; LPGP_GEMM_BAND = 4 / 8 / 16 for the measurement in DESIGN.md §5)
 // Distributed trailing update (GemmArgs::cyc): number of valid local tile columns of local tile row r -- the
 // columns whose global tile index does not exceed the row's (non-decreasing in r: a staircase).
 __host__ __device__ __forceinline__ int stair_nc(const GemmArgs& g, int r) {
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr
   if (idx >= g.ntiles) return false;
   int b, j;
   if (!TRI) {
-    const int per = BAND * g.nt;
+    const int per = g.band * g.nt;
     b = idx / per;
     j = idx - b * per;
   } else {
@@ -206,8 +206,8 @@ __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr
     b = lo;
     j = idx - g.band_prefix[b];
   }
-  const int r0 = b * BAND;
-  const int R = (g.mt - r0 < BAND) ? g.mt - r0 : BAND;
+  const int r0 = b * g.band;
+  const int R = (g.mt - r0 < g.band) ? g.mt - r0 : g.band;
   int r, c;
   if (!TRI) {
     c = j / R;
@@ -600,15 +600,17 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   const size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>), shmem));
   GemmArgs ga = g;
-  if (ctx->dense_tiles && (g.mt + BAND - 1) / BAND <= GemmArgs::MAXB) {
+  const int BANDR = ctx->gemm_band;
+  ga.band = BANDR;
+  if (ctx->dense_tiles && (g.mt + BANDR - 1) / BANDR <= GemmArgs::MAXB) {
     ga.dense = 1;
-    ga.nbands = (g.mt + BAND - 1) / BAND;
+    ga.nbands = (g.mt + BANDR - 1) / BANDR;
     if (TRI) {
       LPGP_CHECK(g.cyc || g.mt >= g.nt, "gemm: triangular update needs mt >= nt");
       int acc = 0;
       for (int b = 0; b < ga.nbands; ++b) {
         ga.band_prefix[b] = acc;
-        const int r0 = b * BAND, R = std::min(BAND, g.mt - r0);
+        const int r0 = b * BANDR, R = std::min(BANDR, g.mt - r0);
         if (g.cyc) {
           acc += stair_band_count(g, r0, R);
         } else {

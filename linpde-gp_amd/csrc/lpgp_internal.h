@@ -104,6 +104,7 @@ struct lpgp_ctx {
   double chain_us_tile = 150.0, solve_chain_us_tile = 150.0, chain_us_fixed = 80.0;   // (re-swept after the tile solves got their refinement step: scratch/sweep_chain.sh)
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
+  int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
@@ -245,7 +246,7 @@ struct GemmArgs {
   int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm; legacy mapping)
   // dense tile enumeration (set by launch_gemm; map_tile_dense in gemm.hip)
   int32_t dense = 0;
-  int32_t ntiles = 0, chunk = 0, nbands = 0;
+  int32_t ntiles = 0, chunk = 0, nbands = 0, band = 8;
   static constexpr int MAXB = 192; // bands of 8 tile rows: 1536 tile rows = 196 608 matrix rows (> 288 GB of fp64)
   int32_t band_prefix[MAXB + 1];   // triangular shapes only: tiles before band b
   // distributed trailing update (cyc != 0, triangular shapes, dense enumeration): C is a region of this rank's
