@@ -169,23 +169,32 @@ def main():
         os.environ["LPGP_FORCE_RCCL"] = "1"
         ctx.dist_init(comm)
         dist_note = "single rank through the DISTRIBUTED code path (LPGP_BENCH_FORCE_DIST=1)"
+    transport = os.environ.get("LPGP_DIST_TRANSPORT", "rccl")
     if world > 1 and not replicas:
-        # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be
-        # created (on every rank alike), the run degrades to independent replicas and says so.
-        try:
-            # LPGP_DIST_TRANSPORT=host: bring-up on a box whose ranks share one GPU (panels staged
-            # through the host; never a benchmark configuration)
-            ctx.dist_init(comm, transport=os.environ.get("LPGP_DIST_TRANSPORT", "rccl"))
-            ok, err = True, ""
-        except Exception as exc:            # noqa: BLE001 (reported in the JSON line)
-            ok, err = False, f"{type(exc).__name__}: {exc}"
-        oks = comm.allgather((ok, err))
-        if not all(o for o, _ in oks):
+        # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be created (on every
+        # rank alike) the run falls back to the direct-peer transport (IPC-mapped windows, device-to-device pushes), and
+        # if that cannot be set up either, to independent replicas -- and says so.
+        # LPGP_DIST_TRANSPORT=ipc selects the direct-peer transport; =host: bring-up on a box whose ranks share one GPU
+        # (messages staged through the host; never a benchmark configuration)
+        for attempt in ([transport, "ipc"] if transport == "rccl" else [transport]):
+            try:
+                ctx.dist_init(comm, transport=attempt)
+                ok, err = True, ""
+            except Exception as exc:            # noqa: BLE001 (reported in the JSON line)
+                ok, err = False, f"{type(exc).__name__}: {exc}"
+            oks = comm.allgather((ok, err))
+            if all(o for o, _ in oks):
+                if attempt != transport:
+                    dist_note_fallback = f"RCCL communicator creation failed ({first_err[:160]}): direct-peer (IPC) transport instead"
+                    sys.stderr.write("bench.py: " + dist_note_fallback + "\n") if rank == 0 else None
+                transport = attempt
+                break
             if any(o for o, _ in oks):
-                raise SystemExit("RCCL communicator creation failed on some ranks only: "
-                                 + "; ".join(e for o, e in oks if not o))
+                raise SystemExit(f"{attempt} transport set up on some ranks only: " + "; ".join(e for o, e in oks if not o))
+            first_err = oks[0][1]
+        else:
             replicas = True
-            dist_note = "RCCL communicator creation failed (" + oks[0][1][:200] + "): independent replicas instead"
+            dist_note = "communicator creation failed (" + first_err[:200] + "): independent replicas instead"
             if rank == 0:
                 sys.stderr.write("bench.py: " + dist_note + "\n")
     info = ctx.device_info()
@@ -289,12 +298,13 @@ def main():
                           (dist_note or "independent replicas (one problem per GPU)") if replicas else
                           f"one problem, Gram matrix / factor sharded in 2-D block-cyclic tiles (blocks of 512) over a "
                           f"{ctx.grid[0]} x {ctx.grid[1]} process grid, "
-                          + ("HOST-STAGED panel exchange (bring-up transport, not a benchmark configuration)"
-                             if os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host" else
-                             "panel gather by grouped RCCL point-to-point sends")
+                          + {"host": "HOST-STAGED panel exchange (bring-up transport, not a benchmark configuration)",
+                             "ipc": "panel gather by direct-peer pushes into IPC-mapped windows (device-to-device copies, barriers over the control plane)",
+                             "rccl": "panel gather by grouped RCCL point-to-point sends"}[transport]
                           + ", prediction points sharded over the ranks, factor streamed for the solves"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
-            "rccl_ranks": 0 if (world == 1 or replicas or os.environ.get("LPGP_DIST_TRANSPORT", "rccl") == "host") else world,
+            "rccl_ranks": world if (world > 1 and not replicas and transport == "rccl") else 0,
+            "transport": None if (world == 1 or replicas) else transport,
             "process_grid": None if (world == 1 or replicas) else list(ctx.grid),
             "comm_per_rank_per_step": None if (world == 1 or replicas) else [
                 {"rank": r, "bytes_sent": row[0], "bytes_received": row[1], "seconds_in_comm": row[2] * 1e-3}

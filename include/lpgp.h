@@ -100,6 +100,18 @@ int  lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, 
  * selects it).                                                                                              */
 typedef int (*lpgp_host_exchange_fn)(void* user, int32_t op, void* buf, int64_t bytes, int32_t root);
 int  lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user);
+/* Direct-peer transport, the alternative to RCCL: every rank exports a receive window in its HBM
+ * (lpgp_dist_ipc_export: hipMalloc + hipIpcGetMemHandle, 64-byte handle out), the caller ships the handles (any control
+ * plane), lpgp_dist_init_ipc maps every peer's window (hipIpcOpenMemHandle; handles = world x 64 bytes, rank-major).
+ * A panel piece is then pushed by its root straight into the windows of all peers with device-to-device copies (one per
+ * peer, every xGMI link of the root busy at once) -- no ring, no staging through the host; only the barriers between
+ * the phases of an exchange (and the info all-reduce) use the caller's exchange (op 1 of lpgp_host_exchange_fn).
+ * Several ranks may share one GPU, so tests/test_gpu_dist.py runs multi-rank jobs with a real device data path on
+ * the single-GPU box.  Host-synchronous per exchange (the root drains its stream before the barrier): it does not
+ * overlap with the look-ahead the way the RCCL group does.                                                    */
+int  lpgp_dist_ipc_export(lpgp_ctx* ctx, int64_t window_bytes, char* handle64);
+int  lpgp_dist_init_ipc(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* handles,
+                        lpgp_host_exchange_fn fn, void* user);
 
 /* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) ----- */
 int  lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out);

@@ -407,6 +407,9 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   }
   (void)hipFree(ctx->d_info);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  for (size_t r = 0; r < ctx->ipc_peer.size(); ++r)
+    if ((int)r != ctx->rank && ctx->ipc_peer[r]) (void)hipIpcCloseMemHandle(ctx->ipc_peer[r]);
+  if (ctx->ipc_window) (void)hipFree(ctx->ipc_window);
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
   for (int i = 0; i < 2; ++i)
     if (ctx->d_panel[i]) (void)hipFree(ctx->d_panel[i]);
@@ -547,6 +550,50 @@ int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_ex
   LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init_host: already initialised");
   LPGP_CHECK(!ctx->grid_set || ctx->pr * ctx->pc == world, "lpgp_dist_init_host: grid %d x %d does not match %d ranks", ctx->pr, ctx->pc, world);
   ctx->host_xfer = fn;
+  ctx->host_xfer_user = user;
+  ctx->rank = rank;
+  ctx->world = world;
+  choose_grid(ctx, world);
+  return 0;
+}
+
+int lpgp_dist_ipc_export(lpgp_ctx* ctx, int64_t window_bytes, char* handle64) {
+  LPGP_CHECK(ctx && handle64 && window_bytes >= (int64_t)(1 << 20), "lpgp_dist_ipc_export: bad argument (window of at least 1 MiB)");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed() && !ctx->ipc_window, "lpgp_dist_ipc_export: already initialised");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+  const size_t doubles = (size_t)window_bytes / sizeof(double);
+  LPGP_HIP(hipMalloc(&ctx->ipc_window, doubles * sizeof(double)));
+  ctx->ipc_window_doubles = doubles;
+  hipIpcMemHandle_t h;
+  LPGP_HIP(hipIpcGetMemHandle(&h, ctx->ipc_window));
+  std::memcpy(handle64, &h, 64);
+  return 0;
+}
+
+int lpgp_dist_init_ipc(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* handles, lpgp_host_exchange_fn fn, void* user) {
+  LPGP_CHECK(ctx && handles && fn && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init_ipc: bad argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed() && ctx->ipc_window, "lpgp_dist_init_ipc: call lpgp_dist_ipc_export first (once)");
+  LPGP_CHECK(!ctx->grid_set || ctx->pr * ctx->pc == world, "lpgp_dist_init_ipc: grid %d x %d does not match %d ranks", ctx->pr, ctx->pc, world);
+  ctx->ipc_peer.assign((size_t)world, nullptr);
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) {
+      ctx->ipc_peer[r] = ctx->ipc_window;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + (size_t)r * 64, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      set_error("lpgp_dist_init_ipc: hipIpcOpenMemHandle for the window of rank %d: %s", r, hipGetErrorString(e));
+      ctx->ipc_peer.clear();
+      return -1;
+    }
+    ctx->ipc_peer[r] = (double*)p;
+  }
+  ctx->host_xfer = fn;                 // barriers and the info all-reduce travel over the caller's control plane
   ctx->host_xfer_user = user;
   ctx->rank = rank;
   ctx->world = world;

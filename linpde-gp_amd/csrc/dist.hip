@@ -81,7 +81,69 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
   ctx->comm_bytes_sent += sent;
   ctx->comm_bytes_recv += recv;
   prof_begin(ctx, st, LPGP_K_COMM, 0.0, sent + recv);
-  if (ctx->host_xfer) {
+  if (ctx->ipc()) {
+    // direct-peer transport.  The pieces of one exchange are laid out back to back in every rank's window (same
+    // offsets everywhere); an exchange that does not fit is cut into rounds.  Per round:
+    //   barrier A  every rank has copied the previous round out of its window (its stream is drained first)
+    //   push       each root copies its pieces into the window of every peer, device to device, and drains its stream
+    //   barrier B  all pushes have landed
+    //   copy out   window -> destination buffers, asynchronously on `st`
+    auto barrier = [&]() -> int {
+      int v = 0;
+      LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, &v, (int64_t)sizeof(int), 0) == 0, "ipc transport: barrier failed");
+      return 0;
+    };
+    size_t i = 0;
+    while (i < pieces.size()) {
+      // one round: pieces [i, j) (a piece larger than the window travels in slices)
+      size_t used = 0, j = i;
+      std::vector<size_t> offs;
+      while (j < pieces.size() && used + pieces[j].count <= ctx->ipc_window_doubles) {
+        offs.push_back(used);
+        used += pieces[j].count;
+        ++j;
+      }
+      if (j == i) {
+        // a single piece exceeds the window: slices of the window's size
+        const Piece& p = pieces[i];
+        for (size_t o = 0; o < p.count; o += ctx->ipc_window_doubles) {
+          const size_t n = std::min(ctx->ipc_window_doubles, p.count - o);
+          LPGP_HIP(hipStreamSynchronize(st));
+          LPGP_TRY(barrier());
+          if (p.root == ctx->rank) {
+            for (int peer = 0; peer < ctx->world; ++peer)
+              if (peer != ctx->rank)
+                LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer], p.buf + o, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            LPGP_HIP(hipStreamSynchronize(st));
+          }
+          LPGP_TRY(barrier());
+          if (p.root != ctx->rank)
+            LPGP_HIP(hipMemcpyAsync(p.buf + o, ctx->ipc_window, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        ++i;
+        continue;
+      }
+      LPGP_HIP(hipStreamSynchronize(st));
+      LPGP_TRY(barrier());
+      bool pushed = false;
+      for (size_t q = i; q < j; ++q) {
+        const Piece& p = pieces[q];
+        if (p.count == 0 || p.root != ctx->rank) continue;
+        for (int peer = 0; peer < ctx->world; ++peer)
+          if (peer != ctx->rank)
+            LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer] + offs[q - i], p.buf, p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
+        pushed = true;
+      }
+      if (pushed) LPGP_HIP(hipStreamSynchronize(st));
+      LPGP_TRY(barrier());
+      for (size_t q = i; q < j; ++q) {
+        const Piece& p = pieces[q];
+        if (p.count == 0 || p.root == ctx->rank) continue;
+        LPGP_HIP(hipMemcpyAsync(p.buf, ctx->ipc_window + offs[q - i], p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
+      }
+      i = j;
+    }
+  } else if (ctx->host_xfer) {
     // bring-up / test transport: every piece staged through the host and broadcast by the caller's exchange
     std::vector<double> stage;
     for (const auto& p : pieces) {
@@ -122,7 +184,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
 
 static int allreduce_max_int(lpgp_ctx* ctx, hipStream_t st, int* h_value) {
   if (ctx->world <= 1) return 0;
-  if (ctx->host_xfer) {
+  if (ctx->host_xfer) {     // host and direct-peer transports: the control-plane exchange
     LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, h_value, (int64_t)sizeof(int), 0) == 0, "host exchange: all-reduce failed");
     return 0;
   }

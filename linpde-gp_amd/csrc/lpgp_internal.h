@@ -133,6 +133,13 @@ struct lpgp_ctx {
   void* nccl_comm = nullptr;       // ncclComm_t
   lpgp_host_exchange_fn host_xfer = nullptr;   // test transport (lpgp_dist_init_host): panels staged through the host
   void* host_xfer_user = nullptr;
+  // direct-peer transport (lpgp_dist_init_ipc): every rank owns a receive window in HBM, mapped into every peer by
+  // IPC handle; a root pushes its pieces straight into the peers' windows (device-to-device copies over xGMI / inside
+  // the GPU), the host exchange above only carries the barriers between the phases of an exchange
+  double* ipc_window = nullptr;               // this rank's window
+  size_t ipc_window_doubles = 0;
+  std::vector<double*> ipc_peer;              // window of rank r as mapped here (own window for r == rank)
+  bool ipc() const { return !ipc_peer.empty(); }
   bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr || dist_broken; }
   double* d_pack = nullptr;        // packed panel pieces: [own piece | pieces received from the other sources]
   size_t pack_cap = 0;             // doubles

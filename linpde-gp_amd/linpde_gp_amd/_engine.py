@@ -31,11 +31,13 @@ class Context:
         `grid` = (Pr, Pc) process grid of the 2-D block-cyclic tile distribution (rank = r * Pc + c); default:
         $LPGP_GRID ("2x4") or the library's choice (Pr = world, Pc = 1, see lpgp.h).
         transport "rccl" (the product path): rank 0 creates the RCCL unique id, everybody receives it, then
-        `ncclCommInitRank`; panels travel as grouped point-to-point sends over xGMI.  transport "host"
+        `ncclCommInitRank`; panels travel as grouped point-to-point sends over xGMI.  transport "ipc": direct-peer
+        pushes into IPC-mapped receive windows (device-to-device copies, barriers over the control plane; several ranks
+        may share one GPU).  transport "host"
         (bring-up / tests): the same messages staged through the host and exchanged over the control plane, so
         that several ranks may share one GPU.  From here on every call on a `GramMatrix` is collective."""
-        if transport not in ("rccl", "host"):
-            raise ValueError("transport must be 'rccl' or 'host'")
+        if transport not in ("rccl", "host", "ipc"):
+            raise ValueError("transport must be 'rccl', 'ipc' or 'host'")
         if comm.world == 1 and not os.environ.get("LPGP_FORCE_RCCL") and transport == "rccl":
             self.comm = comm
             return
@@ -46,7 +48,7 @@ class Context:
             if grid[0] * grid[1] != comm.world:
                 raise ValueError(f"grid {grid[0]} x {grid[1]} does not match {comm.world} ranks")
             check(lib.lpgp_dist_set_grid(self._h, int(grid[0]), int(grid[1])), "lpgp_dist_set_grid")
-        if transport == "host":
+        if transport in ("host", "ipc"):
             def exchange(_user, op, buf, nbytes, root):
                 try:
                     view = (C.c_char * nbytes).from_address(buf)
@@ -61,8 +63,24 @@ class Context:
                 except Exception:  # noqa: BLE001 (reported through the C return code)
                     return 1
             self._host_exchange = _lib.HOST_EXCHANGE_FN(exchange)      # keep the callback alive
-            check(lib.lpgp_dist_init_host(self._h, comm.rank, comm.world, self._host_exchange, None),
-                  "lpgp_dist_init_host")
+            if transport == "ipc":
+                # direct-peer transport: export this rank's receive window, gather everybody's handle, map the peers'
+                # windows; panel pieces then travel device to device, the control plane only carries barriers
+                handle = C.create_string_buffer(64)
+                window = int(os.environ.get("LPGP_IPC_WINDOW_MB", "512")) << 20
+                rc = lib.lpgp_dist_ipc_export(self._h, window, handle)
+                err = "" if rc == 0 else lib.lpgp_last_error().decode(errors="replace")
+                got = comm.allgather((rc == 0, err, handle.raw))
+                if not all(g[0] for g in got):
+                    raise _lib.LpgpError("lpgp_dist_ipc_export failed: " + "; ".join(f"rank {r}: {g[1]}" for r, g in enumerate(got) if not g[0]))
+                rc = lib.lpgp_dist_init_ipc(self._h, comm.rank, comm.world, b"".join(g[2] for g in got), self._host_exchange, None)
+                err = "" if rc == 0 else lib.lpgp_last_error().decode(errors="replace")
+                res = comm.allgather((rc == 0, err))
+                if not all(o for o, _ in res):
+                    raise _lib.LpgpError("lpgp_dist_init_ipc failed: " + "; ".join(f"rank {r}: {e}" for r, (o, e) in enumerate(res) if not o))
+            else:
+                check(lib.lpgp_dist_init_host(self._h, comm.rank, comm.world, self._host_exchange, None),
+                      "lpgp_dist_init_host")
             self.rank, self.world, self.comm = comm.rank, comm.world, comm
             return
         # every rank leaves the bring-up in step, also when it fails: rank 0 broadcasts (ok, id-or-error), and the

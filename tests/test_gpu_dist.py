@@ -65,7 +65,7 @@ from oracle import workloads as owl
 comm = _dist.Comm.from_env()
 ctx = _engine.default_context()            # LPGP_DEVICE=0 on every rank: the ranks share the GPU
 ctx.set_option("nb", %(nb)d)
-ctx.dist_init(comm, transport="host", grid=%(grid)r)
+ctx.dist_init(comm, transport=%(transport)r, grid=%(grid)r)
 assert ctx.world == comm.world and ctx.rank == comm.rank and ctx.grid == %(grid)r
 wl = problems.%(workload)s
 u, mean, var = problems.condition_and_predict(wl)
@@ -91,10 +91,13 @@ comm.close()
 """
 
 
-def _run_ranks(world, grid, workload, nb, port):
+def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None):
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
     env.pop("LOCAL_RANK", None)
-    procs = [subprocess.Popen([sys.executable, "-c", MULTI % {"root": ROOT, "workload": workload, "nb": nb, "grid": grid}],
+    if window_mb is not None:
+        env["LPGP_IPC_WINDOW_MB"] = str(window_mb)
+    procs = [subprocess.Popen([sys.executable, "-c", MULTI % {"root": ROOT, "workload": workload, "nb": nb, "grid": grid,
+                                                              "transport": transport}],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     outs = []
@@ -120,6 +123,18 @@ def _run_ranks(world, grid, workload, nb, port):
 ])
 def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port)
+
+
+@pytest.mark.parametrize("grid,workload,nb,port,window_mb", [
+    ((2, 1), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 512, 29911, 64),     # a panel fits the window: one round per exchange
+    ((2, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 29921, 1),      # 1-MiB windows: pieces travel in slices
+    ((3, 1), "heat_1d(nt=40, nx=24, m_side=8)", 256, 29931, 2),
+])
+def test_multi_rank_on_one_gpu_direct_peer_transport(grid, workload, nb, port, window_mb):
+    """The same jobs with the DIRECT-PEER transport (`lpgp_dist_init_ipc`): panel pieces pushed device to device into
+    IPC-mapped receive windows of the peers -- the data path of a multi-GPU node without RCCL, here between processes
+    that share the one GPU; the control plane only carries barriers."""
+    _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="ipc", window_mb=window_mb)
 
 
 CHAIN = r"""
