@@ -281,7 +281,9 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak" if ((replicas or weak) and world > 1) else "strong",
+        # the N = 1, 2, 4, 8 series of the default mode grows the problem with N (flops per GPU fixed): weak scaling, and the
+        # N = 1 line is the first point of that series; "strong" only for LPGP_BENCH_STRONG=1 / an explicit --n-side
+        "scaling": "strong" if (strong or (world > 1 and not replicas and not weak)) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
