@@ -369,9 +369,10 @@ class ConditionalGaussianProcess(GaussianProcess):
     def predict(self, x, *, return_var: bool = True):
         """Posterior mean and marginal variance at `x` in one pass over the factor.
 
-        In a multi-GPU job every rank holds the full factor, so the prediction points are
-        simply sharded over the ranks (contiguous slices) and the results gathered over the
-        control plane; every rank returns the full arrays."""
+        In a multi-GPU job the prediction points are sharded over the ranks (contiguous slices): every rank
+        solves for its own columns of the cross-covariance while the sharded factor is streamed past it panel by
+        panel (`trsm_lower_dist`), and the results are gathered over the control plane; every rank returns the
+        full arrays.  Collective: every rank calls it with the same `x`."""
         self._check_current()
         X, batch = self._flat(x)
         ctx = self._state.ctx
