@@ -145,7 +145,10 @@ def dumps(obj) -> bytes:
 
 
 def loads(blob) -> object:
-    obj, pos = _decode(memoryview(blob))
+    try:
+        obj, pos = _decode(memoryview(blob))
+    except (struct.error, OverflowError, MemoryError, RecursionError) as exc:     # malformed input never escapes as anything else
+        raise ValueError(f"control plane: malformed message ({type(exc).__name__})") from None
     if pos != len(blob):
         raise ValueError("control plane: trailing bytes")
     return obj

@@ -427,3 +427,43 @@ def _wait_port(port, timeout=20.0):
         except OSError:
             time.sleep(0.05)
     return False
+
+
+def test_wire_format_round_trip_property():
+    """Any tree of the carried types survives dumps / loads unchanged, and no prefix / corruption of a valid message
+    makes `loads` do anything but return or raise ValueError (hypothesis)."""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+    _dist = _load_dist()
+    leaves = st.one_of(st.none(), st.booleans(), st.integers(-2**63, 2**63 - 1), st.floats(allow_nan=False), st.text(max_size=20),
+                       st.binary(max_size=40),
+                       hnp.arrays(np.float64, hnp.array_shapes(max_dims=3, max_side=4), elements=st.floats(-1e6, 1e6)),
+                       hnp.arrays(np.int64, hnp.array_shapes(max_dims=2, max_side=4), elements=st.integers(-10**9, 10**9)))
+    trees = st.recursive(leaves, lambda ch: st.one_of(st.lists(ch, max_size=4), st.lists(ch, max_size=4).map(tuple),
+                                                      st.dictionaries(st.one_of(st.text(max_size=5), st.integers(-100, 100)), ch, max_size=3)),
+                         max_leaves=12)
+
+    def same(a, b):
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+        if isinstance(a, (list, tuple)):
+            return type(a) is type(b) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, dict):
+            return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        return type(a) is type(b) and a == b
+
+    @settings(max_examples=150, deadline=None)
+    @given(trees, st.data())
+    def check(tree, data):
+        blob = _dist.dumps(tree)
+        assert same(_dist.loads(blob), tree)
+        cut = data.draw(st.integers(0, len(blob)))
+        flip = data.draw(st.integers(0, max(len(blob) - 1, 0)))
+        for bad in (blob[:cut], blob[:flip] + bytes([blob[flip] ^ 0x5A]) + blob[flip + 1:] if blob else b""):
+            try:
+                _dist.loads(bad)
+            except (ValueError, UnicodeDecodeError):
+                pass
+
+    check()
