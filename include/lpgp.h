@@ -275,8 +275,10 @@ int  lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, co
                          const double* Linv, double* ms);
 /* the fused panel step of the forward substitution on host buffers: V (nt * 128 rows x cols, col-major, ld = nt * 128,
  * cols a multiple of 128) <- Lblk^{-1} V with Lblk the nt x nt tile lower-triangular block (col-major, ld nt * 128, the
- * diagonal TILES with zeros above their diagonal) and Linv the nt explicit inverses of its diagonal tiles.       */
-int  lpgp_test_panel_solve(lpgp_ctx* ctx, double* V, int32_t nt, int64_t cols, const double* Lblk,
+ * diagonal TILES with zeros above their diagonal) and Linv the nt explicit inverses of its diagonal tiles.
+ * rows_form != 0: the same chain for rows, X (cols rows x nt * 128 columns, col-major, ld = cols) <- X Lblk^{-T}
+ * (the panel solve of the multi-GPU factorisation and of a block append).                                       */
+int  lpgp_test_panel_solve(lpgp_ctx* ctx, int32_t rows_form, double* V, int32_t nt, int64_t cols, const double* Lblk,
                            const double* Linv, double* ms);
 /* diagnostics: histogram over the 8 XCDs of where the single workgroup of the tile Cholesky ran
  * since the last reset (the CU reservation of the update streams is built on it)           */

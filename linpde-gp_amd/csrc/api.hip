@@ -1402,7 +1402,7 @@ int lpgp_test_tile_step(lpgp_ctx* ctx, int32_t which, double* XV, int64_t n, con
   return rc;
 }
 
-int lpgp_test_panel_solve(lpgp_ctx* ctx, double* V, int32_t nt, int64_t cols, const double* Lblk, const double* Linv, double* ms) {
+int lpgp_test_panel_solve(lpgp_ctx* ctx, int32_t rows_form, double* V, int32_t nt, int64_t cols, const double* Lblk, const double* Linv, double* ms) {
   LPGP_CHECK(ctx && V && Lblk && Linv && nt >= 1 && nt <= 4 && cols > 0 && cols % TILE == 0, "lpgp_test_panel_solve: bad argument");
   LPGP_DEVICE(ctx);
   const int64_t rows = (int64_t)nt * TILE;
@@ -1418,7 +1418,9 @@ int lpgp_test_panel_solve(lpgp_ctx* ctx, double* V, int32_t nt, int64_t cols, co
   LPGP_HIP(hipEventCreate(&e0));
   LPGP_HIP(hipEventCreate(&e1));
   LPGP_HIP(hipEventRecord(e0, ctx->s_main));
-  int rc = launch_trsv_panel(ctx, ctx->s_main, d, rows, di, dl, rows, nt, (int)(cols / TILE), -1);
+  // rows_form: V holds X (cols rows x nt * 128 columns, column-major ld = cols) and X <- X Lblk^{-T}
+  int rc = rows_form ? launch_trsm_panel(ctx, ctx->s_main, d, cols, di, dl, rows, nt, (int)(cols / TILE), -1)
+                     : launch_trsv_panel(ctx, ctx->s_main, d, rows, di, dl, rows, nt, (int)(cols / TILE), -1);
   LPGP_HIP(hipEventRecord(e1, ctx->s_main));
   LPGP_HIP(hipEventSynchronize(e1));
   float t = 0.f;

@@ -298,6 +298,9 @@ static int panel_rows_solve(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const 
   const int64_t ld = mat->lr_cap, nb = (int64_t)G.nbt * TILE;
   const int K = c0 / G.nbt, b0 = c0 - K * G.nbt;
   double* X = mat->a + (int64_t)rl0 * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+  if (ctx->fused_solve && c1 - c0 <= 4)        // the diagonal block is final here: the whole chain of the panel in one launch
+    return launch_trsm_panel(ctx, st, X, ld, mat->linv + (int64_t)c0 * TILE * TILE, dblk_tile(mat, G, K, b0, b0), nb, c1 - c0, mt,
+                             LPGP_K_PANEL);
   for (int j = 0; j < c1 - c0; ++j) {
     double* Xj = X + (int64_t)j * TILE * ld;
     LPGP_TRY(launch_trsm_tile(ctx, st, Xj, ld, mat->linv + (int64_t)(c0 + j) * TILE * TILE, dblk_tile(mat, G, K, b0 + j, b0 + j), nb, mt,

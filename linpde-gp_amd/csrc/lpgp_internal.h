@@ -281,6 +281,9 @@ int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, 
 // tiles of rows, top row at V) <- L_KK^{-1} V; linv: the panel's tile inverses (contiguous), L: its diagonal block
 int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
                       int nt_rows, int nt_cols, int prof_kernel);
+// the same chain for rows: X (mt tiles of rows x nt_cols <= 4 tile columns) <- X L_KK^{-T}, L_KK already factored
+int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
+                      int nt_cols, int mt, int prof_kernel);
 
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);

@@ -454,6 +454,11 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
     double* rows = a + (int64_t)t_done * tb;          // row offset of the new rows
     for (int p0 = 0; p0 < t_done; p0 += nbt) {
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
+      if (ctx->fused_solve && p1 - p0 <= 4) {
+        // the old panel's diagonal block is final: the chain of the new rows through it in one launch (panel_solve_kernel)
+        LPGP_TRY(launch_trsm_panel(ctx, sP, rows + (int64_t)p0 * tb * ld, ld, mat->linv + (int64_t)p0 * tb * tb,
+                                   a + (int64_t)p0 * tb * (ld + 1), ld, p1 - p0, mnew, LPGP_K_PANEL));
+      } else
       for (int jt = p0; jt < p1; ++jt) {
         double* X = rows + (int64_t)jt * tb * ld;
         LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, mnew));

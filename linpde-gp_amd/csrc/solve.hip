@@ -207,27 +207,39 @@ __global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
   for (int q = 0; q < 8; ++q) pbase[q * pstep] = x[q];
 }
 
-int launch_panel_solve_4(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols);    // solve4.hip
+int launch_panel_solve_4(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols, bool kfast);    // solve4.hip
+
+template <bool KFAST>
+static int launch_panel_any(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
+                            int nt_panel, int64_t count, int prof_kernel) {
+  if (count <= 0 || nt_panel <= 0) return 0;
+  LPGP_CHECK(nt_panel <= 4, "panel solve: at most 4 tiles per panel (got %d)", nt_panel);
+  PanelSolveArgs a;
+  a.V = V; a.ldv = ldv; a.linv = linv; a.L = L; a.ldl = ldl;
+  // algorithmic flops of the triangular solve of the panel: count x (nt_panel * 128)^2
+  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, (double)count * (double)(nt_panel * TILE) * (double)(nt_panel * TILE), 0.0);
+  int rc;
+  switch (nt_panel) {
+    case 1: rc = launch_panel_solve_nt<1, KFAST>(ctx, stream, a, count); break;
+    case 2: rc = launch_panel_solve_nt<2, KFAST>(ctx, stream, a, count); break;
+    case 3: rc = launch_panel_solve_nt<3, KFAST>(ctx, stream, a, count); break;
+    default: rc = launch_panel_solve_4(ctx, stream, a, count, KFAST); break;
+  }
+  if (prof_kernel >= 0) prof_end(ctx, stream);
+  return rc;
+}
 
 // V (nt_rows <= 4 tiles of rows x nt_cols * 128 columns, column-major ldv) <- L_KK^{-1} V in place, L_KK the panel's diagonal block
 int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
                       int nt_rows, int nt_cols, int prof_kernel) {
-  if (nt_cols <= 0 || nt_rows <= 0) return 0;
-  LPGP_CHECK(nt_rows <= 4, "panel solve: at most 4 tile rows per panel (got %d)", nt_rows);
-  PanelSolveArgs a;
-  a.V = V; a.ldv = ldv; a.linv = linv; a.L = L; a.ldl = ldl;
-  const int64_t cols = (int64_t)nt_cols * TILE;
-  // algorithmic flops of the triangular solve of the panel: cols x (nt_rows * 128)^2
-  if (prof_kernel >= 0) prof_begin(ctx, stream, prof_kernel, (double)cols * (double)(nt_rows * TILE) * (double)(nt_rows * TILE), 0.0);
-  int rc;
-  switch (nt_rows) {
-    case 1: rc = launch_panel_solve_nt<1>(ctx, stream, a, cols); break;
-    case 2: rc = launch_panel_solve_nt<2>(ctx, stream, a, cols); break;
-    case 3: rc = launch_panel_solve_nt<3>(ctx, stream, a, cols); break;
-    default: rc = launch_panel_solve_4(ctx, stream, a, cols); break;
-  }
-  if (prof_kernel >= 0) prof_end(ctx, stream);
-  return rc;
+  return launch_panel_any<true>(ctx, stream, V, ldv, linv, L, ldl, nt_rows, (int64_t)nt_cols * TILE, prof_kernel);
+}
+
+// X (mt * 128 rows x nt_cols <= 4 tiles of columns, column-major ldx) <- X L_KK^{-T} in place: the rows below (or appended
+// to) an already factored diagonal block
+int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
+                      int nt_cols, int mt, int prof_kernel) {
+  return launch_panel_any<false>(ctx, stream, X, ldx, linv, L, ldl, nt_cols, (int64_t)mt * TILE, prof_kernel);
 }
 
 template <bool KFAST>

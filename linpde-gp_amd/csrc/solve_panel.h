@@ -116,7 +116,10 @@ struct PanelSolveArgs {
 
 // RG = 16-column groups per workgroup (2: eight waves, 32 columns; 1: four waves, 16 columns -- half the matrix work per
 // workgroup on twice as many, for right-hand-side blocks that would not fill the chip otherwise)
-template <int NT, int RG>
+// KFAST = true: the forward substitution (above).  KFAST = false: the same chain for ROWS below an already factored
+// diagonal block, X[rows, panel columns] <- X L_KK^{-T} with X(i, c) at V[i + c ldv] -- the panel solve of the multi-GPU
+// factorisation (the diagonal block arrives first there) and of a block append (old panels, new rows).
+template <int NT, int RG, bool KFAST>
 __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs g) {
   static_assert(psv_sched_ok<NT, RG>(), "panel solve: broken stage schedule");
   constexpr PsvSched<NT> SCH = psv_make_sched<NT>(4 / RG);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
   const int rg = wu >> 2, s4 = wu & 3;
   const int cc = rg ? 3 - s4 : s4;
   const int li = lane & 15, lj = lane >> 4;
-  const int64_t i0 = (int64_t)blockIdx.x * (16 * RG) + rg * 16 + li;      // this lane's right-hand-side column
+  const int64_t i0 = (int64_t)blockIdx.x * (16 * RG) + rg * 16 + li;      // this lane's right-hand-side column (KFAST) / row
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
 
   auto issue = [&](auto S_) {
@@ -156,11 +159,12 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
 
   // fragments of the NT tiles of the panel: fragment (t, q) = element (column i0, panel row 128 t + 4 (cc + 4 q) + lj)
   double a[NT][8], x[8];
-  double* const pbase = g.V + i0 * g.ldv + (4 * cc + lj);
+  double* const pbase = KFAST ? g.V + i0 * g.ldv + (4 * cc + lj) : g.V + i0 + (int64_t)(4 * cc + lj) * g.ldv;
+  const int64_t cstep = KFAST ? 1 : g.ldv;                  // address step per column c of X
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a[t][q] = pbase[t * TILE + q * 16];
+    for (int q = 0; q < 8; ++q) a[t][q] = pbase[(t * TILE + q * 16) * cstep];
   asm volatile("" ::: "memory");
   issue(std::integral_constant<int, 0>{});
   double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;
@@ -248,23 +252,23 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) pbase[t * TILE + q * 16] = a[t][q];
+    for (int q = 0; q < 8; ++q) pbase[(t * TILE + q * 16) * cstep] = a[t][q];
   (void)NS;
 }
 
-template <int NT, int RG>
+template <int NT, int RG, bool KFAST>
 int launch_panel_solve_rg(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
   const size_t shmem = (size_t)(RG * 32 * 64 + TSV_RING) * sizeof(double);
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG>), shmem));
-  hipLaunchKernelGGL((panel_solve_kernel<NT, RG>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG, KFAST>), shmem));
+  hipLaunchKernelGGL((panel_solve_kernel<NT, RG, KFAST>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
 // 16-column workgroups (RG = 1) throughout: per column the 32-column variant is no faster (measured: 264 workgroups of
 // either kind take 117 us at NT = 4 for 4224 resp. 205 us for 8448 columns) and the chain of a narrow block is half as long
-template <int NT>
+template <int NT, bool KFAST>
 int launch_panel_solve_nt(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
-  return launch_panel_solve_rg<NT, 1>(ctx, stream, a, cols);
+  return launch_panel_solve_rg<NT, 1, KFAST>(ctx, stream, a, cols);
 }
 
 }  // namespace lpgp

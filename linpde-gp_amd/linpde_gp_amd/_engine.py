@@ -480,11 +480,14 @@ def test_tile_step(ctx: Context, which: int, XV: np.ndarray, L: np.ndarray, Linv
     return XV, ms.value
 
 
-def test_panel_solve(ctx: Context, V: np.ndarray, Lblk: np.ndarray):
-    """Fused panel step of the forward substitution (`lpgp_test_panel_solve`): V (nt*128 x cols) <- Lblk^{-1} V.
-    Returns (result, milliseconds)."""
+def test_panel_solve(ctx: Context, V: np.ndarray, Lblk: np.ndarray, rows_form: bool = False):
+    """Fused panel chain (`lpgp_test_panel_solve`): V (nt*128 x cols) <- Lblk^{-1} V, or with `rows_form`
+    X (cols x nt*128) <- X Lblk^{-T}.  Returns (result, milliseconds)."""
     import scipy.linalg
-    rows, cols = V.shape
+    if rows_form:
+        cols, rows = V.shape
+    else:
+        rows, cols = V.shape
     nt = rows // 128
     V = np.asfortranarray(V, dtype=np.double).copy(order="F")
     Lb = np.asfortranarray(np.tril(Lblk), dtype=np.double)
@@ -492,7 +495,7 @@ def test_panel_solve(ctx: Context, V: np.ndarray, Lblk: np.ndarray):
         Lb[t * 128:(t + 1) * 128, t * 128:(t + 1) * 128], np.eye(128), lower=True))).reshape(-1, order="F") for t in range(nt)])
     ms = C.c_double(0.0)
     pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_panel_solve(ctx._h, V.ctypes.data_as(pd), nt, cols, Lb.ctypes.data_as(pd),
+    check(lib.lpgp_test_panel_solve(ctx._h, int(bool(rows_form)), V.ctypes.data_as(pd), nt, cols, Lb.ctypes.data_as(pd),
                                     np.ascontiguousarray(Linv).ctypes.data_as(pd), C.byref(ms)), "lpgp_test_panel_solve")
     return V, ms.value
 

@@ -116,7 +116,7 @@ def _load() -> C.CDLL:
     sig("lpgp_test_potrf_tile", C.c_int, vp, pd, pd, C.POINTER(i32))
     sig("lpgp_debug_tile_xcc", C.c_int, vp, C.POINTER(i32), i32)
     sig("lpgp_test_tile_step", C.c_int, vp, i32, pd, i64, pd, pd, pd)
-    sig("lpgp_test_panel_solve", C.c_int, vp, pd, i32, i64, pd, pd, pd)
+    sig("lpgp_test_panel_solve", C.c_int, vp, i32, pd, i32, i64, pd, pd, pd)
     sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
     sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
     return lib

@@ -205,3 +205,8 @@ def test_fused_panel_solve(nt, cols):
     res = np.abs(L @ got - V) / (np.abs(L) @ np.abs(got))
     assert np.max(res) < 5e-14, np.max(res)
     np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * np.abs(exact).max())
+    # the rows orientation (panel solve of the multi-GPU factorisation / block append): X <- X L^{-T}
+    got_r, _ = _engine.test_panel_solve(ctx, np.ascontiguousarray(V.T), L, rows_form=True)
+    np.testing.assert_allclose(got_r, exact.T, rtol=0, atol=1e-9 * np.abs(exact).max())
+    res_r = np.abs(got_r @ L.T - V.T) / (np.abs(got_r) @ np.abs(L.T))
+    assert np.max(res_r) < 5e-14, np.max(res_r)
