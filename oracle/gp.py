@@ -52,6 +52,17 @@ def _noise_cov_dense(block: ObsBlock) -> np.ndarray | None:
     return c
 
 
+def colsumsq(V: np.ndarray) -> np.ndarray:
+    """Column sums of squares, accumulated along the CONTIGUOUS axis so that numpy's pairwise summation applies.
+
+    `np.sum(V * V, axis=0)` / `einsum("ij,ij->j")` on a C-ordered V add the N rows one after another; when the posterior
+    variance is 1e-6 of the prior variance (c5) that naive N-term accumulation alone is 1.6e-13 = 2e-8 of the variance away
+    from the long-double sum (measured at full c5, `profiles/r02_c5_full_parity.txt`) -- above the 1e-8 parity bar and 25x
+    the device's distance from the long-double sum.  The checker must not be the noisiest part of the check."""
+    Vt = np.ascontiguousarray(V.T)
+    return np.sum(Vt * Vt, axis=1)
+
+
 def prior_mean_L(mean_const: float, L: dict, n: int) -> np.ndarray:
     """L[m](X) for a constant prior mean: only the order-0 coefficient survives."""
     d = len(next(iter(L)))
@@ -112,7 +123,7 @@ class Posterior:
         L0 = covfuncs.identity(d) if Ltest is None else Ltest
         K = cross_cov(self.kernel, self.blocks, Xtest, Ltest)
         V = scipy.linalg.solve_triangular(self.chol, K.T, lower=True)
-        return covfuncs.k_diag(self.kernel, L0, L0, Xtest) - np.sum(V * V, axis=0)
+        return covfuncs.k_diag(self.kernel, L0, L0, Xtest) - colsumsq(V)
 
     def cov(self, X0, X1=None, Ltest: dict | None = None) -> np.ndarray:
         """Full posterior covariance (`_conditional.py:223-231`, via `cho_solve`)."""

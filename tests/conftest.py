@@ -58,35 +58,32 @@ def golden_dir():
 # GPU-vs-oracle posterior comparison in tests/, by bench.py --check and by smoke().
 #
 #   mean:      max|mean - ref| <= 1e-8 * max|ref_mean|
-#   variance:  max|var  - ref| <= 1e-8 * max|ref_var| + 2 sqrt(N_tot) eps k(x,x)
+#   variance:  max|var  - ref| <= 1e-8 * max|ref_var|
 #
-# The second variance term is the rounding floor of the quantity itself: both the oracle (LAPACK) and
-# the device form  var = k(x,x) - sum_{i<=N_tot} v_i^2  in fp64, a sum of N_tot squares that cancels
-# against the prior variance k(x,x); each evaluation carries an error of order sqrt(N_tot) eps k(x,x)
-# (random-walk model; worst case N_tot eps k), hence 2 sqrt(N_tot) eps k(x,x) between the two.  It
-# matters only where the posterior variance is tiny against the prior's (c2: max var 1e-6 vs k = 4:
-# floor 1.6e-13 = 1.6e-7 of max var; measured difference 3e-14).
+# Nothing else: no absolute slack.  (Until the middle of round 2 the variance bound carried an extra
+# 2 sqrt(N_tot) eps k(x,x) "rounding floor".  It was covering for the ORACLE: `np.sum(V * V, axis=0)`
+# adds the N_tot rows one after another, and at full c5 that naive accumulation alone sits 1.6e-13 =
+# 2e-8 of max var away from the long-double sum while the device is 6e-15 away from it
+# (profiles/r02_c5_full_parity.txt).  The oracle now sums pairwise (`oracle.gp.colsumsq`) and every
+# GPU test passes the plain bound.)
 # ---------------------------------------------------------------------------------------------
 POSTERIOR_RTOL = 1e-8
 
 
-def posterior_tolerances(ref_mean, ref_var, prior_var: float, n_total: int):
-    eps = np.finfo(np.double).eps
-    mean_atol = POSTERIOR_RTOL * float(np.max(np.abs(ref_mean)))
-    var_atol = POSTERIOR_RTOL * float(np.max(np.abs(ref_var))) + 2.0 * np.sqrt(float(n_total)) * eps * float(prior_var)
-    return mean_atol, var_atol
+def posterior_tolerances(ref_mean, ref_var):
+    return POSTERIOR_RTOL * float(np.max(np.abs(ref_mean))), POSTERIOR_RTOL * float(np.max(np.abs(ref_var)))
 
 
-def assert_posterior_close(mean, var, ref_mean, ref_var, prior_var: float, n_total: int):
+def assert_posterior_close(mean, var, ref_mean, ref_var):
     """Returns the measured (mean error / mean_atol, var error / var_atol) ratios (both <= 1)."""
-    mean_atol, var_atol = posterior_tolerances(ref_mean, ref_var, prior_var, n_total)
+    mean_atol, var_atol = posterior_tolerances(ref_mean, ref_var)
     em = float(np.max(np.abs(np.asarray(mean) - ref_mean)))
     assert em <= mean_atol, f"posterior mean: max abs err {em:.3e} > {mean_atol:.3e} (1e-8 of max |mean|)"
     ev = 0.0
     if var is not None:
         ev = float(np.max(np.abs(np.asarray(var) - ref_var)))
         assert ev <= var_atol, (f"posterior variance: max abs err {ev:.3e} > {var_atol:.3e} "
-                                f"(1e-8 max|var| + 2 sqrt(N) eps k(x,x))")
+                                f"(1e-8 of max |var|)")
     return em / max(mean_atol, 1e-300), ev / max(var_atol, 1e-300)
 
 
