@@ -64,7 +64,7 @@ def cpu_baseline(problems, wl, sample_side=0):
         except Exception:  # pragma: no cover
             pass
     w = wl if full else problems.poisson_2d(n_side=sample_side, m_side=32)
-    res = owl.run(w)
+    res = owl.run(w, want_cond=full)
     sec = res["seconds"]
     what = ("the bench workload itself" if full else f"BOUNDED SAMPLE of the workload at {sample_side}x{sample_side} collocation")
     return {
@@ -95,6 +95,7 @@ def parity_report(mean, var, ref, wl):
         "criterion": "mean <= 1e-8 max|mean|; var <= 1e-8 max|var|",
         "pass": bool(em <= mean_atol and ev <= var_atol),
         "var_max": float(np.max(ref["var"])),
+        "gram_cond2_estimate": ref.get("cond2"),      # lower bound, power / inverse iteration on the oracle's G and factor
         "cpu_seconds_full": ref["seconds"],
     }
 
@@ -355,7 +356,7 @@ def main():
     if args.check or ref is not None:
         if ref is None:
             from oracle import workloads as owl
-            ref = owl.run(wl)
+            ref = owl.run(wl, want_cond=True)
         out["parity"] = parity_report(mean, var, ref, wl)
     _libc.fflush(None)
     sys.stdout.flush()

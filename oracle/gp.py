@@ -63,6 +63,24 @@ def colsumsq(V: np.ndarray) -> np.ndarray:
     return np.sum(Vt * Vt, axis=1)
 
 
+def cond2_estimate(G: np.ndarray, chol: np.ndarray, iters: int = 25, seed: int = 24) -> float:
+    """2-norm condition estimate of the SPD Gram matrix ("report cond-estimate of G"): largest eigenvalue by
+    power iteration on G, smallest by inverse iteration through the Cholesky factor; Rayleigh quotients, so the estimate
+    is a LOWER bound that converges from below."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(G.shape[0]); v /= np.linalg.norm(v)
+    u = v.copy()
+    lmax = lmin_inv = 0.0
+    for _ in range(iters):
+        y = G @ v
+        lmax = float(v @ y)
+        v = y / np.linalg.norm(y)
+        z = scipy.linalg.cho_solve((chol, True), u, check_finite=False)
+        lmin_inv = float(u @ z)
+        u = z / np.linalg.norm(z)
+    return lmax * lmin_inv
+
+
 def prior_mean_L(mean_const: float, L: dict, n: int) -> np.ndarray:
     """L[m](X) for a constant prior mean: only the order-0 coefficient survives."""
     d = len(next(iter(L)))

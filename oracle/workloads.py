@@ -22,8 +22,8 @@ def blocks_of(wl) -> list:
     return [gp.ObsBlock(o.X, o.op, o.Y, None, o.noise_var) for o in wl.observations]
 
 
-def run(wl, want_var: bool = True) -> dict:
-    """Returns mean, var and per-phase seconds."""
+def run(wl, want_var: bool = True, want_cond: bool = False) -> dict:
+    """Returns mean, var and per-phase seconds (and, untimed, a 2-norm condition estimate of the Gram matrix)."""
     blocks = blocks_of(wl)
     t = {}
     t0 = time.perf_counter()
@@ -50,4 +50,7 @@ def run(wl, want_var: bool = True) -> dict:
         var = covfuncs.k_diag(wl.kernel, ident, ident, wl.Xtest) - gp.colsumsq(V)
         t["var"] = time.perf_counter() - t0
     t["total"] = sum(t.values())
-    return {"mean": mean, "var": var, "seconds": t, "weights": w}
+    out = {"mean": mean, "var": var, "seconds": t, "weights": w}
+    if want_cond:
+        out["cond2"] = gp.cond2_estimate(G, chol)
+    return out
