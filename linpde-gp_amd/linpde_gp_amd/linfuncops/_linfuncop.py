@@ -47,7 +47,7 @@ class LinearFunctionOperator:
     # -- application --------------------------------------------------------------------
     def __call__(self, f, /, *, argnum: int = 0):
         # local imports: the packages import each other like in the reference
-        from ..functions import Constant, Function
+        from ..functions import Function
         from ..randprocs import covfuncs
         from ..randprocs import _gaussian_process as gps
 
@@ -60,16 +60,16 @@ class LinearFunctionOperator:
                 mean=self(f.mean),
                 cov=self(self(f.cov, argnum=1), argnum=0),
             )
-        if isinstance(f, Constant):
-            # derivatives of a constant vanish; only the order-0 coefficient survives
-            d = len(self._input_domain_shape) and self._input_domain_shape[0] or 1
-            c0 = self.coefficients_dict().get((0,) * d, 0.0)
-            return Constant(f.input_shape, c0 * f.value)
         if isinstance(f, Function):
-            raise NotImplementedError(
-                "applying a differential operator to a general mean function needs autodiff "
-                "(JAX fallback of the reference, `diffops/_lindiffop.py:104-129`): out of scope"
-            )
+            # sum_alpha c_alpha d^alpha f, term by term, for means that carry their derivatives in closed form
+            # (Constant / Zero, Polynomial, Affine, LambdaFunction with `derivatives`); NotImplementedError where the
+            # reference would differentiate by JAX autodiff (`diffops/_lindiffop.py:104-129`)
+            from ..functions import apply_coefficients
+            d = len(self._input_domain_shape) and self._input_domain_shape[0] or 1
+            coeffs = self.coefficients_dict()
+            if any(len(mi) != d for mi in coeffs):
+                raise ValueError("the operator's multi-indices do not match the input dimension of the function")
+            return apply_coefficients(coeffs, f)
         raise NotImplementedError(f"cannot apply {type(self).__name__} to {type(f).__name__}")
 
     def to_linfunctl(self, X):

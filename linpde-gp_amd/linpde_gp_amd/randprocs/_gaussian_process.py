@@ -362,9 +362,8 @@ class ConditionalGaussianProcess(GaussianProcess):
         c0 = self._test_coeffs.get((0,) * d, 0.0)
         if isinstance(m, functions.Constant):
             return np.full(n, c0 * float(m.value))
-        if any(any(mi) for mi in self._test_coeffs):
-            raise NotImplementedError("differentiating a general prior mean needs autodiff (out of scope)")
-        return c0 * np.asarray(m(x), dtype=np.double).reshape(-1)
+        # derivative read-outs of a non-constant mean: closed-form derivatives or NotImplementedError (functions.differentiate)
+        return np.asarray(functions.apply_coefficients(self._test_coeffs, m)(x), dtype=np.double).reshape(-1)
 
     def predict(self, x, *, return_var: bool = True):
         """Posterior mean and marginal variance at `x` in one pass over the factor.

@@ -598,3 +598,41 @@ def test_functional_of_crosscovariance_is_a_linear_operator_covariance(lp):
     G = L0(L0(k, argnum=1))
     assert _rel(G.matrix, ocf.LkL(okern, lap, lap, X0.reshape(-1, 2), X0.reshape(-1, 2))) < 1e-12
     assert isinstance(G + lp.randvars.ArrayCovariance(np.zeros((5, 7, 5, 7)), (5, 7), (5, 7)), lp.randvars.ArrayCovariance)
+
+
+def test_polynomial_prior_mean_under_operators(lp):
+    """A non-constant prior mean: the posterior given (Y, L) under mean m is m + the zero-mean posterior given
+    Y - L[m](X) (`_conditional.py:96-110,193-197`); `L[m]` by closed-form derivatives (`functions.Polynomial`), the
+    zero-mean side against the oracle.  Also the derivative read-out of the posterior, whose mean needs L[m](x)."""
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    coeffs = [0.3, -1.0, 0.25, 0.5]
+    m = lp.functions.Polynomial(coeffs)
+    k = 1.7**2 * cf.Matern((), nu=2.5, lengthscales=0.8)
+    okern = [(1.7**2, [("matern", 2.5, 0.8)])]
+    X, Xb = np.linspace(-1.0, 1.0, 40), np.array([-1.0, 1.0])
+    Y, Yb = np.sin(2.0 * X), np.array([0.2, -0.1])
+    L = -1.0 * diffops.Laplacian(())
+    noise = lp.randvars.Normal(np.zeros(2), 1e-6 * np.eye(2))
+    u = lp.GaussianProcess(m, k).condition_on_observations(Yb, Xb, b=noise).condition_on_observations(Y, X, L=L)
+    Lm = -np.polyval(np.polyder(coeffs[::-1], 2), X)                      # -m''(X)
+    Y0, Yb0 = Y - Lm, Yb - m(Xb)
+    u0 = lp.GaussianProcess(lp.functions.Zero(()), k).condition_on_observations(Yb0, Xb, b=noise) \
+        .condition_on_observations(Y0, X, L=L)
+    post = ogp.condition(okern, [ogp.ObsBlock(Xb[:, None], ocf.identity(1), Yb0, np.zeros(2), 1e-6),
+                                 ogp.ObsBlock(X[:, None], {(2,): -1.0}, Y0)])
+    xt = np.linspace(-0.95, 0.95, 33)
+    mean, var = u.predict(xt)
+    assert _rel(mean, post.mean(xt[:, None]) + m(xt)) < 1e-8
+    assert _rel(var, post.var(xt[:, None])) < 1e-8
+    np.testing.assert_allclose(u.representer_weights, u0.representer_weights, rtol=1e-12, atol=1e-12)
+    # first derivative of the posterior: m'(x) + d/dx of the zero-mean posterior mean
+    D = diffops.PartialDerivative(diffops.MultiIndex((1,)))
+    dmean = D(u).mean(xt)
+    ref = np.polyval(np.polyder(coeffs[::-1], 1), xt) + post.mean(xt[:, None], {(1,): 1.0})
+    assert _rel(dmean, ref) < 1e-8
+    # a mean without derivatives under an operator: the reference's JAX fallback, NotImplementedError here
+    g = lp.GaussianProcess(lp.functions.LambdaFunction(np.cos, ()), k)
+    with pytest.raises(NotImplementedError):
+        g.condition_on_observations(Y, X, L=L)
+    assert g.condition_on_observations(Y, X).predict(xt)[0].shape == (33,)        # plain values are fine

@@ -243,3 +243,40 @@ def test_covariance_classes():
         rv.LinearOperatorCovariance(A.reshape(6, 4), (2, 3), (3,))
     with pytest.raises(TypeError):
         c + 1.0
+
+
+def test_mean_functions_with_closed_form_derivatives():
+    """Non-constant prior means under differential operators (`functions/_polynomial.py:39-98`, `_affine.py:9-51`; the
+    reference differentiates them by JAX autodiff, `diffops/_lindiffop.py:104-129` -- here in closed form)."""
+    F = lp.functions
+    p = F.Polynomial([1.0, -2.0, 0.5, 3.0])                       # 1 - 2x + x^2/2 + 3x^3
+    x = np.linspace(-2.0, 2.0, 17)
+    np.testing.assert_allclose(p(x), np.polyval([3.0, 0.5, -2.0, 1.0], x), rtol=1e-15)
+    assert p.degree == 3 and p.differentiate().coefficients == (-2.0, 1.0, 9.0)
+    np.testing.assert_allclose(p.integrate().differentiate().coefficients, p.coefficients)
+    assert (p + F.Constant((), 2.0)).coefficients[0] == 3.0 and (2.0 * p - p).coefficients == p.coefficients
+    assert F.Monomial(3).coefficients == (0.0, 0.0, 0.0, 1.0) and F.Polynomial([4.0]).differentiate().coefficients == (0.0,)
+    # operators in canonical form: -alpha u'' + beta u, one-dimensional
+    L = -0.7 * diffops.Laplacian(()) + 1.5 * lp.linfuncops.Identity(())
+    Lp = L(p)
+    np.testing.assert_allclose(Lp(x), -0.7 * np.polyval(np.polyder([3.0, 0.5, -2.0, 1.0], 2), x) + 1.5 * p(x), rtol=1e-14)
+    # through a functional (what `condition_on_observations` evaluates as L[m](X))
+    np.testing.assert_allclose(L.to_linfunctl(x)(p), Lp(x))
+    # affine mean of the real line
+    a = F.Affine(2.0, -1.0)
+    np.testing.assert_allclose(diffops.PartialDerivative(diffops.MultiIndex((1,)))(a)(x), np.full_like(x, 2.0))
+    np.testing.assert_allclose(L(a)(x), 1.5 * (2.0 * x - 1.0))
+    # vector-valued affine maps evaluate with the reference's shape rules
+    A = F.Affine(np.array([[1.0, 2.0], [0.0, -1.0], [3.0, 0.5]]), np.array([0.5, 0.0, -1.0]))
+    assert A.input_shape == (2,) and A.output_shape == (3,)
+    X2 = np.random.default_rng(0).standard_normal((5, 2))
+    np.testing.assert_allclose(A(X2), X2 @ A.A.T + A.b)
+    # a callable with analytic derivatives supplied by the caller, 2-D Laplacian
+    f = F.LambdaFunction(lambda z: np.sin(z[..., 0]) * z[..., 1] ** 2, (2,),
+                         derivatives={(2, 0): lambda z: -np.sin(z[..., 0]) * z[..., 1] ** 2,
+                                      (0, 2): lambda z: 2.0 * np.sin(z[..., 0])})
+    np.testing.assert_allclose(diffops.Laplacian((2,))(f)(X2), -np.sin(X2[:, 0]) * X2[:, 1] ** 2 + 2.0 * np.sin(X2[:, 0]))
+    with pytest.raises(NotImplementedError):                       # a derivative nobody supplied
+        diffops.PartialDerivative(diffops.MultiIndex((1, 0)))(f)
+    with pytest.raises(NotImplementedError):                       # no derivatives at all: the reference's JAX fallback
+        diffops.Laplacian((2,))(F.LambdaFunction(lambda z: z[..., 0], (2,)))
