@@ -172,6 +172,10 @@ int  lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* 
 /* dense copy-out (n x n, C-order, n = lpgp_mat_size).  what = 0: symmetric Gram as
  * assembled (only valid while nothing is factored), 1: lower Cholesky factor.           */
 int  lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host);
+/* diagonal of the Cholesky factor (n = lpgp_mat_size doubles): `LinearOperator.det / logabsdet` of the Gram operator
+ * (probnum protocol behind `ConditionalGaussianProcess.gram`, _conditional.py:92-94) without collecting the factor:
+ * log det G = 2 sum_i log L_ii.  Local in a multi-GPU job (the diagonal blocks are replicated).                      */
+int  lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host);
 
 /* ---- factor + solve: replaces `gram.solve`, `LinearOperator.cholesky`
  *      (_conditional.py:44,108) and the Schur-complement append

@@ -906,6 +906,31 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
   return 0;
 }
 
+int lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host) {
+  LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_factor_diag: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_factor_diag: matrix is not (fully) factored");
+  const int64_t pn = mat->pn;
+  if (pn == 0) return 0;
+  std::vector<double> tmp((size_t)pn);
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  if (ctx->distributed()) {
+    // replicated diagonal blocks: block K at dblk + K nb^2, leading dimension nb
+    const int64_t nb = ctx->nb;
+    for (int64_t k0 = 0; k0 < pn; k0 += nb) {
+      const int64_t h = std::min(nb, pn - k0);
+      LPGP_HIP(hipMemcpy2D(tmp.data() + k0, sizeof(double), mat->dblk + (k0 / nb) * nb * nb, (size_t)(nb + 1) * sizeof(double),
+                           sizeof(double), (size_t)h, hipMemcpyDeviceToHost));
+    }
+  } else {
+    LPGP_HIP(hipMemcpy2D(tmp.data(), sizeof(double), mat->a, (size_t)(mat->lr_cap + 1) * sizeof(double), sizeof(double), (size_t)pn,
+                         hipMemcpyDeviceToHost));
+  }
+  for (const auto& b : mat->blocks)
+    for (int64_t i = 0; i < b.n; ++i) out_host[b.off + i] = tmp[(size_t)(b.poff + i)];
+  return 0;
+}
+
 // ---- factor + solve -----------------------------------------------------------------------
 int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   LPGP_CHECK(ctx && mat, "lpgp_potrf: null argument");

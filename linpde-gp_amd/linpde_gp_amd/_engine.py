@@ -349,6 +349,12 @@ class GramMatrix:
         check(lib.lpgp_mat_to_host(self.ctx._h, self._h, 0 if what == "gram" else 1, as_pd(out)), "lpgp_mat_to_host")
         return out
 
+    def factor_diag(self) -> np.ndarray:
+        """Diagonal of the Cholesky factor (`lpgp_mat_factor_diag`)."""
+        out = np.empty(self.n)
+        check(lib.lpgp_mat_factor_diag(self.ctx._h, self._h, as_pd(out)), "lpgp_mat_factor_diag")
+        return out
+
     def potrf(self) -> int:
         info = C.c_int32()
         check(lib.lpgp_potrf(self.ctx._h, self._h, C.byref(info)), "lpgp_potrf")

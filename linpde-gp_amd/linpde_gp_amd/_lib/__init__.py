@@ -94,6 +94,7 @@ def _load() -> C.CDLL:
     sig("lpgp_mat_add_diag", C.c_int, vp, vp, i32, pd, dbl)
     sig("lpgp_mat_add_dense", C.c_int, vp, vp, i32, pd)
     sig("lpgp_mat_to_host", C.c_int, vp, vp, i32, pd)
+    sig("lpgp_mat_factor_diag", C.c_int, vp, vp, pd)
     sig("lpgp_potrf", C.c_int, vp, vp, C.POINTER(i32))
     sig("lpgp_potrs", C.c_int, vp, vp, pd, i64)
     sig("lpgp_solve_weights", C.c_int, vp, vp, pd, pd)
@@ -130,7 +131,7 @@ EXPORTED = [
     "lpgp_dist_grid", "lpgp_dist_stats", "lpgp_test_stair_enumerate", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_pop_block", "lpgp_mat_set_view", "lpgp_mat_num_blocks",
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
-    "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host",
+    "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_profile_enable", "lpgp_profile_reset",

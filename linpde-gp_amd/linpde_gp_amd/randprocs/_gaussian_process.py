@@ -95,8 +95,10 @@ class _ObservationBlock:
 
 
 class _GramOperator:
-    """What `ConditionalGaussianProcess.gram` returns: the resident factorisation with the
-    `solve` / `cholesky` / `todense` subset of probnum's `LinearOperator` protocol."""
+    """What `ConditionalGaussianProcess.gram` returns (`_conditional.py:92-94`): the resident factorisation behind the part
+    of probnum's `LinearOperator` protocol the reference's callers use (`solve`, `inv`, `cholesky`,
+    `todense`, `@`, `.T`, `det` / `logabsdet`, `trace`).  The Gram matrix itself no longer exists in HBM (it was factored
+    in place): products `G @ V` re-evaluate its blocks matrix-free (`lpgp_kernel_matvec`) and add the noise terms."""
 
     def __init__(self, cgp: "ConditionalGaussianProcess"):
         self._cgp = cgp
@@ -106,9 +108,20 @@ class _GramOperator:
         n = sum(ob.points.n for ob in self._cgp._blocks)
         return (n, n)
 
+    dtype = np.dtype(np.double)
+    is_symmetric = True
+    is_positive_definite = True
+
+    @property
+    def T(self):
+        return self
+
     def solve(self, B):
         self._cgp._check_current()
         return self._cgp._state.mat.potrs(B)
+
+    def inv(self):
+        return _GramInverse(self)
 
     def cholesky(self, lower: bool = True):
         self._cgp._check_current()
@@ -118,6 +131,82 @@ class _GramOperator:
     def todense(self):
         Lf = self.cholesky(True)
         return Lf @ Lf.T
+
+    def logabsdet(self) -> float:
+        """log det G = 2 sum_i log L_ii from the diagonal of the resident factor (`lpgp_mat_factor_diag`)."""
+        self._cgp._check_current()
+        d = self._cgp._state.mat.factor_diag()
+        return float(2.0 * np.sum(np.log(d)))
+
+    def det(self) -> float:
+        return float(np.exp(self.logabsdet()))
+
+    def trace(self) -> float:
+        """Sum of the diagonal of G: the differentiated kernel at coinciding points, block by block, plus the noise."""
+        cgp = self._cgp
+        base = cgp._prior.cov
+        tr = 0.0
+        for ob in cgp._blocks:
+            k = covfuncs.DifferentiatedCovarianceFunction(covfuncs._base(base), *_combine(base, ob.coeffs, ob.coeffs))
+            tr += ob.points.n * _engine.kernel_diag(cgp._state.ctx, k.lower())
+            tr += float(np.sum(_noise_diag(ob)))
+        return tr
+
+    def __matmul__(self, V):
+        cgp = self._cgp
+        V = np.asarray(V, dtype=np.double)
+        n = self.shape[0]
+        if V.shape[0] != n or V.ndim > 2:
+            raise ValueError(f"operand of shape {V.shape} does not match the Gram operator {self.shape}")
+        V2 = V.reshape(n, -1)
+        out = np.zeros_like(V2)
+        base = cgp._prior.cov
+        offs = np.cumsum([0] + [ob.points.n for ob in cgp._blocks])
+        for i, bi in enumerate(cgp._blocks):
+            for j, bj in enumerate(cgp._blocks):
+                if bi.points.n == 0 or bj.points.n == 0:
+                    continue
+                k = covfuncs.DifferentiatedCovarianceFunction(covfuncs._base(base), *_combine(base, bi.coeffs, bj.coeffs))
+                out[offs[i]:offs[i + 1]] += _engine.kernel_matvec(cgp._state.ctx, k.lower(), bi.points, bj.points,
+                                                                  np.ascontiguousarray(V2[offs[j]:offs[j + 1]]))
+            if bi.b is not None and isinstance(bi.b, randvars.Normal):
+                if bi.b.cov_diag is not None:
+                    out[offs[i]:offs[i + 1]] += np.asarray(bi.b.cov_diag)[:, None] * V2[offs[i]:offs[i + 1]]
+                else:
+                    out[offs[i]:offs[i + 1]] += np.asarray(bi.b.cov).reshape(bi.points.n, bi.points.n) @ V2[offs[i]:offs[i + 1]]
+        return out.reshape(V.shape)
+
+
+def _noise_diag(ob) -> np.ndarray:
+    if ob.b is None or not isinstance(ob.b, randvars.Normal):
+        return np.zeros(0)
+    if ob.b.cov_diag is not None:
+        return np.asarray(ob.b.cov_diag, dtype=np.double)
+    return np.diag(np.asarray(ob.b.cov).reshape(ob.points.n, ob.points.n))
+
+
+class _GramInverse:
+    """`gram.inv()`: products are solves with the resident factor."""
+
+    def __init__(self, gram: _GramOperator):
+        self._gram = gram
+
+    @property
+    def shape(self):
+        return self._gram.shape
+
+    @property
+    def T(self):
+        return self
+
+    def __matmul__(self, B):
+        return self._gram.solve(B)
+
+    def inv(self):
+        return self._gram
+
+    def todense(self):
+        return self._gram.solve(np.eye(self.shape[0]))
 
 
 class _DeviceState:

@@ -78,6 +78,8 @@ G = Lf @ Lf.T
 from oracle import gp as ogp
 G_ref = ogp.gram(wl.kernel, owl.blocks_of(wl))
 eg = np.max(np.abs(G - G_ref)) / np.max(np.abs(G_ref))
+ld = u.gram.logabsdet()                      # from the replicated diagonal blocks: local, no communication
+assert abs(ld - 2.0 * np.sum(np.log(np.diag(Lf)))) < 1e-10 * abs(ld) and abs(ld - np.linalg.slogdet(G_ref)[1]) < 1e-6 * abs(ld)
 w = u.representer_weights
 ew = np.max(np.abs(w - ref["weights"])) / np.max(np.abs(ref["weights"]))
 m_only = u.mean(wl.Xtest)                    # mean through the weights (prediction points sharded, results gathered)

@@ -417,6 +417,18 @@ def test_potrs_multiple_rhs_and_dense_noise(lp):
     Xt = np.linspace(-1, 1, 33)[:, None]
     m, v = u.predict(Xt)
     assert _rel(m, post.mean(Xt)) < 1e-9 and _rel(v, post.var(Xt)) < 1e-9
+    # the rest of the `LinearOperator` protocol the reference's callers use on `gram`
+    g = u.gram
+    assert g.shape == (300, 300) and g.T is g
+    np.testing.assert_allclose(g @ B, post.G @ B, rtol=1e-12, atol=1e-12)          # matrix-free re-evaluation + dense noise
+    np.testing.assert_allclose(g @ B[:, 0], post.G @ B[:, 0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g.inv() @ B, np.linalg.solve(post.G, B), rtol=1e-8, atol=1e-8)
+    assert g.inv().inv() is g
+    sign, logdet = np.linalg.slogdet(post.G)
+    assert sign == 1.0 and abs(g.logabsdet() - logdet) < 1e-9 * abs(logdet)
+    assert abs(g.trace() - np.trace(post.G)) < 1e-12 * np.trace(post.G)
+    with pytest.raises(ValueError):
+        g @ np.zeros(7)
 
 
 def test_not_positive_definite_raises(lp):
