@@ -87,7 +87,7 @@ em2 = np.max(np.abs(m_only - ref["mean"])) / np.max(np.abs(ref["mean"]))
 st = ctx.dist_stats()
 print("RANK", comm.rank, "of", comm.world, em, ev, eg, ew, em2, st, flush=True)
 assert em < 1e-8 and ev < 1e-8 and eg < 1e-12 and ew < 1e-5 and em2 < 1e-8       # (the weights carry the conditioning of G)
-assert st["bytes_sent"] > 0 and st["bytes_received"] > 0
+assert st["bytes_received"] > 0             # (a rank that owns no tile of a small matrix sends nothing)
 comm.barrier()
 comm.close()
 """
@@ -125,6 +125,18 @@ def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None
 ])
 def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port)
+
+
+@pytest.mark.skipif(not os.environ.get("LPGP_SLOW_TESTS"), reason="eight processes on ONE GPU oversubscribe its hardware queues: "
+                    "300 s per case (both passed in round 2, profiles/r02_eight_ranks_one_gpu.txt); set LPGP_SLOW_TESTS=1")
+@pytest.mark.parametrize("grid,workload,nb,port", [
+    # the grids of an 8-GPU node, eight processes on the one GPU: 8 x 1 (the default there) with 7 blocks of 128 -- rank 7
+    # owns NOTHING -- and 2 x 4 (north_star's example)
+    ((8, 1), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29771),
+    ((2, 4), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29781),
+])
+def test_eight_ranks_on_one_gpu_host_transport(grid, workload, nb, port):
+    _run_ranks(8, grid, workload, nb, port)
 
 
 @pytest.mark.parametrize("grid,workload,nb,port,window_mb", [
