@@ -132,8 +132,8 @@ def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
 @pytest.mark.parametrize("grid,workload,nb,port", [
     # the grids of an 8-GPU node, eight processes on the one GPU: 8 x 1 (the default there) with 7 blocks of 128 -- rank 7
     # owns NOTHING -- and 2 x 4 (north_star's example)
-    ((8, 1), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29771),
-    ((2, 4), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29781),
+    ((8, 1), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29871),
+    ((2, 4), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29881),
 ])
 def test_eight_ranks_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(8, grid, workload, nb, port)
