@@ -154,6 +154,34 @@ class Posterior:
         return kxx - K0 @ scipy.linalg.cho_solve((self.chol, True), K1.T)
 
 
+def refined_posterior(post: "Posterior", Xtest, Ltest: dict | None = None, iters: int = 12):
+    """Posterior mean and marginal variance of the fp64 Gram matrix to (nearly) working accuracy: every solve with `G` is
+    refined with long-double residuals until it stops moving (LAPACK's factor as the preconditioner).  This is the yardstick
+    for ill-conditioned problems, where LAPACK itself is cond(G) x eps away from the exact answer and a comparison of two fp64
+    implementations at 1e-8 says nothing (`tests/test_gpu_random.py`, `scratch/random_diag.py`)."""
+    d = np.asarray(Xtest).shape[1]
+    L0 = covfuncs.identity(d) if Ltest is None else Ltest
+    Gl = post.G.astype(np.longdouble)
+
+    def solve(B):
+        B = np.asarray(B, dtype=np.double)
+        X = scipy.linalg.cho_solve((post.chol, True), B).astype(np.longdouble)
+        for _ in range(iters):
+            R = (B.astype(np.longdouble) - Gl @ X).astype(np.double)
+            dX = scipy.linalg.cho_solve((post.chol, True), R)
+            X = X + dX
+            if np.max(np.abs(dX)) <= 1e-18 * np.max(np.abs(X)):
+                break
+        return X
+
+    K = cross_cov(post.kernel, post.blocks, Xtest, Ltest)                 # (M, N)
+    w = solve(residual(post.blocks, post.mean_const))
+    mean = prior_mean_L(post.mean_const, L0, K.shape[0]).astype(np.longdouble) + K.astype(np.longdouble) @ w
+    W = solve(K.T)                                                        # (N, M)
+    var = covfuncs.k_diag(post.kernel, L0, L0, Xtest).astype(np.longdouble) - np.sum(K.T.astype(np.longdouble) * W, axis=0)
+    return np.asarray(mean, dtype=np.double), np.asarray(var, dtype=np.double)
+
+
 def condition(kernel, blocks: list[ObsBlock], mean_const: float = 0.0) -> Posterior:
     """One-shot dense conditioning (`test_posterior_gp.py:182-197`)."""
     G = gram(kernel, blocks)
