@@ -169,6 +169,13 @@ def main():
         ctx.dist_init(comm)
         dist_note = "single rank through the DISTRIBUTED code path (LPGP_BENCH_FORCE_DIST=1)"
     transport = os.environ.get("LPGP_DIST_TRANSPORT", "rccl")
+    loopback = bool(int(os.environ.get("LPGP_BENCH_RCCL_LOOPBACK", "0")))
+    if loopback and world > 1:
+        # bring-up aid for a box whose ranks SHARE one GPU: RCCL refuses two ranks on one device unless it takes them for
+        # different hosts; a distinct NCCL_HOSTID per rank makes it run its socket transport over the loopback interface.
+        # The product's RCCL code path end to end, NOT the xGMI data path and never a benchmark configuration (run it with
+        # LPGP_DEVICE=0 so that every rank opens the one GPU).
+        os.environ.update(NCCL_HOSTID=f"lpgp-bench-host-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
     if world > 1 and not replicas:
         # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be created (on every
         # rank alike) the run falls back to the direct-peer transport (IPC-mapped windows, device-to-device pushes), and
@@ -301,7 +308,9 @@ def main():
                           f"{ctx.grid[0]} x {ctx.grid[1]} process grid, "
                           + {"host": "HOST-STAGED panel exchange (bring-up transport, not a benchmark configuration)",
                              "ipc": "panel gather by direct-peer pushes into IPC-mapped windows (device-to-device copies, barriers over the control plane)",
-                             "rccl": "panel gather by grouped RCCL point-to-point sends"}[transport]
+                             "rccl": "panel gather by grouped RCCL point-to-point sends"
+                                     + (" -- OVER LOOPBACK SOCKETS between ranks that share one GPU (LPGP_BENCH_RCCL_LOOPBACK=1: "
+                                        "bring-up aid, not a benchmark configuration)" if loopback else "")}[transport]
                           + ", prediction points sharded over the ranks, factor streamed for the solves"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
             "rccl_ranks": world if (world > 1 and not replicas and transport == "rccl") else 0,

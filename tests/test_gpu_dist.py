@@ -93,14 +93,15 @@ comm.close()
 """
 
 
-def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None):
+def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None, rank_env=None):
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
     env.pop("LOCAL_RANK", None)
     if window_mb is not None:
         env["LPGP_IPC_WINDOW_MB"] = str(window_mb)
     procs = [subprocess.Popen([sys.executable, "-c", MULTI % {"root": ROOT, "workload": workload, "nb": nb, "grid": grid,
                                                               "transport": transport}],
-                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                              env=dict(env, RANK=str(r), **(rank_env(r) if rank_env else {})),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     outs = []
     try:
@@ -151,6 +152,25 @@ def test_multi_rank_on_one_gpu_direct_peer_transport(grid, workload, nb, port, w
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="ipc", window_mb=window_mb)
 
 
+def _rccl_as_if_on_separate_hosts(r):
+    """RCCL refuses two ranks on one GPU ("Duplicate GPU detected") -- unless it believes they sit on different HOSTS: a
+    distinct NCCL_HOSTID per rank turns the job into a multi-node one whose ranks talk through RCCL's socket transport over
+    the loopback interface.  Not the xGMI data path, but the product's RCCL code path end to end: communicator bring-up
+    over the control plane, the grouped ncclSend / ncclRecv exchanges of `gather_panel` on the panel stream beside the
+    update stream, ncclAllReduce of the factorisation status."""
+    return {"NCCL_HOSTID": f"lpgp-test-host-{r}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NCCL_NET": "Socket",
+            "NCCL_DEBUG": "WARN", "LPGP_FORCE_RCCL": "1"}
+
+
+@pytest.mark.parametrize("grid,workload,nb,port", [
+    ((2, 1), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 512, 30011),
+    ((2, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 30021),
+    ((3, 1), "heat_1d(nt=40, nx=24, m_side=8)", 256, 30031),
+])
+def test_multi_rank_rccl_over_loopback_sockets(grid, workload, nb, port):
+    _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="rccl", rank_env=_rccl_as_if_on_separate_hosts)
+
+
 CHAIN = r"""
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
@@ -161,7 +181,7 @@ from oracle import covfuncs as ocf, gp as ogp
 comm = _dist.Comm.from_env()
 ctx = _engine.default_context()
 ctx.set_option("nb", 128)
-ctx.dist_init(comm, transport="host", grid=%(grid)r)
+ctx.dist_init(comm, transport=%(transport)r, grid=%(grid)r)
 cf = lp.randprocs.covfuncs
 okern, ident = [(1.0, [("expquad", 1.0)])], ocf.identity(1)
 prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
@@ -200,14 +220,17 @@ comm.close()
 """
 
 
-@pytest.mark.parametrize("grid,port", [((2, 1), 29771), ((2, 2), 29781)])
-def test_multi_rank_views_rollback_and_small_prediction_sets(grid, port):
+@pytest.mark.parametrize("grid,port,transport", [((2, 1), 29771, "host"), ((2, 2), 29781, "host"), ((2, 1), 30041, "rccl")])
+def test_multi_rank_views_rollback_and_small_prediction_sets(grid, port, transport):
     """On a sharded factor: a failed conditioning raises on every rank and is rolled back, an earlier posterior of the
-    chain keeps working after a later conditioning (view), prediction sets smaller than the job are not sharded."""
+    chain keeps working after a later conditioning (view), prediction sets smaller than the job are not sharded.  The
+    "rccl" case runs the failure path (status all-reduce, no abort: the failure is a numerical one) through RCCL."""
     world = grid[0] * grid[1]
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
     env.pop("LOCAL_RANK", None)
-    procs = [subprocess.Popen([sys.executable, "-c", CHAIN % {"root": ROOT, "grid": grid}], env=dict(env, RANK=str(r)),
+    rank_env = _rccl_as_if_on_separate_hosts if transport == "rccl" else (lambda r: {})
+    procs = [subprocess.Popen([sys.executable, "-c", CHAIN % {"root": ROOT, "grid": grid, "transport": transport}],
+                              env=dict(env, RANK=str(r), **rank_env(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     try:
