@@ -360,6 +360,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
     LPGP_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   }
   LPGP_HIP(hipMalloc(&ctx->d_info, sizeof(int)));
+  LPGP_HIP(hipHostMalloc(&ctx->h_info_pinned, 64, hipHostMallocDefault));
   if (const char* e = std::getenv("LPGP_NB")) {
     long v = std::atol(e);
     if (v >= TILE && v % TILE == 0) ctx->nb = v;
@@ -406,6 +407,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
     (void)hipEventDestroy(sl.done);
   }
   (void)hipFree(ctx->d_info);
+  (void)hipHostFree(ctx->h_info_pinned);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   for (size_t r = 0; r < ctx->ipc_peer.size(); ++r)
     if ((int)r != ctx->rank && ctx->ipc_peer[r]) (void)hipIpcCloseMemHandle(ctx->ipc_peer[r]);
@@ -527,6 +529,8 @@ int lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, i
   return 0;
 }
 
+static int dist_fail(lpgp_ctx* ctx, int rc);
+
 int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128) {
   LPGP_CHECK(ctx && uid128 && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init: bad argument");
   LPGP_CHECK(!ctx->distributed(), "lpgp_dist_init: already initialised");
@@ -541,7 +545,8 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
   ctx->rank = rank;
   ctx->world = world;
   choose_grid(ctx, world);
-  return 0;
+  // every connection is made NOW, while all ranks are alive (see dist_warm_up); also the first check that data arrives
+  return dist_fail(ctx, dist_warm_up(ctx));
 }
 
 int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user) {
@@ -967,8 +972,11 @@ int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
     if (rc) break;
     rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, m_pad)) : trsm_lower_t_blocked(ctx, mat, pn / TILE, dv, pn, m_pad);
     if (rc) break;
+    // (wait FIRST, watched: the copy into pageable memory below is synchronous and would wait unwatched behind a streamed
+    //  solve whose peer is gone)
+    if ((rc = sync_stream(ctx, ctx->s_main)) != 0) break;
     if (hipMemcpyAsync(hp.data(), dv, hp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main) != hipSuccess) { rc = -1; break; }
-    if (hipStreamSynchronize(ctx->s_main) != hipSuccess) { rc = -1; break; }
+    rc = sync_stream(ctx, ctx->s_main);          // (behind a streamed solve: polls, so that a failed peer cannot block this rank)
   } while (0);
   (void)hipFree(dv);
   if (rc != 0) {
@@ -1006,8 +1014,9 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
     rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);
   }
   if (rc != 0) return rc;
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
   LPGP_HIP(hipMemcpyAsync(hp.data(), mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
   mat->has_w = 1;
   if (w_host) gather_padded(mat, hp.data(), w_host);
   return 0;
@@ -1101,7 +1110,7 @@ int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   rc = ctx->distributed() ? dist_fail(ctx, trsm_lower_dist(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad))
                           : trsm_lower_blocked(ctx, mat, mat->pn / TILE, V->v, V->ld, V->m_pad);
   if (rc != 0) return rc;
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
   return 0;
 }
 
@@ -1129,8 +1138,9 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                        (const double*)mat->w, ctx->d_tmp);
     LPGP_HIP(hipGetLastError());
+    LPGP_TRY(sync_stream(ctx, ctx->s_main));
     LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+    LPGP_TRY(sync_stream(ctx, ctx->s_main));
     for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h[j];
   }
   if (var_host) {
@@ -1146,17 +1156,19 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
                          (const double*)zcol, ctx->d_tmp, ctx->d_tmp + K->m_pad);
       LPGP_HIP(hipGetLastError());
       h2.resize((size_t)m);
+      LPGP_TRY(sync_stream(ctx, ctx->s_main));
       LPGP_HIP(hipMemcpyAsync(h2.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
       LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp + K->m_pad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost,
                               ctx->s_main));
-      LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+      LPGP_TRY(sync_stream(ctx, ctx->s_main));
       for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h2[j];
     } else {
       hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                          (const double*)nullptr, ctx->d_tmp);
       LPGP_HIP(hipGetLastError());
+      LPGP_TRY(sync_stream(ctx, ctx->s_main));
       LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-      LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+      LPGP_TRY(sync_stream(ctx, ctx->s_main));
     }
     for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - h[j];
   }

@@ -35,8 +35,11 @@
 // (trsm_lower_t_dist).  No right-hand-side data ever travels; the factor is streamed once per solve at S / Pr
 // per link and never stored replicated.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -53,6 +56,64 @@ namespace lpgp {
       return -3;                                                                           \
     }                                                                                      \
   } while (0)
+
+// LPGP_DIST_TRACE=1: one line on stderr around every call of the multi-GPU path that can block (bring-up aid)
+static const bool g_trace = [] { const char* e = std::getenv("LPGP_DIST_TRACE"); return e && std::atoi(e) != 0; }();
+#define DTRACE(ctx, ...)                                       \
+  do {                                                         \
+    if (g_trace) {                                             \
+      std::fprintf(stderr, "[lpgp rank %d] ", (ctx)->rank);    \
+      std::fprintf(stderr, __VA_ARGS__);                       \
+      std::fprintf(stderr, "\n");                              \
+      std::fflush(stderr);                                     \
+    }                                                          \
+  } while (0)
+
+int sync_stream(lpgp_ctx* ctx, hipStream_t st) {
+  DTRACE(ctx, "sync_stream: begin");
+  if (!(ctx->nccl_comm && ctx->world > 1)) {
+    LPGP_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  static const double timeout_s = [] { const char* e = std::getenv("LPGP_DIST_TIMEOUT_S"); return e ? std::atof(e) : 600.0; }();
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  auto last = t0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) {
+      DTRACE(ctx, "sync_stream: done");
+      return 0;
+    }
+    if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      set_error("waiting for the panel stream: %s", hipGetErrorString(q));
+      return -1;
+    }
+    const auto now = clock::now();
+    if (now - last > std::chrono::milliseconds(2)) {
+      last = now;
+      ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+      ncclResult_t aerr = ncclSuccess;
+      const ncclResult_t r = ncclCommGetAsyncError(comm, &aerr);
+      const double waited = std::chrono::duration<double>(now - t0).count();
+      const bool remote = r != ncclSuccess || (aerr != ncclSuccess && aerr != ncclInProgress);
+      const bool late = timeout_s > 0.0 && waited > timeout_s;
+      if (remote || late) {
+        if (remote)
+          set_error("a peer of the job failed: RCCL reports '%s' while this rank waited for its data (%.1f s)",
+                    ncclGetErrorString(r != ncclSuccess ? r : aerr), waited);
+        else
+          set_error("no progress on the panel stream for %.0f s (LPGP_DIST_TIMEOUT_S): communicator aborted", waited);
+        (void)ncclCommAbort(comm);           // terminates this rank's pending RCCL kernels; the peers notice the same way
+        ctx->nccl_comm = nullptr;
+        ctx->dist_broken = 1;
+        return -3;
+      }
+    }
+    std::this_thread::yield();
+  }
+}
 
 static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int mt, int nt,
                           int k, double alpha, double beta, int tri) {
@@ -164,6 +225,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
     // LPGP_DIST_COLLECTIVE=bcast: one ncclBroadcast per piece instead of the point-to-point group (a fallback to compare
     // with on the 8-GPU node, which the builder has no access to; RCCL then picks its own ring / tree)
     static const bool use_bcast = [] { const char* e = std::getenv("LPGP_DIST_COLLECTIVE"); return e && std::string(e) == "bcast"; }();
+    DTRACE(ctx, "exchange: group of %zu pieces", pieces.size());
     LPGP_NCCL(ncclGroupStart());
     for (const auto& p : pieces) {
       if (p.count == 0) continue;
@@ -177,6 +239,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       }
     }
     LPGP_NCCL(ncclGroupEnd());
+    DTRACE(ctx, "exchange: group enqueued");
   }
   prof_end(ctx, st);
   return 0;
@@ -188,12 +251,51 @@ static int allreduce_max_int(lpgp_ctx* ctx, hipStream_t st, int* h_value) {
     LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, h_value, (int64_t)sizeof(int), 0) == 0, "host exchange: all-reduce failed");
     return 0;
   }
+  // through PINNED host memory: a copy to or from pageable memory is synchronous -- it would wait, unwatched, behind a
+  // collective whose peer is gone; like this only sync_stream waits, and it watches RCCL's error state
   int* d = ctx->d_info;
-  LPGP_HIP(hipMemcpyAsync(d, h_value, sizeof(int), hipMemcpyHostToDevice, st));
+  int* hp = ctx->h_info_pinned;
+  *hp = *h_value;
+  LPGP_HIP(hipMemcpyAsync(d, hp, sizeof(int), hipMemcpyHostToDevice, st));
+  DTRACE(ctx, "all-reduce: enqueue");
   LPGP_NCCL(ncclAllReduce(d, d, 1, ncclInt, ncclMax, (ncclComm_t)ctx->nccl_comm, st));
-  LPGP_HIP(hipMemcpyAsync(h_value, d, sizeof(int), hipMemcpyDeviceToHost, st));
-  LPGP_HIP(hipStreamSynchronize(st));
+  LPGP_HIP(hipMemcpyAsync(hp, d, sizeof(int), hipMemcpyDeviceToHost, st));
+  LPGP_TRY(sync_stream(ctx, st));
+  *h_value = *hp;
   return 0;
+}
+
+int dist_warm_up(lpgp_ctx* ctx) {
+  if (ctx->world <= 1 || !ctx->nccl_comm) return 0;
+  hipStream_t st = ctx->s_main;
+  const int W = ctx->world;
+  double* d = nullptr;
+  LPGP_HIP(hipMalloc(&d, (size_t)W * sizeof(double)));
+  std::vector<double> h((size_t)W, -1.0);
+  h[(size_t)ctx->rank] = 1000.0 + ctx->rank;
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; break; }
+    std::vector<Piece> pieces;
+    for (int r = 0; r < W; ++r) pieces.push_back({r, d + r, 1});
+    if ((rc = bcast_pieces(ctx, st, pieces)) != 0) break;
+    if (hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
+    if ((rc = sync_stream(ctx, st)) != 0) break;
+    for (int r = 0; r < W; ++r)
+      if (h[(size_t)r] != 1000.0 + r) {
+        set_error("communicator warm-up: rank %d received %g from rank %d (expected %g)", ctx->rank, h[(size_t)r], r, 1000.0 + r);
+        rc = -3;
+      }
+    if (rc != 0) break;
+    int v = ctx->rank;
+    if ((rc = allreduce_max_int(ctx, st, &v)) != 0) break;
+    if (v != W - 1) {
+      set_error("communicator warm-up: all-reduce(max) of the ranks gave %d, expected %d", v, W - 1);
+      rc = -3;
+    }
+  } while (0);
+  (void)hipFree(d);
+  return rc;
 }
 
 // ---- panel gather -------------------------------------------------------------------------------------------------
@@ -209,8 +311,11 @@ __global__ __launch_bounds__(256) void unpack_piece_kernel(double* __restrict__ 
   *reinterpret_cast<double2*>(dst + col * ldd + gr) = *reinterpret_cast<const double2*>(src + col * lds + r);
 }
 
-static int ensure_buf(double** p, size_t* cap, size_t doubles) {
+static int ensure_buf(lpgp_ctx* ctx, double** p, size_t* cap, size_t doubles) {
   if (doubles <= *cap) return 0;
+  DTRACE(ctx, "ensure_buf: %zu -> %zu doubles", *cap, doubles);
+  // hipFree waits for the device: drain the panel stream first, WATCHED (an exchange with a dead peer may be pending on it)
+  if (*p) LPGP_TRY(sync_stream(ctx, ctx->s_main));
   if (*p) LPGP_HIP(hipFree(*p));
   *p = nullptr;
   *cap = 0;
@@ -250,7 +355,7 @@ static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid
     nt[r] = cyc_before(cr, T) - l0[r];
     total += (size_t)nt[r] * TILE * cols;
   }
-  LPGP_TRY(ensure_buf(&ctx->d_pack, &ctx->pack_cap, total));
+  LPGP_TRY(ensure_buf(ctx, &ctx->d_pack, &ctx->pack_cap, total));
   std::vector<Piece> pieces;
   std::vector<double*> pbuf(G.Pr);
   size_t off = 0;
@@ -367,7 +472,7 @@ static int factor_diag_block(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const
   return 0;
 }
 
-static int ensure_panel(lpgp_ctx* ctx, int which, size_t doubles) { return ensure_buf(&ctx->d_panel[which], &ctx->panel_cap[which], doubles); }
+static int ensure_panel(lpgp_ctx* ctx, int which, size_t doubles) { return ensure_buf(ctx, &ctx->d_panel[which], &ctx->panel_cap[which], doubles); }
 
 // Factor tile columns [t_done, T) of the distributed matrix; columns [0, t_done) already hold L.
 int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
@@ -397,7 +502,15 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
   auto row_lo = [&](const Panel& p) { return p.fresh ? p.c1 : t_done; };
 
   // Panel step, part 1 (panel stream): diagonal block, rows below, gather into panel buffer `which`
+  // test hook: rank LPGP_TEST_FAIL_RANK fails (locally, like an allocation or launch error would) at its
+  // LPGP_TEST_FAIL_PANEL-th panel step; tests/test_gpu_dist.py checks that the OTHER ranks return an error instead of
+  // waiting for ever for that rank's pieces
+  static const int fail_rank = [] { const char* e = std::getenv("LPGP_TEST_FAIL_RANK"); return e ? std::atoi(e) : -1; }();
+  static const int fail_panel = [] { const char* e = std::getenv("LPGP_TEST_FAIL_PANEL"); return e ? std::atoi(e) : -1; }();
+  int panel_steps = 0;
   auto panel_part = [&](const Panel& p, int which) -> int {
+    LPGP_CHECK(!(ctx->rank == fail_rank && panel_steps++ == fail_panel), "injected failure at panel step %d (LPGP_TEST_FAIL_PANEL)",
+               fail_panel);
     const int pcK = (p.c0 / G.nbt) % G.Pc;
     if (p.fresh) LPGP_TRY(factor_diag_block(ctx, sP, mat, G, T, p.c0, p.c1));
     if (p.c1 >= T) return 0;
@@ -445,9 +558,9 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
     LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
   }
-  int h_info = 0;
-  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
-  LPGP_HIP(hipStreamSynchronize(sP));
+  LPGP_HIP(hipMemcpyAsync(ctx->h_info_pinned + 1, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
+  LPGP_TRY(sync_stream(ctx, sP));
+  int h_info = ctx->h_info_pinned[1];
   LPGP_TRY(allreduce_max_int(ctx, sP, &h_info));        // a failed pivot is seen by the owner of its diagonal block only
   if (info) *info = h_info;
   return 0;
@@ -586,7 +699,7 @@ int factor_to_host_dist(lpgp_ctx* ctx, lpgp_mat* mat, double* out) {
     // rows from the panel's own first tile on (the diagonal block included: gathered like any other rows)
     LPGP_TRY(ensure_panel(ctx, 0, (size_t)(T - c0) * TILE * (size_t)(c1 - c0) * TILE));
     LPGP_TRY(gather_panel(ctx, st, mat, G, T, c0, c1, c0, ctx->d_panel[0]));
-    LPGP_HIP(hipStreamSynchronize(st));
+    LPGP_TRY(sync_stream(ctx, st));
     const int64_t rows = (int64_t)(T - c0) * TILE;
     LPGP_HIP(hipMemcpy2D(out + (int64_t)c0 * TILE * (pn + 1), (size_t)pn * sizeof(double), ctx->d_panel[0], (size_t)rows * sizeof(double),
                          (size_t)rows * sizeof(double), (size_t)(c1 - c0) * TILE, hipMemcpyDeviceToHost));

@@ -116,6 +116,7 @@ struct lpgp_ctx {
   DescSlot desc_ring[DESC_RING];
   int desc_next = 0;
   int* d_info = nullptr;           // potrf info word
+  int* h_info_pinned = nullptr;    // pinned mirror (multi-GPU: a device-to-host copy into pageable memory would BLOCK behind a collective that waits for a dead peer)
   double* d_tmp = nullptr;         // small scratch (vectors)
   int64_t tmp_cap = 0;
   // caching allocator: freed device buffers are kept for reuse (a hipMalloc/hipFree pair
@@ -223,6 +224,17 @@ inline int ensure_lds_attr(lpgp_ctx* ctx, const void* fn, size_t bytes) {
   ctx->lds_attr_done.push_back(fn);
   return 0;
 }
+
+// Wait for `stream` (dist.hip).  With an RCCL communicator of more than one rank this is NOT hipStreamSynchronize: a peer
+// that failed has aborted its communicator, and a kernel of this rank that still waits for that peer's data would wait for
+// ever.  The stream is polled instead, RCCL's asynchronous error state is checked every few milliseconds, and on a remote
+// error -- or after LPGP_DIST_TIMEOUT_S seconds (default 600, 0: none) -- this rank aborts its own communicator, which
+// terminates the pending kernels, and returns an error (the context is unusable afterwards, `dist_broken`).
+int sync_stream(lpgp_ctx* ctx, hipStream_t stream);
+// One tiny message between every pair of ranks and one all-reduce, checked (dist.hip; called by lpgp_dist_init while every
+// rank is known to be alive): RCCL sets its connections up at first use, inside a BLOCKING host call -- later, with a peer
+// gone, that call would never return; after this every exchange only enqueues kernels, which sync_stream can watch.
+int dist_warm_up(lpgp_ctx* ctx);
 
 // device memory pool (api.hip)
 int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh);

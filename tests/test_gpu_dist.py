@@ -171,6 +171,53 @@ def test_multi_rank_rccl_over_loopback_sockets(grid, workload, nb, port):
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="rccl", rank_env=_rccl_as_if_on_separate_hosts)
 
 
+FAILING = r"""
+import os, sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine, problems
+comm = _dist.Comm.from_env()
+ctx = _engine.default_context()
+ctx.set_option("nb", 128)
+ctx.dist_init(comm, transport="rccl", grid=(2, 1))
+wl = problems.poisson_2d(n_side=24, n_bdry=20, m_side=5)
+t0 = time.time()
+try:
+    problems.condition_and_predict(wl)
+except Exception as exc:      # noqa: BLE001
+    print("RAISED", comm.rank, type(exc).__name__, f"{time.time() - t0:.1f}s", str(exc)[:400].replace("\n", " "), flush=True)
+    os._exit(0)               # the job is dead: no further collective, no clean shutdown of the aborted communicator
+print("NO ERROR", comm.rank, flush=True)
+os._exit(3)
+"""
+
+
+def test_a_failing_rank_does_not_leave_its_peer_waiting():
+    """Rank 1 fails locally inside the factorisation (test hook LPGP_TEST_FAIL_RANK / _PANEL in `potrf_dist`) and aborts
+    its communicator (`dist_fail`); rank 0, whose next receive would wait for rank 1's pieces for ever, polls RCCL's
+    asynchronous error state while it waits for its stream (`sync_stream`), aborts too and raises -- both within seconds."""
+    world, port = 2, 30051
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0",
+               LPGP_TEST_FAIL_RANK="1", LPGP_TEST_FAIL_PANEL="2", LPGP_DIST_TIMEOUT_S="120")
+    env.pop("LOCAL_RANK", None)
+    procs = [subprocess.Popen([sys.executable, "-c", FAILING % {"root": ROOT}],
+                              env=dict(env, RANK=str(r), **_rccl_as_if_on_separate_hosts(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RAISED {r}" in so, f"rank {r} (rc {p.returncode}): " + so[-1500:] + se[-3000:]
+    assert "injected failure" in outs[1][0]
+    assert "peer of the job failed" in outs[0][0] or "communicator" in outs[0][0], outs[0][0]
+
+
 CHAIN = r"""
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
