@@ -162,13 +162,15 @@ def _rccl_as_if_on_separate_hosts(r):
             "NCCL_DEBUG": "WARN", "LPGP_FORCE_RCCL": "1"}
 
 
-@pytest.mark.parametrize("grid,workload,nb,port", [
-    ((2, 1), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 512, 30011),
-    ((2, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 30021),
-    ((3, 1), "heat_1d(nt=40, nx=24, m_side=8)", 256, 30031),
+@pytest.mark.parametrize("grid,workload,nb,port,collective", [
+    ((2, 1), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 512, 30011, None),
+    ((2, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 30021, None),
+    ((3, 1), "heat_1d(nt=40, nx=24, m_side=8)", 256, 30031, None),
+    ((1, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 30061, "bcast"),    # LPGP_DIST_COLLECTIVE=bcast: ncclBroadcast per piece
 ])
-def test_multi_rank_rccl_over_loopback_sockets(grid, workload, nb, port):
-    _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="rccl", rank_env=_rccl_as_if_on_separate_hosts)
+def test_multi_rank_rccl_over_loopback_sockets(grid, workload, nb, port, collective):
+    env = (lambda r: dict(_rccl_as_if_on_separate_hosts(r), LPGP_DIST_COLLECTIVE=collective)) if collective else _rccl_as_if_on_separate_hosts
+    _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="rccl", rank_env=env)
 
 
 FAILING = r"""
