@@ -111,7 +111,9 @@ int sync_stream(lpgp_ctx* ctx, hipStream_t st) {
         return -3;
       }
     }
-    std::this_thread::yield();
+    // spin for the first 200 us (exchanges of the panel chain are short), then back off
+    if (now - t0 < std::chrono::microseconds(200)) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
 }
 
