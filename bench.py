@@ -240,6 +240,14 @@ def main():
     dt = time.perf_counter() - t0
     dt = comm.allreduce_max(dt)
     comm.barrier()
+    # ---- the two phases of a step (un-instrumented steps; the conditioning phase ends with the read-back of the
+    #      factorisation status, so a host stamp between the phases costs nothing): max over ranks ----
+    ph = []
+    for _ in range(2):
+        st_ = []
+        problems.condition_and_predict(wl, prior=prior, device_arrays=dev, stamps=st_)
+        ph.append((st_[1] - st_[0], st_[2] - st_[1]))
+    phase_rows = comm.gather([min(p_[0] for p_ in ph) * 1e3, min(p_[1] for p_ in ph) * 1e3])
     # ---- per-kernel HIP-event timing (same process, same workload, right after the timed
     #      region: event records between launches cost ~25 % wall time, so they stay out of it) ----
     prof_steps = max(1, min(args.steps, 3))
@@ -341,6 +349,9 @@ def main():
             }
             for name, p in prof.items()
         },
+        "phase_ms": {"condition": max(r_[0] for r_ in phase_rows), "predict": max(r_[1] for r_ in phase_rows),
+                     "note": "host stamps around the conditioning chain (assembly, block appends, factorisation) and the prediction "
+                             "(cross-covariance, streamed solve, read-outs) of two extra steps; best of two, max over ranks"},
         "posterior": {"mean_max": float(np.max(mean)), "var_min": float(np.min(var)), "var_max": float(np.max(var))},
     }
     # assembly kernels, one entry per kernel symbol (HBM-write bound by design; bytes = entries stored x 8,

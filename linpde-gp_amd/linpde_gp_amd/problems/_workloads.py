@@ -156,10 +156,17 @@ def operator_of(op: dict, d: int):
     return diffops.LinearDifferentialOperator(coeffs, input_shapes=(shape, ()))
 
 
-def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True):
+def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True, stamps: list | None = None):
     """The canonical user sequence (`experiments/0001_poisson_dirichlet_2d.ipynb` cells 6-22):
-    condition block by block, then posterior mean and marginal variance on the test grid."""
+    condition block by block, then posterior mean and marginal variance on the test grid.
+    `stamps`: receives `time.perf_counter()` at the start, after the last conditioning (every conditioning ends with the
+    read-back of the factorisation status, so the device is idle there) and at the end."""
+    import time
+
     from .. import randvars
+
+    if stamps is not None:
+        stamps.append(time.perf_counter())
 
     prior = build_prior(wl) if prior is None else prior
     u = prior
@@ -170,11 +177,15 @@ def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var
         n = o.X.shape[0]
         b = None if o.noise_var is None else randvars.Normal(np.zeros(Y.shape), np.full(n, o.noise_var))
         u = u.condition_on_observations(Y, X=X, L=operator_of(o.op, wl.d), b=b)
+    if stamps is not None:
+        stamps.append(time.perf_counter())
     Xt = wl.Xtest if device_arrays is None else device_arrays["test"]
     if want_var:
         mean, var = u.predict(Xt)
     else:
         mean, var = u.predict(Xt, return_var=False), None
+    if stamps is not None:
+        stamps.append(time.perf_counter())
     return u, mean, var
 
 
