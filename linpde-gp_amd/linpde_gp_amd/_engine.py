@@ -317,7 +317,7 @@ class GramMatrix:
         return GramMatrix(self.ctx, _handle=h, _block_sizes=self.block_sizes[:nblocks])
 
     def assemble(self, kdesc, X0: Points, X1: Points | None, bi: int, bj: int):
-        arr = _lib.make_kdesc_array(kdesc)
+        arr = _kdesc_array(kdesc)
         if X0.grid_factors is not None and (X1 is None or X1.grid_factors is not None):
             # both point sets are tensor grids: sum of Kronecker products of 1-D kernel matrices
             F0 = (C.c_void_p * len(X0.grid_factors))(*[f._h for f in X0.grid_factors])
@@ -401,7 +401,7 @@ class Rhs:
             self._h = None
 
     def cross_assemble(self, kdesc, X_obs: Points, X_test: Points, bi: int):
-        arr = _lib.make_kdesc_array(kdesc)
+        arr = _kdesc_array(kdesc)
         check(lib.lpgp_cross_assemble(self.ctx._h, arr, len(arr), X_obs._h, X_test._h, self._h, self.mat._h, bi),
               "lpgp_cross_assemble")
 
@@ -431,15 +431,26 @@ class Rhs:
         return out
 
 
+def _kdesc_array(kdesc):
+    """ctypes descriptor array of a lowered kernel; an array built earlier (`lowered_array`) passes through."""
+    return kdesc if isinstance(kdesc, C.Array) else _lib.make_kdesc_array(kdesc)
+
+
+def lowered_array(kdesc):
+    """The C-ABI form of a lowered kernel, built once: callers that assemble the same block structure again and again
+    (a chain of conditionings, one posterior per step of a sweep) keep it instead of the Python description."""
+    return _lib.make_kdesc_array(kdesc)
+
+
 def kernel_diag(ctx: Context, kdesc) -> float:
-    arr = _lib.make_kdesc_array(kdesc)
+    arr = _kdesc_array(kdesc)
     v = C.c_double()
     check(lib.lpgp_kernel_diag(ctx._h, arr, len(arr), C.byref(v)), "lpgp_kernel_diag")
     return v.value
 
 
 def kernel_matrix(ctx: Context, kdesc, X0: Points, X1: Points) -> np.ndarray:
-    arr = _lib.make_kdesc_array(kdesc)
+    arr = _kdesc_array(kdesc)
     out = np.empty((X0.n, X1.n))
     check(lib.lpgp_kernel_matrix(ctx._h, arr, len(arr), X0._h, X1._h, as_pd(out)), "lpgp_kernel_matrix")
     return out
@@ -447,7 +458,7 @@ def kernel_matrix(ctx: Context, kdesc, X0: Points, X1: Points) -> np.ndarray:
 
 def kernel_matvec(ctx: Context, kdesc, X0: Points, X1: Points, V: np.ndarray) -> np.ndarray:
     """K(X0, X1) @ V without forming K (`lpgp_kernel_matvec`); V of shape (n1,) or (n1, nrhs)."""
-    arr = _lib.make_kdesc_array(kdesc)
+    arr = _kdesc_array(kdesc)
     V = np.asarray(V, dtype=np.double)
     vec = V.ndim == 1
     V2 = np.ascontiguousarray(V.reshape(X1.n, -1))

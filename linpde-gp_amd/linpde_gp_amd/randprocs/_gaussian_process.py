@@ -284,12 +284,8 @@ class ConditionalGaussianProcess(GaussianProcess):
     def _assemble_and_factor(mat, base, bi, old_blocks, new_block) -> int:
         # lower-left blocks  (L_new k L_j'^*)(X_new, X_j)   (`_conditional.py:270`)
         for bj, ob in enumerate(old_blocks):
-            k = covfuncs.DifferentiatedCovarianceFunction(
-                covfuncs._base(base), *_combine(base, new_block.coeffs, ob.coeffs))
-            mat.assemble(k.lower(), new_block.points, ob.points, bi, bj)
-        k = covfuncs.DifferentiatedCovarianceFunction(
-            covfuncs._base(base), *_combine(base, new_block.coeffs, new_block.coeffs))
-        mat.assemble(k.lower(), new_block.points, None, bi, bi)
+            mat.assemble(_lowered(base, new_block.coeffs, ob.coeffs), new_block.points, ob.points, bi, bj)
+        mat.assemble(_lowered(base, new_block.coeffs, new_block.coeffs), new_block.points, None, bi, bi)
         # measurement noise  gram + b.cov   (`_conditional.py:392-394`)
         if new_block.b is not None and isinstance(new_block.b, randvars.Normal):
             n = new_block.points.n
@@ -434,16 +430,12 @@ class ConditionalGaussianProcess(GaussianProcess):
         base = self._prior.cov
         for bi, ob in enumerate(self._blocks):
             # (L_obs k Ltest'^*)(X_obs, x)  == (Ltest k L_obs'^*)(x, X_obs) for the symmetric priors here
-            k = covfuncs.DifferentiatedCovarianceFunction(
-                covfuncs._base(base), *_combine(base, ob.coeffs, self._test_coeffs))
-            rhs.cross_assemble(k.lower(), ob.points, Xtest_pts, bi)
+            rhs.cross_assemble(_lowered(base, ob.coeffs, self._test_coeffs), ob.points, Xtest_pts, bi)
         return rhs
 
     def _prior_diag(self) -> float:
         base = self._prior.cov
-        k = covfuncs.DifferentiatedCovarianceFunction(
-            covfuncs._base(base), *_combine(base, self._test_coeffs, self._test_coeffs))
-        return _engine.kernel_diag(self._state.ctx, k.lower())
+        return _engine.kernel_diag(self._state.ctx, _lowered(base, self._test_coeffs, self._test_coeffs))
 
     def _prior_mean_at(self, x, n):
         m = self._prior.mean
@@ -502,6 +494,26 @@ class ConditionalGaussianProcess(GaussianProcess):
         if len(batch) != 1:
             raise ValueError("`__call__` needs inputs of shape (N,) + input_shape")
         return randvars.Normal(self.mean(x), self.cov.matrix(x))
+
+
+_LOWERED: dict = {}      # (id(base), operator maps) -> (base, descriptor array); bounded, see _lowered
+
+
+def _lowered(base, c0: dict, c1: dict):
+    """C-ABI descriptor of the block  L0 (base) L1'^*, cached: composing the operator maps, lowering and filling the ctypes
+    array cost ~25 us of Python per block -- a third of a whole step at N_tot ~ 1 000 -- and a chain of conditionings asks
+    for the same few combinations every time.  Kernels are immutable; the entry keeps `base` alive so that its id cannot be
+    reused while the entry exists."""
+    key = (id(base), tuple(sorted(c0.items())), tuple(sorted(c1.items())))
+    hit = _LOWERED.get(key)
+    if hit is not None and hit[0] is base:
+        return hit[1]
+    k = covfuncs.DifferentiatedCovarianceFunction(covfuncs._base(base), *_combine(base, c0, c1))
+    arr = _engine.lowered_array(k.lower())
+    if len(_LOWERED) >= 512:
+        _LOWERED.clear()
+    _LOWERED[key] = (base, arr)
+    return arr
 
 
 def _combine(base_cov, c0: dict, c1: dict):

@@ -47,7 +47,10 @@ class CovarianceFunction:
 
     @property
     def input_size(self):
-        return int(np.prod(self._input_shape, dtype=int))
+        n = 1
+        for s_ in self._input_shape:
+            n *= int(s_)
+        return n
 
     @property
     def output_shape_0(self):
