@@ -111,6 +111,10 @@ def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if transport == "rccl" and any("lpgp_dist_init failed" in so + se or "lpgp_dist_unique_id failed" in so + se for so, se in outs):
+        # the bring-up itself did not work on this box (no loopback interface, RCCL without its socket transport ...):
+        # nothing of the product path ran
+        pytest.skip("RCCL could not be brought up over loopback sockets here: " + (outs[0][0] + outs[0][1])[-300:])
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
         assert f"RANK {r} of {world}" in so
@@ -214,6 +218,8 @@ def test_a_failing_rank_does_not_leave_its_peer_waiting():
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if any("lpgp_dist_init failed" in so + se or "lpgp_dist_unique_id failed" in so + se for so, se in outs):
+        pytest.skip("RCCL could not be brought up over loopback sockets here: " + (outs[0][0] + outs[0][1])[-300:])
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RAISED {r}" in so, f"rank {r} (rc {p.returncode}): " + so[-1500:] + se[-3000:]
     assert "injected failure" in outs[1][0]
@@ -289,6 +295,8 @@ def test_multi_rank_views_rollback_and_small_prediction_sets(grid, port, transpo
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if transport == "rccl" and any("lpgp_dist_init failed" in so + se or "lpgp_dist_unique_id failed" in so + se for so, se in outs):
+        pytest.skip("RCCL could not be brought up over loopback sockets here: " + (outs[0][0] + outs[0][1])[-300:])
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
         assert f"CHAIN {r} ok" in so
