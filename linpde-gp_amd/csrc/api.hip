@@ -375,6 +375,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_US_FIXED")) ctx->chain_us_fixed = std::atof(e);
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM_BAND")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ctx->gemm_band = v; }
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
@@ -415,7 +416,14 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
   for (int i = 0; i < 2; ++i)
     if (ctx->d_panel[i]) (void)hipFree(ctx->d_panel[i]);
+  if (ctx->nccl_comm_bulk) (void)ncclCommDestroy((ncclComm_t)ctx->nccl_comm_bulk);
   if (ctx->nccl_comm) (void)ncclCommDestroy((ncclComm_t)ctx->nccl_comm);
+  if (ctx->d_pack_bulk) (void)hipFree(ctx->d_pack_bulk);
+  if (ctx->s_comm) (void)hipStreamDestroy(ctx->s_comm);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
+    if (ctx->ev_rows[i]) (void)hipEventDestroy(ctx->ev_rows[i]);
+  }
   for (auto& b : ctx->pool) (void)hipFree(b.p);
   ctx->pool.clear();
   (void)hipStreamDestroy(ctx->s_main);
@@ -545,6 +553,12 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
   ctx->rank = rank;
   ctx->world = world;
   choose_grid(ctx, world);
+  if (world > 1 && ctx->split_gather) {
+    // a second communicator for the bulk of split panel gathers (operations on one communicator are serialised: the
+    // small exchanges of the panel chain would queue behind it).  Without it the split gather still works, serialised.
+    ncclComm_t bulk = nullptr;
+    if (ncclCommSplit(comm, 0, rank, &bulk, nullptr) == ncclSuccess) ctx->nccl_comm_bulk = bulk;
+  }
   // every connection is made NOW, while all ranks are alive (see dist_warm_up); also the first check that data arrives
   return dist_fail(ctx, dist_warm_up(ctx));
 }
@@ -875,7 +889,8 @@ int lpgp_mat_add_dense(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* B
 static int dist_fail(lpgp_ctx* ctx, int rc) {
   if (rc != 0 && ctx->nccl_comm && ctx->world > 1) {
     (void)ncclCommAbort((ncclComm_t)ctx->nccl_comm);
-    ctx->nccl_comm = nullptr;
+    if (ctx->nccl_comm_bulk) (void)ncclCommAbort((ncclComm_t)ctx->nccl_comm_bulk);
+    ctx->nccl_comm = ctx->nccl_comm_bulk = nullptr;
     ctx->dist_broken = 1;
   }
   return rc;

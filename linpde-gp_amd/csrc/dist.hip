@@ -95,7 +95,9 @@ int sync_stream(lpgp_ctx* ctx, hipStream_t st) {
       last = now;
       ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
       ncclResult_t aerr = ncclSuccess;
-      const ncclResult_t r = ncclCommGetAsyncError(comm, &aerr);
+      ncclResult_t r = ncclCommGetAsyncError(comm, &aerr);
+      if (r == ncclSuccess && (aerr == ncclSuccess || aerr == ncclInProgress) && ctx->nccl_comm_bulk)
+        r = ncclCommGetAsyncError((ncclComm_t)ctx->nccl_comm_bulk, &aerr);
       const double waited = std::chrono::duration<double>(now - t0).count();
       const bool remote = r != ncclSuccess || (aerr != ncclSuccess && aerr != ncclInProgress);
       const bool late = timeout_s > 0.0 && waited > timeout_s;
@@ -106,7 +108,8 @@ int sync_stream(lpgp_ctx* ctx, hipStream_t st) {
         else
           set_error("no progress on the panel stream for %.0f s (LPGP_DIST_TIMEOUT_S): communicator aborted", waited);
         (void)ncclCommAbort(comm);           // terminates this rank's pending RCCL kernels; the peers notice the same way
-        ctx->nccl_comm = nullptr;
+        if (ctx->nccl_comm_bulk) (void)ncclCommAbort((ncclComm_t)ctx->nccl_comm_bulk);
+        ctx->nccl_comm = ctx->nccl_comm_bulk = nullptr;
         ctx->dist_broken = 1;
         return -3;
       }
@@ -133,7 +136,7 @@ struct Piece {
   size_t count;          // doubles
 };
 
-static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>& pieces) {
+static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>& pieces, bool bulk = false) {
   if (ctx->world <= 1) return 0;
   double sent = 0.0, recv = 0.0;
   for (const auto& p : pieces) {
@@ -222,8 +225,8 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       }
     }
   } else {
-    ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
-    LPGP_CHECK(comm != nullptr, "panel exchange: no communicator (aborted after an earlier failure?)");
+    ncclComm_t comm = (ncclComm_t)((bulk && ctx->nccl_comm_bulk) ? ctx->nccl_comm_bulk : ctx->nccl_comm);
+    LPGP_CHECK(comm != nullptr && ctx->nccl_comm != nullptr, "panel exchange: no communicator (aborted after an earlier failure?)");
     // LPGP_DIST_COLLECTIVE=bcast: one ncclBroadcast per piece instead of the point-to-point group (a fallback to compare
     // with on the 8-GPU node, which the builder has no access to; RCCL then picks its own ring / tree)
     static const bool use_bcast = [] { const char* e = std::getenv("LPGP_DIST_COLLECTIVE"); return e && std::string(e) == "bcast"; }();
@@ -281,6 +284,7 @@ int dist_warm_up(lpgp_ctx* ctx) {
     std::vector<Piece> pieces;
     for (int r = 0; r < W; ++r) pieces.push_back({r, d + r, 1});
     if ((rc = bcast_pieces(ctx, st, pieces)) != 0) break;
+    if (ctx->nccl_comm_bulk && (rc = bcast_pieces(ctx, st, pieces, true)) != 0) break;
     if (hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) { rc = -1; break; }
     if ((rc = sync_stream(ctx, st)) != 0) break;
     for (int r = 0; r < W; ++r)
@@ -318,6 +322,7 @@ static int ensure_buf(lpgp_ctx* ctx, double** p, size_t* cap, size_t doubles) {
   DTRACE(ctx, "ensure_buf: %zu -> %zu doubles", *cap, doubles);
   // hipFree waits for the device: drain the panel stream first, WATCHED (an exchange with a dead peer may be pending on it)
   if (*p) LPGP_TRY(sync_stream(ctx, ctx->s_main));
+  if (*p && ctx->s_comm) LPGP_TRY(sync_stream(ctx, ctx->s_comm));
   if (*p) LPGP_HIP(hipFree(*p));
   *p = nullptr;
   *cap = 0;
@@ -339,30 +344,33 @@ static Grid grid_of(const lpgp_ctx* ctx) {
   return g;
 }
 
-// Make rows [g_lo, T) (global tiles) of tile columns [c0, c1) of the (partly) factored matrix available on every rank
-// as a dense column-major panel `out` (leading dimension (T - g_lo) * 128), global row order.  The columns live on
-// process column pcK = (c0 / nbt) % Pc.  Collective; everything is enqueued on `st`.
-static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out) {
-  const int rows_t = T - g_lo;
-  if (rows_t <= 0) return 0;
-  const int64_t ldo = (int64_t)rows_t * TILE, cols = (int64_t)(c1 - c0) * TILE;
+// Make rows [g_a, g_b) (global tiles) of tile columns [c0, c1) of the (partly) factored matrix available on every rank
+// inside a dense column-major panel `out` whose first row is global tile g_lo (leading dimension (T - g_lo) * 128), global
+// row order.  The columns live on process column pcK = (c0 / nbt) % Pc.  Collective; everything is enqueued on `st`.
+// with_self = false: this rank's own rows are in `out` already (self_unpack) -- it still sends them.  bulk: the second
+// communicator and its own pack buffer (the exchange runs beside the small exchanges of the panel chain).
+static int gather_rows(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, int g_a, int g_b,
+                       bool with_self, bool bulk, double* out) {
+  if (g_b <= g_a || T <= g_lo) return 0;
+  const int64_t ldo = (int64_t)(T - g_lo) * TILE, cols = (int64_t)(c1 - c0) * TILE;
   const int pcK = (c0 / G.nbt) % G.Pc;
   const int64_t ld = mat->lr_cap;
-  // piece of row member r: its local tiles [l0_r, l1_r)
+  // piece of row member r: its local tiles [l0_r, l0_r + nt_r)
   std::vector<int> l0(G.Pr), nt(G.Pr);
   size_t total = 0;
   for (int r = 0; r < G.Pr; ++r) {
     const Cyc cr = G.Rof(r);
-    l0[r] = cyc_before(cr, g_lo);
-    nt[r] = cyc_before(cr, T) - l0[r];
+    l0[r] = cyc_before(cr, g_a);
+    nt[r] = cyc_before(cr, g_b) - l0[r];
     total += (size_t)nt[r] * TILE * cols;
   }
-  LPGP_TRY(ensure_buf(ctx, &ctx->d_pack, &ctx->pack_cap, total));
+  double** pack = bulk ? &ctx->d_pack_bulk : &ctx->d_pack;
+  LPGP_TRY(ensure_buf(ctx, pack, bulk ? &ctx->pack_bulk_cap : &ctx->pack_cap, total));
   std::vector<Piece> pieces;
   std::vector<double*> pbuf(G.Pr);
   size_t off = 0;
   for (int r = 0; r < G.Pr; ++r) {
-    pbuf[r] = ctx->d_pack + off;
+    pbuf[r] = *pack + off;
     off += (size_t)nt[r] * TILE * cols;
     if (nt[r] == 0) continue;
     const int root = r * G.Pc + pcK;
@@ -373,10 +381,11 @@ static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid
     }
     pieces.push_back({root, pbuf[r], (size_t)nt[r] * TILE * cols});
   }
-  LPGP_TRY(bcast_pieces(ctx, st, pieces));
+  LPGP_TRY(bcast_pieces(ctx, st, pieces, bulk));
   for (int r = 0; r < G.Pr; ++r) {
     if (nt[r] == 0) continue;
     const int root = r * G.Pc + pcK;
+    if (root == ctx->rank && !with_self) continue;
     const double* src = pbuf[r];
     int64_t lds = (int64_t)nt[r] * TILE;
     if (root == ctx->rank && ctx->world <= 1) {
@@ -387,6 +396,24 @@ static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid
     hipLaunchKernelGGL(unpack_piece_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, out, ldo, src,
                        lds, G.Rof(r), l0[r], g_lo, rows);
   }
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out) {
+  return gather_rows(ctx, st, mat, G, T, c0, c1, g_lo, g_lo, T, true, false, out);
+}
+
+// This rank's OWN rows [g_lo, T) of tile columns [c0, c1) (it is a member of their process column) into the dense panel:
+// a local copy, no communication
+static int self_unpack(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out) {
+  (void)ctx;
+  const int l0 = cyc_before(G.R, g_lo), nt = cyc_before(G.R, T) - l0;
+  if (nt <= 0) return 0;
+  const int64_t ld = mat->lr_cap, rows = (int64_t)nt * TILE, cols = (int64_t)(c1 - c0) * TILE;
+  const double* src = mat->a + (int64_t)l0 * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+  hipLaunchKernelGGL(unpack_piece_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, out,
+                     (int64_t)(T - g_lo) * TILE, src, ld, G.R, l0, g_lo, rows);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
@@ -510,16 +537,51 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
   static const int fail_rank = [] { const char* e = std::getenv("LPGP_TEST_FAIL_RANK"); return e ? std::atoi(e) : -1; }();
   static const int fail_panel = [] { const char* e = std::getenv("LPGP_TEST_FAIL_PANEL"); return e ? std::atoi(e) : -1; }();
   int panel_steps = 0;
-  auto panel_part = [&](const Panel& p, int which) -> int {
+  // SPLIT GATHER (P x 1 grids, look-ahead on): the look-ahead update (a) of the next panel's columns reads, besides this
+  // rank's OWN solved rows, only the rows of the next panel's diagonal block -- one small exchange from their owner.  So
+  // the panel stream gathers just those (head), and the bulk of the panel (tail: S / P bytes per link, the longest item
+  // of the chain while the panel is long, scratch/dist_model.py) travels on the exchange stream through the second
+  // communicator, beside the chain, awaited only by the remainder update (b).
+  const bool split = la && G.Pc == 1 && ctx->split_gather != 0 && ctx->world > 1;
+  hipStream_t sC = sP;
+  if (split) {
+    if (!ctx->s_comm) {
+      int lo = 0, hi = 0;
+      LPGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_comm, hipStreamNonBlocking, hi));
+      for (int i = 0; i < 2; ++i) {
+        LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
+        LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_rows[i], hipEventDisableTiming));
+      }
+    }
+    sC = ctx->s_comm;
+  }
+  bool tail_pending[2] = {false, false};
+  // Panel step, part 1 (panel stream): diagonal block, rows below, gather into panel buffer `which`; head_end: first
+  // global tile row the look-ahead update does NOT need (end of the next panel), T without a next panel
+  auto panel_part = [&](const Panel& p, int which, int head_end) -> int {
     LPGP_CHECK(!(ctx->rank == fail_rank && panel_steps++ == fail_panel), "injected failure at panel step %d (LPGP_TEST_FAIL_PANEL)",
                fail_panel);
     const int pcK = (p.c0 / G.nbt) % G.Pc;
     if (p.fresh) LPGP_TRY(factor_diag_block(ctx, sP, mat, G, T, p.c0, p.c1));
+    tail_pending[which] = false;
     if (p.c1 >= T) return 0;
     if (G.my_c == pcK) LPGP_TRY(panel_rows_solve(ctx, sP, mat, G, p.c0, p.c1, cyc_before(G.R, row_lo(p)), LTr));
     LPGP_TRY(ensure_panel(ctx, which, (size_t)(T - p.c1) * TILE * (size_t)(p.c1 - p.c0) * TILE));
-    return gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, ctx->d_panel[which]);
+    double* out = ctx->d_panel[which];
+    if (!split) return gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, out);
+    LPGP_HIP(hipEventRecord(ctx->ev_rows[which], sP));           // the rows below the panel are final
+    LPGP_TRY(self_unpack(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, out));
+    LPGP_TRY(gather_rows(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, p.c1, head_end, false, false, out));
+    if (head_end < T) {
+      LPGP_HIP(hipStreamWaitEvent(sC, ctx->ev_rows[which], 0));   // (also orders the tail behind the last readers of this buffer)
+      LPGP_TRY(gather_rows(ctx, sC, mat, G, T, p.c0, p.c1, p.c1, head_end, T, false, true, out));
+      LPGP_HIP(hipEventRecord(ctx->ev_tail[which], sC));
+      tail_pending[which] = true;
+    }
+    return 0;
   };
+  auto head_end_of = [&](size_t i) { return i + 1 < panels.size() ? panels[i + 1].c1 : T; };
 
   bool have_upd = false;
   for (size_t i = 0; i < panels.size(); ++i) {
@@ -527,7 +589,7 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     const int which = (int)(i & 1);
     if (i == 0) {
       // the panel buffer about to be written was last read by the update two panels ago -- none yet
-      LPGP_TRY(panel_part(p, which));
+      LPGP_TRY(panel_part(p, which, head_end_of(i)));
     }
     if (p.c1 >= T) break;
     const double* panel = ctx->d_panel[which];
@@ -536,8 +598,9 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     const int rt0 = cyc_before(G.R, row_lo(p));
     const int ct0 = cyc_before(G.C, p.c1);
     if (!la || i + 1 >= panels.size()) {
+      if (tail_pending[which]) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_tail[which], 0));
       LPGP_TRY(update_local(ctx, sP, mat, G, panel, ldp, p.c1, K128, rt0, LTr, ct0, LTc, LPGP_K_SYRK));
-      if (i + 1 < panels.size()) LPGP_TRY(panel_part(panels[i + 1], which ^ 1));
+      if (i + 1 < panels.size()) LPGP_TRY(panel_part(panels[i + 1], which ^ 1, head_end_of(i + 1)));
       continue;
     }
     // look-ahead: (a) the next panel's own columns first, on the panel stream, followed at once by that panel's
@@ -545,16 +608,17 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     const Panel& q = panels[i + 1];
     const int cta = cyc_before(G.C, q.c0), ctb = cyc_before(G.C, q.c1);      // local columns of the next panel (empty off its process column)
     hipEvent_t evp = ctx->ev_panel[i & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));                                       // panel p is gathered
+    LPGP_HIP(hipEventRecord(evp, sP));                                       // panel p is gathered (split: its head)
     if (have_upd) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(i + 1) & 1], 0));   // (a)'s columns were last written by the previous (b)
     LPGP_TRY(update_local(ctx, sP, mat, G, panel, ldp, p.c1, K128, rt0, LTr, cta, ctb, LPGP_K_SYRK_AHEAD));
     LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+    if (tail_pending[which]) LPGP_HIP(hipStreamWaitEvent(sU, ctx->ev_tail[which], 0));   // (b) reads every row of the panel
     LPGP_TRY(update_local(ctx, sU, mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, LPGP_K_SYRK));
     LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sU));
     have_upd = true;
     // the next gather writes panel buffer which ^ 1, last read by (b) of panel i - 1: that update has been waited
     // for above (ev_upd[(i + 1) & 1]) before anything of this step was enqueued on the panel stream
-    LPGP_TRY(panel_part(q, which ^ 1));
+    LPGP_TRY(panel_part(q, which ^ 1, head_end_of(i + 1)));
   }
   if (have_upd) {
     LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));

@@ -132,6 +132,13 @@ struct lpgp_ctx {
   hipStream_t s_comm = nullptr;    // panel exchange (RCCL point-to-point group calls)
   hipEvent_t ev_comm[2] = {nullptr, nullptr};
   void* nccl_comm = nullptr;       // ncclComm_t
+  void* nccl_comm_bulk = nullptr;  // second communicator (ncclCommSplit of the first): the bulk of a split panel gather travels on it,
+                                   // beside the small exchanges of the panel chain (operations on ONE communicator are serialised)
+  hipEvent_t ev_tail[2] = {nullptr, nullptr};   // the bulk part of the gather into panel buffer 0 / 1 has landed
+  hipEvent_t ev_rows[2] = {nullptr, nullptr};   // the rows below panel i are solved (the bulk gather may read them)
+  int split_gather = 1;            // P x 1 grids with look-ahead: gather the next diagonal block's rows first, the rest off the chain
+  double* d_pack_bulk = nullptr;   // pack / receive buffer of the bulk part
+  size_t pack_bulk_cap = 0;
   lpgp_host_exchange_fn host_xfer = nullptr;   // test transport (lpgp_dist_init_host): panels staged through the host
   void* host_xfer_user = nullptr;
   // direct-peer transport (lpgp_dist_init_ipc): every rank owns a receive window in HBM, mapped into every peer by

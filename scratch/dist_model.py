@@ -19,13 +19,13 @@ def xfer(bytes_per_link):
     return LAT_US * 1e-6 + bytes_per_link / (LINK_GBS * 1e9)
 
 
-def step_time(n_side, P, Pr, Pc):
+def step_time(n_side, P, Pr, Pc, split=False):
     N = n_side * n_side + 4 * n_side
     M = (n_side // 2) ** 2
     T = -(-N // TILE)
     comm = P > 1
     # ---- factorisation ----
-    chain, b = [], []
+    chain, b, tail = [], [], []
     for p0 in range(0, T, NBT):
         p1 = min(T, p0 + NBT)
         w = p1 - p0
@@ -36,11 +36,17 @@ def step_time(n_side, P, Pr, Pc):
         t_rows = -(-int(rows_local / 16) // 512) * T_FUSED if r else 0.0
         S = r * TILE * w * TILE * 8.0
         t_gather = (xfer(S / Pr) + 2 * S / COPY) if comm else S / COPY
+        t_tail = 0.0
+        if split and comm and Pc == 1:
+            # head: own rows copied locally + the next diagonal block's rows from their owner; the rest (tail) beside the chain
+            t_tail = t_gather
+            t_gather = xfer((w * TILE) ** 2 * 8.0) + 2 * (S / Pr) / COPY
+        tail.append(t_tail)
         t_a = 2.0 * (r * TILE / Pr) * (w * TILE / Pc if Pc > 1 else w * TILE) * (w * TILE) / RATE_SMALL if r else 0.0
         chain.append(t_diag + t_bc + t_rows + t_gather + t_a)
         rr = max(r - NBT, 0)
         b.append((rr * (rr + 1) / 2.0) * 2.0 * TILE * TILE * (w * TILE) / P / RATE)
-    t_fact = chain[0] + sum(max(chain[i + 1], b[i]) for i in range(len(chain) - 1)) + b[-1]
+    t_fact = chain[0] + sum(max(chain[i + 1], b[i], tail[i]) for i in range(len(chain) - 1)) + b[-1]
     # ---- prediction: forward substitution of M / P columns per rank, factor streamed ----
     cols = M / P
     t_pred = 0.0
@@ -62,8 +68,10 @@ base = None
 print(f"assumed link {LINK_GBS:.0f} GB/s per direction per peer, {LAT_US:.0f} us per exchange")
 for P, grids in ((1, [(1, 1)]), (2, [(2, 1)]), (4, [(4, 1), (2, 2)]), (8, [(8, 1), (2, 4), (4, 2)])):
     for Pr, Pc in grids:
-        N, M, t, fl = step_time(sides[P], P, Pr, Pc)
-        v = fl / t / 1e12
-        if P == 1:
-            base = v
-        print(f"P={P} grid {Pr}x{Pc}: N_tot={N} M={M}  {t * 1e3:7.1f} ms  {v:6.1f} TFLOP/s  efficiency vs P x (1 GPU) = {v / (P * base):.2f}")
+        for split in ((False, True) if (P > 1 and Pc == 1) else (False,)):
+            N, M, t, fl = step_time(sides[P], P, Pr, Pc, split)
+            v = fl / t / 1e12
+            if P == 1:
+                base = v
+            print(f"P={P} grid {Pr}x{Pc}{' split gather' if split else '':13s}: N_tot={N} M={M}  {t * 1e3:7.1f} ms  {v:6.1f} TFLOP/s  "
+                  f"efficiency vs P x (1 GPU) = {v / (P * base):.2f}")
