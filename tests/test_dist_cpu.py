@@ -165,6 +165,42 @@ def _model_potrf_dist_2d(tiles, dblk, t_done, T, nbt, tb, pr, pc, rank, bcast):
                 X = sla.solve_triangular(LKK, A.T, lower=True).T
                 for j, gj in enumerate(range(c0, c1)):
                     tiles[(gi, gj)] = X[:, j * tb:(j + 1) * tb].copy()
+        nxt = min(T, (c1 // nbt + 1) * nbt)          # end of the next panel (panels never straddle a block)
+        if pc == 1 and pr > 1:
+            # SPLIT GATHER (P x 1 grids, dist.hip): the look-ahead update of the next panel's columns [c1, nxt) may read this
+            # rank's OWN rows and the rows of the next diagonal block ONLY -- `panel` holds nothing else at that point, so
+            # any other access raises KeyError -- and the rest of the panel arrives afterwards
+            panel = {gi: np.hstack([tiles[(gi, gj)] for gj in range(c0, c1)]) for gi in range(c1, T) if own_r(gi) == my_r}
+            root = own_r(c1) * pc + own_c(c0)
+            head = list(range(c1, nxt))
+            if rank == root:
+                send = np.stack([panel[gi] for gi in head])
+            else:
+                send = np.empty((len(head), tb, kw * tb))
+            for gi, P in zip(head, bcast(send, root)):
+                panel[gi] = P
+            for gi in range(row_lo, T):              # (a)
+                if own_r(gi) != my_r:
+                    continue
+                for gj in range(c1, min(nxt, gi + 1)):
+                    tiles[(gi, gj)] = tiles[(gi, gj)] - panel[gi] @ panel[gj].T
+            for r in range(pr):                      # tail: every member's rows beyond the next block
+                rows = [gi for gi in range(nxt, T) if own_r(gi) == r]
+                if not rows:
+                    continue
+                root = r * pc + own_c(c0)
+                if rank == root:
+                    send = np.stack([panel[gi] for gi in rows])
+                else:
+                    send = np.empty((len(rows), tb, kw * tb))
+                for gi, P in zip(rows, bcast(send, root)):
+                    panel.setdefault(gi, P)
+            for gi in range(row_lo, T):              # (b)
+                if own_r(gi) != my_r:
+                    continue
+                for gj in range(nxt, gi + 1):
+                    tiles[(gi, gj)] = tiles[(gi, gj)] - panel[gi] @ panel[gj].T
+            continue
         # gather the rows below the panel: one broadcast per source rank (r', process column of the panel)
         panel = {}
         for r in range(pr):
