@@ -375,6 +375,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_US_FIXED")) ctx->chain_us_fixed = std::atof(e);
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM_BAND")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ctx->gemm_band = v; }
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
@@ -389,6 +390,9 @@ int lpgp_init(int device, lpgp_ctx** out) {
 int lpgp_finalize(lpgp_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
+  if (ctx->nccl_comm && ctx->world > 1 && sync_stream(ctx, ctx->s_main) != 0) {
+    // (sync_stream has aborted the communicators: a kernel of this rank was still waiting for a peer that is gone)
+  }
   (void)hipDeviceSynchronize();
   for (auto& p : ctx->pending) {
     (void)hipEventDestroy(p.e0);
@@ -470,6 +474,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "fused_solve") == 0) {
     ctx->fused_solve = (int)value;
+  } else if (std::strcmp(key, "gemm3") == 0) {
+    ctx->gemm3 = value < 0 ? lpgp_ctx().gemm3 : (int)value;       // (negative: back to the built-in default)
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
   } else if (std::strcmp(key, "nb_solve") == 0) {
@@ -559,8 +565,17 @@ int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid12
     ncclComm_t bulk = nullptr;
     if (ncclCommSplit(comm, 0, rank, &bulk, nullptr) == ncclSuccess) ctx->nccl_comm_bulk = bulk;
   }
-  // every connection is made NOW, while all ranks are alive (see dist_warm_up); also the first check that data arrives
-  return dist_fail(ctx, dist_warm_up(ctx));
+  // every connection is made NOW, while all ranks are alive (see dist_warm_up, which also makes the ranks AGREE on the
+  // bulk communicator: all of them use it or none does); also the first check that data arrives
+  int rc = dist_fail(ctx, dist_warm_up(ctx));
+  if (rc != 0) {
+    // a failed bring-up leaves a plain single-GPU context behind (the caller may try another transport, or run replicas)
+    ctx->rank = 0;
+    ctx->world = 1;
+    if (!ctx->grid_set) ctx->pr = ctx->pc = 1;
+    ctx->dist_broken = 0;
+  }
+  return rc;
 }
 
 int lpgp_dist_init_host(lpgp_ctx* ctx, int32_t rank, int32_t world, lpgp_host_exchange_fn fn, void* user) {
@@ -723,7 +738,7 @@ int lpgp_mat_pop_block(lpgp_ctx* ctx, lpgp_mat* mat) {
   LPGP_CHECK(!mat->blocks.empty(), "lpgp_mat_pop_block: no block");
   const lpgp_block b = mat->blocks.back();
   LPGP_CHECK(b.poff >= mat->pn_fact, "lpgp_mat_pop_block: the last block is part of the factor");
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));      // nothing of a failed append still in flight
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));          // nothing of a failed append still in flight (watched: an exchange with a dead peer may be pending)
   mat->blocks.pop_back();
   mat->n -= b.n;
   mat->pn -= b.pn;
@@ -904,7 +919,7 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
   if (what == 1) LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_to_host: matrix is not (fully) factored");
   const int64_t pn = mat->pn, n = mat->n;
   std::vector<double> tmp((size_t)pn * pn);
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));       // assembly launches are asynchronous
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));           // assembly launches are asynchronous
   if (ctx->distributed()) {
     LPGP_CHECK(what == 1, "lpgp_mat_to_host: only the factor can be collected in a multi-GPU job");
     int rc = dist_fail(ctx, factor_to_host_dist(ctx, mat, tmp.data()));      // collective: the factor is streamed to every rank
@@ -933,7 +948,7 @@ int lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host) {
   const int64_t pn = mat->pn;
   if (pn == 0) return 0;
   std::vector<double> tmp((size_t)pn);
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
   if (ctx->distributed()) {
     // replicated diagonal blocks: block K at dblk + K nb^2, leading dimension nb
     const int64_t nb = ctx->nb;
@@ -1017,13 +1032,13 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
     // ranks end with the same weights, no further communication)
     void* pv = nullptr;
     const size_t vb = (size_t)pn * TILE * sizeof(double);
-    if (pool_alloc(ctx, &pv, vb, nullptr) != 0) return -1;
+    if (pool_alloc(ctx, &pv, vb, nullptr) != 0) return dist_fail(ctx, -1);      // (the peers are about to enter the streamed solve)
     double* dv = (double*)pv;
     hipError_t e = hipMemsetAsync(dv, 0, vb, ctx->s_main);
     if (e == hipSuccess) e = hipMemcpyAsync(dv, mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main);
     rc = dist_fail(ctx, e == hipSuccess ? trsm_lower_dist(ctx, mat, pn / TILE, dv, pn, TILE) : -1);
     if (rc == 0) rc = dist_fail(ctx, trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, TILE));
-    if (rc == 0 && hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) rc = -1;
+    if (rc == 0 && hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) rc = dist_fail(ctx, -1);
     pool_free(ctx, pv, vb);
   } else {
     rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);

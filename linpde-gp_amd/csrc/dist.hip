@@ -159,6 +159,15 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, &v, (int64_t)sizeof(int), 0) == 0, "ipc transport: barrier failed");
       return 0;
     };
+    // ONE window per rank, shared by the exchanges of every stream: with the split gather the head exchange (panel stream)
+    // queues its copy-out asynchronously and the tail exchange (exchange stream) follows at once -- before a peer may push
+    // into this window again, EVERY stream that can hold a pending copy-out is drained, not just `st`
+    auto drain = [&]() -> int {
+      LPGP_HIP(hipStreamSynchronize(st));
+      if (ctx->s_main != st) LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+      if (ctx->s_comm && ctx->s_comm != st) LPGP_HIP(hipStreamSynchronize(ctx->s_comm));
+      return 0;
+    };
     size_t i = 0;
     while (i < pieces.size()) {
       // one round: pieces [i, j) (a piece larger than the window travels in slices)
@@ -174,7 +183,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
         const Piece& p = pieces[i];
         for (size_t o = 0; o < p.count; o += ctx->ipc_window_doubles) {
           const size_t n = std::min(ctx->ipc_window_doubles, p.count - o);
-          LPGP_HIP(hipStreamSynchronize(st));
+          LPGP_TRY(drain());
           LPGP_TRY(barrier());
           if (p.root == ctx->rank) {
             for (int peer = 0; peer < ctx->world; ++peer)
@@ -189,7 +198,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
         ++i;
         continue;
       }
-      LPGP_HIP(hipStreamSynchronize(st));
+      LPGP_TRY(drain());
       LPGP_TRY(barrier());
       bool pushed = false;
       for (size_t q = i; q < j; ++q) {
@@ -274,6 +283,17 @@ int dist_warm_up(lpgp_ctx* ctx) {
   if (ctx->world <= 1 || !ctx->nccl_comm) return 0;
   hipStream_t st = ctx->s_main;
   const int W = ctx->world;
+  {
+    // ncclCommSplit is checked locally only: agree on its outcome (max over the ranks of "I have none") on the MAIN
+    // communicator, and drop the bulk communicator everywhere unless every rank got one -- ranks that disagree would
+    // post their bulk exchanges on different communicators and wait for each other until the watchdog fires
+    int none = ctx->nccl_comm_bulk ? 0 : 1;
+    LPGP_TRY(allreduce_max_int(ctx, st, &none));
+    if (none && ctx->nccl_comm_bulk) {
+      (void)ncclCommDestroy((ncclComm_t)ctx->nccl_comm_bulk);
+      ctx->nccl_comm_bulk = nullptr;
+    }
+  }
   double* d = nullptr;
   LPGP_HIP(hipMalloc(&d, (size_t)W * sizeof(double)));
   std::vector<double> h((size_t)W, -1.0);

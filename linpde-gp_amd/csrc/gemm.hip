@@ -427,6 +427,148 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 }
 
 // =========================================================================================
+// THREE workgroups per CU (round 3).  gemm_f64_kernel above holds 200 registers per lane and 73.7 KB of LDS: exactly two
+// workgroups per CU, and its own stamps say the matrix pipe is saturated only while both are in their k-loops (64-73 % of
+// the time at K = 512: a workgroup spends 13-15 us of its ~145 in the C prologue, and a lone workgroup drives the pipe at
+// 82 %).  This variant trades the register double-buffering of the fragments for a third resident workgroup:
+//   * K staged 8 deep, double-buffered: 2 x 2 x 8 x 144 x 8 B = 36 864 B of LDS (three fit in 160 KB);
+//   * 128 accumulator registers + ONE set of m-fragments (8) + two sets of n-fragments (16) + addresses <= 168, so that
+//     __launch_bounds__(256, 3) holds without spills: the m-fragments of the next k-step are re-loaded inside the last chunk
+//     of the current one, each right behind the four MFMAs that read it last (t-major order in that chunk); the LDS latency
+//     that is left is covered by the two other waves of the SIMD instead of by registers;
+//   * same operand image (M image, [k][LDM]), same swapped-operand accumulator layout, same tile enumerations, same epilogue.
+// NT form only (both operands with the non-contracted index fastest): the symmetric rank-nb updates of the factorisation.
+// =========================================================================================
+constexpr int BK3 = 8;
+constexpr int STAGE3 = BK3 * LDM;        // doubles per operand per stage
+
+__device__ __forceinline__ void dma_tile3(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0, int lane, int w,
+                                          double* sdst) {
+  const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int piece = q * 4 + w;                           // k-row, wave-uniform
+    const char* ub = reinterpret_cast<const char*>(P + idx0 + (k0 + piece) * ld);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * LDM), 16, 0, 0);
+  }
+}
+
+template <int TRI>
+__global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  double* sA = smem;                  // 2 stages
+  double* sB = smem + 2 * STAGE3;
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double*)smem);
+  const int KT = g.k / BK3;
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int wum = wu & 1, wun = wu >> 1;
+  const double alpha = g.alpha, beta = g.beta;
+
+  int tr, tc;
+  if (g.dense) {
+    if (!map_tile_dense<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
+  } else {
+    if (!map_tile<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
+  }
+  const unsigned laneM = lds_base + 8u * frag_lane_m<false>(lane, wm, 0);
+  const unsigned laneN = lds_base + (unsigned)(2 * STAGE3) * 8u + 8u * frag_lane_n<false>(lane, wn);
+
+  int64_t aidx = (int64_t)tr * BM, bidx = (int64_t)tc * BN;
+  if (TRI != 0 && g.cyc) {
+    aidx = (int64_t)(cyc_l2g(g.rowc, g.rt0 + tr) - g.g0) * BM;
+    bidx = (int64_t)(cyc_l2g(g.colc, g.ct0 + tc) - g.g0) * BN;
+  }
+  dma_tile3(g.A, g.lda, aidx, 0, lane, wu, sA);
+  dma_tile3(g.B, g.ldb, bidx, 0, lane, wu, sB);
+
+  char* const cub = reinterpret_cast<char*>(g.C + ((int64_t)tc * BN + wun * 64) * g.ldc + (int64_t)tr * BM + wum * 64);
+  const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldc + (unsigned)(lane & 15)) * 8u;
+  double acc[4][16];
+  if (beta != 0.0) {
+    const double sc_ = beta / alpha;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t][u] = sc_ * *reinterpret_cast<const double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[t][u] = 0.0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    {
+      const int knext = (kt + 1 < KT ? kt + 1 : kt) * BK3;      // (unconditional, see gemm_f64_kernel)
+      dma_tile3(g.A, g.lda, aidx, knext, lane, wu, sA + (cur ^ 1) * STAGE3);
+      dma_tile3(g.B, g.ldb, bidx, knext, lane, wu, sB + (cur ^ 1) * STAGE3);
+    }
+    const unsigned stoff = (unsigned)(cur * STAGE3) * 8u;
+    const unsigned aM = laneM + stoff, aN = laneN + stoff;
+    double am[4], bn[2][4];
+    asm volatile("" ::: "memory");
+    static_for<0, 4>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      am[t] = lds_read_async<frag_imm_m<false>(0, t)>(aM);
+    });
+    static_for<0, 4>([&](auto V_) {
+      constexpr int vv = decltype(V_)::value;
+      bn[0][vv] = lds_read_async<frag_imm_n<false>(0, vv)>(aN);
+    });
+    // 8 chunks of 16 MFMAs per stage (2 k-steps x 4 groups of 4 n-fragments); LDS operations return in order:
+    // at the top of chunk c the n-fragments of chunk c + 1 are issued, and "all but the newest four" covers this chunk's
+    // n-fragments and, after a k-step boundary, the re-loaded m-fragments
+    static_for<0, 8>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      constexpr int ks = c >> 2, uc = c & 3, cb = c & 1;
+      if constexpr (c + 1 < 8) {
+        constexpr int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
+        static_for<0, 4>([&](auto V_) {
+          constexpr int vv = decltype(V_)::value;
+          bn[cb ^ 1][vv] = lds_read_async<frag_imm_n<false>(ks2, uc2 * 4 + vv)>(aN);
+        });
+        LDS_WAIT(4);
+      } else {
+        LDS_WAIT(0);
+      }
+      if constexpr (uc == 3 && c + 1 < 8) {
+        // last chunk of a k-step: m-fragment by m-fragment, each re-loaded for the next k-step behind its last reader
+        static_for<0, 4>([&](auto T_) {
+          constexpr int t = decltype(T_)::value;
+#pragma unroll
+          for (int vv = 0; vv < 4; ++vv)
+            acc[t][uc * 4 + vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[cb][vv], am[t], acc[t][uc * 4 + vv], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          am[t] = lds_read_async<frag_imm_m<false>(ks + 1, t)>(aM);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[t][uc * 4 + vv] = __builtin_amdgcn_mfma_f64_4x4x4f64(bn[cb][vv], am[t], acc[t][uc * 4 + vv], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
+}
+
+// =========================================================================================
 // 64 x 64 tile variant for launches that cannot fill the chip with 128 x 128 tiles: the
 // latency-bound steps of the panel chain (rank-128 solves and updates with 8 ... 100 tiles)
 // and the trailing updates of the last panels.  One 128 x 128 x K tile occupies a CU's four
@@ -595,10 +737,25 @@ static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   return 0;
 }
 
+// the kernel of a launch: the three-resident variant for the NT form when the context asks for it (LPGP_GEMM3)
+template <bool TA, bool TB, int TRI>
+static void pick_kernel(const lpgp_ctx* ctx, void (**fn)(GemmArgs), size_t* shmem) {
+  *fn = gemm_f64_kernel<TA, TB, TRI>;
+  *shmem = (size_t)4 * STAGE * sizeof(double);                  // 73 728 B: two workgroups per CU
+  if constexpr (!TA && !TB && TRI != 2) {
+    if (ctx->gemm3) {
+      *fn = gemm3_f64_kernel<TRI>;
+      *shmem = (size_t)4 * STAGE3 * sizeof(double);             // 36 864 B: three workgroups per CU
+    }
+  }
+}
+
 template <bool TA, bool TB, int TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
-  const size_t shmem = (size_t)4 * STAGE * sizeof(double);      // 73 728 B: two workgroups per CU
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm_f64_kernel<TA, TB, TRI>), shmem));
+  void (*kfn)(GemmArgs) = nullptr;
+  size_t shmem = 0;
+  pick_kernel<TA, TB, TRI>(ctx, &kfn, &shmem);
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(kfn), shmem));
   GemmArgs ga = g;
   const int BANDR = ctx->gemm_band;
   ga.band = BANDR;
@@ -625,7 +782,7 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     }
     if (ga.ntiles == 0) return 0;                    // (distributed update: no valid tile in this rank's region)
     ga.chunk = (ga.ntiles + 7) / 8;
-    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)(8 * ga.chunk)), dim3(256), shmem, stream, ga);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * ga.chunk)), dim3(256), shmem, stream, ga);
     LPGP_HIP(hipGetLastError());
     return 0;
   }
@@ -644,7 +801,7 @@ static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
     if (nsuper >= ctx->min_supertiles) break;      // enough super-tiles per XCD to balance the 8 XCDs
   }
   const int64_t nvirtual = (int64_t)((nsuper + 7) / 8) * 8 * SS;
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, TRI>), dim3((unsigned)nvirtual), dim3(256), shmem, stream, ga);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)nvirtual), dim3(256), shmem, stream, ga);
   LPGP_HIP(hipGetLastError());
   return 0;
 }

@@ -106,6 +106,7 @@ struct lpgp_ctx {
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
+  int gemm3 = 0;                   // NT-form GEMM / SYRK launches use the three-workgroups-per-CU kernel (gemm3_f64_kernel)
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
   // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,

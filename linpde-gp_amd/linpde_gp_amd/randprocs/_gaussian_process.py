@@ -225,6 +225,13 @@ class _DeviceState:
         self.weights_key = None
         self.residual_key = None
 
+    def invalidate(self) -> None:
+        """The device dropped the resident representer weights / residual (`lpgp_mat_add_block`, `lpgp_mat_pop_block`
+        and a growing matrix all clear them): forget which object they belonged to."""
+        self.view = None
+        self.weights_key = None
+        self.residual_key = None
+
     def use(self, nblocks: int) -> None:
         """Make the leading `nblocks` blocks the matrix every following call sees."""
         if nblocks == 0:
@@ -259,6 +266,7 @@ class ConditionalGaussianProcess(GaussianProcess):
         mat = state.mat
         base = prior.cov
         bi = mat.add_block(new_block.points.n)
+        state.invalidate()           # also on the rollback paths below: the parent's next predict must solve again
         assert bi == len(old_blocks)
         try:
             info = cls._assemble_and_factor(mat, base, bi, old_blocks, new_block)
@@ -275,7 +283,6 @@ class ConditionalGaussianProcess(GaussianProcess):
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
         blocks = tuple(old_blocks) + (new_block,)
-        state.view = None
         # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
         # in a chain of conditionings only the last object's weights are ever needed
         return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)

@@ -7,7 +7,9 @@ posterior criterion of tests/conftest.py (`assert_posterior_close`: 1e-8 relativ
   c3  2-D Poisson 128x128 + 4x128, M = 64x64  (the metric's config)       vs oracle AT FULL SIZE (slow)
   c4  2-D Poisson 256x256 + 4x256                                         size-independent properties
   c5  heat 1-D space-time, mixed blocks:  N_tot = 9 024                   vs oracle
-                                          N_tot = 33 600 (full size)      properties + analytic solution
+                                          N_tot = 33 600 (full size)      properties + analytic solution, and
+                                                                          vs oracle AT FULL SIZE (slow, ~1 min of host time)
+  c4  at full size vs the oracle: tests/test_gpu_zz_c4_full.py (runs last: ~5 min of host time)
 (reference test being mirrored: tests/linpde_gp/randprocs/test_posterior_gp.py:152-178,
 tests/linpde_gp/problems/test_heat.py:56-99.)  c4 / c5 on several GPUs: tests/test_gpu_dist.py.
 """
@@ -114,6 +116,27 @@ def test_c5_heat_full_size_properties(lp):
     assert np.max(np.abs(res)) < 1e-6
     sol = np.exp(-0.1 * (np.pi / 2.0) ** 2 * wl.Xtest[:, 0]) * np.sin(np.pi * (wl.Xtest[:, 1] + 1.0) / 2.0)
     assert np.max(np.abs(mean - sol)) < 3e-2
+
+
+@pytest.mark.slow
+def test_c5_heat_full_size_vs_oracle(lp):
+    """c5 at FULL size (N_tot = 33 600, M = 4 096) against the oracle (`oracle.workloads.run_in_place`: 9 GB factor, LAPACK
+    dpotrf + dtrtrs on the host cores), mean and variance on the whole prediction grid with the one criterion."""
+    import os
+    import psutil
+    from linpde_gp_amd import problems
+    wl = problems.heat_1d()
+    assert wl.n_total == 33600 and wl.Xtest.shape[0] == 4096
+    workers = max(1, min(16, (os.cpu_count() or 1) // 8))
+    need = owl.host_memory_needed(wl, 1024, workers)
+    if psutil.virtual_memory().available < 1.2 * need:
+        pytest.skip(f"full-size oracle needs {need / 1e9:.0f} GB of host memory")
+    u, mean, var = _run(lp, wl)
+    del u
+    ref = owl.run_in_place(wl, chunk=1024, workers=workers)
+    rm, rv = assert_posterior_close(mean, var, ref["mean"], ref["var"])
+    print(f"{wl.name}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} mean err {rm:.2e} x tol, var err {rv:.2e} x tol; "
+          f"oracle {ref['seconds']['total']:.1f} s ({workers} assembly threads)")
 
 
 def test_c4_poisson2d_256_properties(lp):

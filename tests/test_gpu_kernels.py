@@ -20,13 +20,16 @@ def test_probes(ctx):
     assert tf > 10.0 and gb > 500.0
 
 
-@pytest.fixture(params=["tile128", "tile64"])
+@pytest.fixture(params=["tile128", "tile64", "tile128x3"])
 def gemm_kernel(ctx, request):
-    """Both GEMM kernels: launches with at most `small_tiles_max` 128x128 tiles run on the
-    64x64-tile kernel (default 256); 0 forces the 128x128-tile kernel."""
-    ctx.set_option("small_tiles_max", 0 if request.param == "tile128" else 1 << 20)
+    """All GEMM kernels: launches with at most `small_tiles_max` 128x128 tiles run on the
+    64x64-tile kernel (default 256); 0 forces the 128x128-tile kernel; "tile128x3": the NT form on the
+    three-workgroups-per-CU kernel (`gemm3_f64_kernel`, option `gemm3`), whatever the default is."""
+    ctx.set_option("small_tiles_max", 1 << 20 if request.param == "tile64" else 0)
+    ctx.set_option("gemm3", {"tile128": 0, "tile64": 0, "tile128x3": 1}[request.param])
     yield request.param
     ctx.set_option("small_tiles_max", 256)
+    ctx.set_option("gemm3", -1)
 
 
 @pytest.mark.parametrize("k", [16, 80, 512])
@@ -55,7 +58,7 @@ def test_syrk_lower_only(ctx, gemm_kernel):
     C0 = rng.standard_normal((n, n))
     out, _ = _engine.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k)
     ref = C0 - P @ P.T
-    edge = 128 if gemm_kernel == "tile128" else 64
+    edge = 64 if gemm_kernel == "tile64" else 128
     tile = np.arange(n) // edge
     lower_tiles = tile[:, None] >= tile[None, :]
     np.testing.assert_allclose(out[lower_tiles], ref[lower_tiles], rtol=1e-12, atol=1e-10)

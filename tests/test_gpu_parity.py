@@ -487,6 +487,11 @@ def test_failed_conditioning_leaves_the_parent_intact(lp):
     u1 = prior.condition_on_observations(Y1, X1, b=noise)
     post1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
     Xt = np.linspace(-1, 1, 7)[:, None]
+    # the parent has predicted (weights and residual are resident and keyed to it) BEFORE the failure (the
+    # rollback clears them on the device, so the host must forget them as well)
+    m0, v0 = u1.predict(Xt)
+    assert _rel(m0, post1.mean(Xt)) < 1e-8
+    assert _rel(u1.mean(Xt), post1.mean(Xt)) < 1e-8
     Xbad = np.array([[0.2], [0.2], [0.5]])           # duplicated point and negative noise: not PD
     with pytest.raises(np.linalg.LinAlgError):
         u1.condition_on_observations(np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
@@ -494,6 +499,7 @@ def test_failed_conditioning_leaves_the_parent_intact(lp):
         u1.condition_on_observations(np.zeros(4), Xbad)
     m, v = u1.predict(Xt)
     assert _rel(m, post1.mean(Xt)) < 1e-8 and np.max(np.abs(v - post1.var(Xt))) < 1e-9
+    assert _rel(u1.mean(Xt), post1.mean(Xt)) < 1e-8          # the mean-only path (representer weights)
     np.testing.assert_allclose(u1.representer_weights, post1.weights, rtol=1e-7, atol=1e-9)
     # and the parent can still be extended
     X2, Y2 = np.array([[0.31], [-0.62]]), np.array([0.1, 0.2])

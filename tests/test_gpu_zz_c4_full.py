@@ -1,0 +1,45 @@
+"""c4 (BASELINE.json config 4: 2-D Poisson-Dirichlet, 256 x 256 collocation + 4 x 256 boundary observations, N_tot = 66 560:
+a 35.4 GB Gram matrix) on one GPU AT FULL SIZE against the CPU oracle, mean and variance on a 64 x 64 prediction grid with
+the one criterion of tests/conftest.py (1e-8 of max |mean| / max |var|).
+
+The oracle (`oracle.workloads.run_in_place`: chunked NumPy assembly into ONE column-major array, LAPACK dpotrf in place,
+dtrtrs overwriting K^T) needs ~60 GB of host memory and ~9.8e13 flop of LAPACK: about five minutes on the GPU box's 256
+host cores -- hence a file of its own whose name sorts LAST in the suite.  On a host with fewer than 128 cores or less
+than 160 GB of free memory the same test runs at 192 x 192 (N_tot = 37 632) and says so.
+(SURVEY.md §8d sizes; reference test mirrored: tests/linpde_gp/randprocs/test_posterior_gp.py:152-178.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_posterior_close
+from oracle import workloads as owl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.slow
+def test_c4_poisson2d_256_full_size_vs_oracle():
+    import psutil
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import problems
+    cores, avail = os.cpu_count() or 1, psutil.virtual_memory().available
+    full = cores >= 128 and avail >= 160e9
+    wl = problems.poisson_2d(256 if full else 192, m_side=64)
+    assert wl.n_total == (66560 if full else 37632) and wl.Xtest.shape[0] == 4096
+    workers = max(1, min(16, cores // 8))
+    need = owl.host_memory_needed(wl, 512, workers)
+    if avail < 1.2 * need:
+        pytest.skip(f"the oracle at N_tot = {wl.n_total} needs {need / 1e9:.0f} GB of host memory, {avail / 1e9:.0f} GB free")
+    lp.config.gram_capacity_hint = wl.n_total
+    try:
+        u, mean, var = problems.condition_and_predict(wl)
+    finally:
+        lp.config.gram_capacity_hint = 0
+    del u
+    ref = owl.run_in_place(wl, chunk=512, workers=workers)
+    rm, rv = assert_posterior_close(mean, var, ref["mean"], ref["var"])
+    print(f"{wl.name}{'' if full else ' (REDUCED: host too small for 256 x 256)'}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} "
+          f"mean err {rm:.2e} x tol, var err {rv:.2e} x tol; oracle {ref['seconds']} ({workers} assembly threads, {cores} cores)")
+    assert abs(mean.max() - 0.5894) < 1e-2
