@@ -9,17 +9,32 @@ conditioning (Gram/cross-block assembly, blocked Cholesky with block append, rep
 weights) + prediction (cross-covariance assembly, posterior mean, marginal variance).
 Point sets are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
+Order of a run at N = 1: the CPU baseline (the oracle on the bench workload itself, ~30 s of host time) FIRST, then
+the GPU section in one piece (warm-up, timed region, per-phase stamps, per-kernel HIP-event passes), so that the
+device is busy in one contiguous stretch.
+
 N > 1 (launched by `python -m torch.distributed.run`, env RANK/LOCAL_RANK/WORLD_SIZE/
 MASTER_ADDR/MASTER_PORT): one process per GPU, all ranks factor ONE problem whose Gram matrix is
-sharded in 2-D block-cyclic tiles over a Pr x Pc process grid ($LPGP_GRID, default Pr = N, Pc = 1); panels
-travel as grouped RCCL point-to-point sends over xGMI, prediction points are sharded over the ranks
-(DESIGN.md §7).  The problem grows with N so that the algorithmic flops PER GPU stay those of c3
-("scaling": "weak": grid side 128 -> 144 / 162 / 182 at 2 / 4 / 8 GPUs, prediction grid side = half of
-it; c3 itself is 33 ms of factorisation, far too small to shard).  LPGP_BENCH_STRONG=1 shards c3
-itself ("strong"); LPGP_BENCH_REPLICAS=1 runs one independent c3 per rank.
+sharded in 2-D block-cyclic tiles over a Pr x Pc process grid; panels travel as grouped RCCL
+point-to-point sends over xGMI, prediction points are sharded over the ranks.
+The problem grows with N so that the algorithmic flops PER GPU stay those of c3 ("scaling": "weak": grid side
+128 -> 144 / 162 / 182 at 2 / 4 / 8 GPUs, prediction grid side = half of it; c3 itself is 33 ms of
+factorisation, far too small to shard).  Before the timed region the run CALIBRATES itself, because the
+builder never had more than one GPU: `config.link_probe` (measured GB/s of every ordered pair of ranks, of one
+rank sending to all, of all to all, through the transport the panels use) and `config.trials` (the same
+workload for two steps each on the P x 1 grid with the split panel gather, on the P/2 x 2 grid, and on
+P x 1 with one ncclBroadcast per panel piece instead of the point-to-point group; the fastest variant runs
+the timed region; LPGP_GRID / LPGP_DIST_COLLECTIVE pin a variant and skip the trials).  After the timed
+region the run also factors the BASELINE configuration named for that GPU count -- c4 (256 x 256, N_tot =
+66 560) at 8 GPUs, c5 (heat, N_tot = 33 600) at 4 and 2 -- reported under `configs` with size-independent
+parity properties (LPGP_BENCH_EXTRA=c4,c5 / none overrides the choice).
+LPGP_BENCH_STRONG=1 shards c3 itself ("strong"); LPGP_BENCH_REPLICAS=1 runs one independent c3 per rank.
 The product path never imports torch; ranks rendezvous over a plain TCP star.
 """
 import argparse
+import gc
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -34,6 +49,7 @@ import numpy as np  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor datasheet)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+ROOFLINE_SLOT = "syrk_trailing"
 
 
 def _blas_info():
@@ -73,7 +89,7 @@ def cpu_baseline(problems, wl, sample_side=0):
         "cores": threads,
         "kind": "port",
         "sample": (f"{what}: {w.name}, N_tot={w.n_total}, M={w.Xtest.shape[0]}; NumPy/SciPy oracle, BLAS={blas} "
-                   f"({threads} threads; the NumPy assembly is single-threaded); {sec['total']:.2f} s total"),
+                   f"({threads} threads; the NumPy assembly is single-threaded); {sec['total']:.2f} s total, timed before the GPU section"),
         "n_total": int(w.n_total),
         "seconds": sec["total"],
         "phase_seconds": {k: v for k, v in sec.items() if k != "total"},
@@ -100,6 +116,35 @@ def parity_report(mean, var, ref, wl):
     }
 
 
+def parity_by_properties(problems, wl, u, mean, var):
+    """Size-independent checks for configurations whose oracle does not fit a bench run (c4: 380 s of host time; the
+    full-size comparisons are tests/test_gpu_zz_c4_full.py and test_gpu_configs.py::test_c5_heat_full_size_vs_oracle):
+    residual of G w = r on re-evaluated rows of the collocation block, variance inside [0, k(x,x)], the closed-form
+    solution where there is one (c5: the reference's own accuracy bar, test_heat.py:25-28), the known maximum of the
+    Poisson solution (c3 / c4).  Collective in a multi-GPU job."""
+    kxx = float(sum(sc for sc, _ in wl.kernel))
+    big = max(o.X.shape[0] for o in wl.observations)
+    rows = np.unique(np.array([0, big // 3 + 17, big // 2 + 5, big - 1]))
+    res = float(np.max(np.abs(problems.row_residual(u, wl, rows))))
+    ymax = float(max(np.max(np.abs(o.Y)) for o in wl.observations))
+    out = {"finite": bool(np.all(np.isfinite(mean)) and np.all(np.isfinite(var))),
+           "var_min": float(np.min(var)), "var_max": float(np.max(var)), "prior_var": kxx,
+           "var_in_bounds": bool(np.all(var > -1e-9 * kxx) and np.all(var < kxx)),
+           "gram_row_residual_max": res, "gram_row_residual_tol": 1e-5 * max(ymax, 1.0)}
+    ok = out["finite"] and out["var_in_bounds"] and res < out["gram_row_residual_tol"]
+    sol = problems.analytic_solution(wl)
+    if sol is not None:
+        out["analytic_solution_max_err"] = float(np.max(np.abs(mean - sol)))
+        out["analytic_solution_tol"] = 3e-2
+        ok = ok and out["analytic_solution_max_err"] < 3e-2
+    elif wl.name.startswith("poisson2d"):
+        out["mean_max"] = float(np.max(mean))
+        out["mean_max_expected"] = 0.5894          # max of the solution of -Lap u = 2, u = 0 on the boundary of [-1,1]^2
+        ok = ok and abs(out["mean_max"] - 0.5894) < 1e-2
+    out["pass"] = bool(ok)
+    return out
+
+
 def _weak_sides(world):
     """Grid side whose algorithmic flops (Workload.algorithmic_work: N^3/3 + 2N^2 + N^2 M + 4NM,
     N = n^2 + 4n, M = (n/2)^2) are closest to world x those of c3; m_side = n_side / 2."""
@@ -111,26 +156,50 @@ def _weak_sides(world):
     return best, best // 2
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of the SAME
-    command (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; the passes are collected by
-    scratch/collect_profiles.sh, which records the command it ran); newest round first, None if absent."""
-    for name in ("r02_bench_c3_summary.json", "r01_bench_c3_summary.json"):
+def csrc_sha16():
+    """Identity of the kernel sources this process runs (the built library follows them: __graft_entry__.build()):
+    sha256 over csrc/*.hip|h|cpp and include/*.h, first 16 hex digits."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "linpde-gp_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "linpde-gp_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "linpde-gp_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(sha, kernel_symbol):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of the SAME command
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; scratch/collect_profiles.sh collects them and records
+    the command and the source identity it ran on).  A summary collected on OTHER kernel sources is not reported as
+    `traffic` (it is named under `traffic_stale`)."""
+    out = {"traffic": None, "traffic_source": None}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c3_summary.json")), reverse=True):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                v = json.load(f).get("syrk_hbm_bytes_per_launch")
-            if v is not None:
-                return v
+            with open(path) as f:
+                summ = json.load(f)
         except Exception:
             continue
-    return None
+        v = summ.get("syrk_hbm_bytes_per_launch")
+        if v is None:
+            continue
+        at = (summ.get("bench_line") or {}).get("config", {}).get("csrc_sha16")
+        rel = os.path.relpath(path, ROOT)
+        if at == sha and kernel_symbol.split("(")[0].strip() in (summ.get("syrk_kernel") or ""):
+            return {"traffic": v, "traffic_source": rel, "traffic_collected_at_csrc": at,
+                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command on these kernel sources; (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch"}
+        out.setdefault("traffic_stale", {"value": v, "source": rel, "collected_at_csrc": at, "running_csrc": sha,
+                                          "kernel": summ.get("syrk_kernel"),
+                                          "note": "collected on other kernel sources (or another roofline kernel) than the running tree: not reported as `traffic`"})
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-side", type=int, default=128, help="collocation grid side (c3: 128)")
     ap.add_argument("--m-side", type=int, default=64, help="prediction grid side (c3: 64)")
     ap.add_argument("--cpu-side", type=int, default=0,
@@ -156,6 +225,21 @@ def main():
     import linpde_gp_amd as lp
     from linpde_gp_amd import _dist, _engine, problems
 
+    def make_workload(n_side, m_side):
+        if args.workload == "poisson1d":
+            return problems.poisson_1d()            # c2
+        if args.workload == "heat1d":
+            return problems.heat_1d()               # c5
+        return problems.poisson_2d(n_side=n_side, m_side=m_side)
+
+    # ---- CPU baseline FIRST (N = 1 only): the host cores are idle, and the GPU section afterwards is one busy stretch ----
+    cpu_json, ref = None, None
+    if world == 1 and not args.no_cpu:
+        cpu_json, ref = cpu_baseline(problems, make_workload(args.n_side, args.m_side), args.cpu_side)
+    elif world == 1 and args.check:
+        from oracle import workloads as owl
+        ref = owl.run(make_workload(args.n_side, args.m_side), want_cond=True)
+
     comm = _dist.Comm.from_env()
     ctx = _engine.default_context()          # device = LOCAL_RANK
     replicas = bool(int(os.environ.get("LPGP_BENCH_REPLICAS", "0")))
@@ -179,9 +263,11 @@ def main():
     if world > 1 and not replicas:
         # RCCL communicator: distributed factorisation of ONE problem.  If the communicator cannot be created (on every
         # rank alike) the run falls back to the direct-peer transport (IPC-mapped windows, device-to-device pushes), and
-        # if that cannot be set up either, to independent replicas -- and says so.
+        # if that cannot be set up either, to independent replicas -- and says so.  (A failed lpgp_dist_init leaves a
+        # plain single-GPU context behind, so the next attempt starts clean.)
         # LPGP_DIST_TRANSPORT=ipc selects the direct-peer transport; =host: bring-up on a box whose ranks share one GPU
         # (messages staged through the host; never a benchmark configuration)
+        first_err = ""
         for attempt in ([transport, "ipc"] if transport == "rccl" else [transport]):
             try:
                 ctx.dist_init(comm, transport=attempt)
@@ -191,18 +277,20 @@ def main():
             oks = comm.allgather((ok, err))
             if all(o for o, _ in oks):
                 if attempt != transport:
-                    dist_note_fallback = f"RCCL communicator creation failed ({first_err[:160]}): direct-peer (IPC) transport instead"
-                    sys.stderr.write("bench.py: " + dist_note_fallback + "\n") if rank == 0 else None
+                    dist_note = f"RCCL communicator creation failed ({first_err[:160]}): direct-peer (IPC) transport instead; "
+                    if rank == 0:
+                        sys.stderr.write("bench.py: " + dist_note + "\n")
                 transport = attempt
                 break
             if any(o for o, _ in oks):
                 raise SystemExit(f"{attempt} transport set up on some ranks only: " + "; ".join(e for o, e in oks if not o))
-            first_err = oks[0][1]
+            first_err = first_err or next(e for _, e in oks if e)
         else:
             replicas = True
             dist_note = "communicator creation failed (" + first_err[:200] + "): independent replicas instead"
             if rank == 0:
                 sys.stderr.write("bench.py: " + dist_note + "\n")
+    distributed = world > 1 and not replicas
     info = ctx.device_info()
     # RCCL prints a version banner through C stdio when a communicator is created; on a pipe it would leave the
     # buffer only at exit, i.e. AFTER the JSON line.  Push it out now, on every rank.
@@ -211,35 +299,65 @@ def main():
     _libc.fflush(None)
 
     n_side, m_side = args.n_side, args.m_side
-    weak = world > 1 and not replicas and not strong and (n_side, m_side) == (128, 64)
+    weak = distributed and not strong and (n_side, m_side) == (128, 64) and args.workload == "poisson2d"
     if weak:
         n_side, m_side = _weak_sides(world)
-    if args.workload == "poisson1d":
-        wl = problems.poisson_1d()            # c2
-    elif args.workload == "heat1d":
-        wl = problems.heat_1d()               # c5
-    else:
-        wl = problems.poisson_2d(n_side=n_side, m_side=m_side)
+    wl = make_workload(n_side, m_side)
+
+    def timed_steps(w, prior_, dev_, k):
+        """k steps bracketed by barrier + device sync on both sides; seconds, max over ranks."""
+        comm.barrier()
+        ctx.sync()
+        t0_ = time.perf_counter()
+        out_ = None
+        for _ in range(k):
+            out_ = None          # drop the previous posterior BEFORE the next step allocates its factor (the pool then reuses the buffer)
+            out_ = problems.condition_and_predict(w, prior=prior_, device_arrays=dev_)
+        ctx.sync()
+        dt_ = comm.allreduce_max(time.perf_counter() - t0_)
+        comm.barrier()
+        return dt_, out_
+
+    # ---- first contact with a real fabric: measure it, then let the measurement pick the variant ----
+    link_probe, trials, chosen = None, None, None
+    if distributed and transport != "host":
+        try:
+            link_probe = ctx.link_probe(32 << 20, 3)
+        except Exception as exc:                # noqa: BLE001
+            link_probe = {"error": f"{type(exc).__name__}: {exc}"}
+    pinned = "LPGP_GRID" in os.environ or "LPGP_DIST_COLLECTIVE" in os.environ or bool(int(os.environ.get("LPGP_BENCH_NO_TRIALS", "0")))
+    if distributed and world >= 4 and world % 2 == 0 and not pinned:
+        variants = [("Px1_p2p_split", (world, 1), 0), ("P/2x2_p2p", (world // 2, 2), 0), ("Px1_bcast", (world, 1), 1)]
+        trials = {}
+        lp.config.gram_capacity_hint = wl.n_total
+        for name, grid, bc in variants:
+            ctx.dist_set_grid(*grid)
+            ctx.set_option("dist_bcast", bc)
+            dev_t = problems.upload(wl)
+            prior_t = problems.build_prior(wl)
+            problems.condition_and_predict(wl, prior=prior_t, device_arrays=dev_t)       # untimed: allocation, connections
+            dt_t, _ = timed_steps(wl, prior_t, dev_t, 2)
+            trials[name] = {"grid": list(grid), "collective": "bcast" if bc else "p2p", "ms_per_step": dt_t / 2 * 1e3}
+            del dev_t, prior_t
+            gc.collect()
+        chosen = min(trials, key=lambda k_: trials[k_]["ms_per_step"])
+        _, grid, bc = next(v for v in variants if v[0] == chosen)
+        ctx.dist_set_grid(*grid)
+        ctx.set_option("dist_bcast", bc)
+
     lp.config.gram_capacity_hint = wl.n_total
     dev = problems.upload(wl)                # point sets resident in HBM before timing
     prior = problems.build_prior(wl)
 
     def step():
-        u, mean, var = problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
-        return mean, var
+        u_, mean_, var_ = problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
+        return mean_, var_
 
     for _ in range(args.warmup):
         mean, var = step()
     # ---- timed region: exactly K steps, no instrumentation ----
-    comm.barrier()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mean, var = step()
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    dt = comm.allreduce_max(dt)
-    comm.barrier()
+    dt, last = timed_steps(wl, prior, dev, args.steps)
+    _, mean, var = last
     # ---- the two phases of a step (un-instrumented steps; the conditioning phase ends with the read-back of the
     #      factorisation status, so a host stamp between the phases costs nothing): max over ranks ----
     ph = []
@@ -265,27 +383,60 @@ def main():
                 p_[k_] = p_[k_] * (args.steps / prof_steps)
         return out_
 
-    prof_syrk = profiled(["syrk_trailing"])      # dominant kernel alone: least perturbation
+    prof_syrk = profiled([ROOFLINE_SLOT])        # dominant kernel alone: least perturbation
     ctx.dist_stats(reset=True)
     prof = profiled(True)                        # every kernel (table)
-    prof["syrk_trailing"] = prof_syrk["syrk_trailing"]
+    prof[ROOFLINE_SLOT] = prof_syrk[ROOFLINE_SLOT]
     # per-rank communication of the table pass: bytes and seconds inside panel exchanges (HIP events on the stream
     # the exchange is enqueued on), gathered so that the driver's scaling curve can be read
     cs = ctx.dist_stats()
     comm_rows = comm.gather([float(cs["bytes_sent"]) / prof_steps, float(cs["bytes_received"]) / prof_steps,
                              float(prof["comm"]["ms"]) / args.steps])
 
+    # ---- the BASELINE configuration named for this GPU count, on the same ranks (collective: every rank runs it) ----
+    extra = os.environ.get("LPGP_BENCH_EXTRA")
+    if extra is None:
+        extra = {8: "c4", 4: "c5", 2: "c5"}.get(world, "none") if (distributed and weak) else "none"
+    configs = {}
+    del dev, prior
+    gc.collect()
+    for name in [e for e in extra.split(",") if e and e != "none"]:
+        w2 = {"c4": lambda: problems.poisson_2d(n_side=256, m_side=128), "c5": problems.heat_1d,
+              "c3": problems.poisson_2d, "c2": problems.poisson_1d}[name]()
+        lp.config.gram_capacity_hint = w2.n_total
+        dev2, prior2 = problems.upload(w2), problems.build_prior(w2)
+        problems.condition_and_predict(w2, prior=prior2, device_arrays=dev2)             # untimed: allocation
+        ctx.dist_stats(reset=True)
+        k2 = 2 if name == "c4" else 3
+        dt2, (u2, mean2, var2) = timed_steps(w2, prior2, dev2, k2)
+        cs2 = ctx.dist_stats()
+        comm2 = comm.gather([float(cs2["bytes_sent"]) / k2, float(cs2["bytes_received"]) / k2])
+        props = parity_by_properties(problems, w2, u2, mean2, var2)
+        per_gpu = (world if replicas else 1)
+        configs[name] = {
+            "workload": w2.name, "n_total": int(w2.n_total), "m_predict": int(w2.Xtest.shape[0]), "steps": k2,
+            "ms_per_step": dt2 / k2 * 1e3, "value": per_gpu * w2.total_flops() / (dt2 / k2) / 1e9, "unit": "GFLOP/s",
+            "frac_of_fp64_mfma_peak_all_gpus": per_gpu * w2.total_flops() / (dt2 / k2) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "algorithmic_flops_per_step": w2.total_flops(),
+            "parity_by_properties": props,
+            "comm_bytes_per_rank_per_step": None if comm2 is None or not distributed else [{"rank": r_, "sent": row[0], "received": row[1]} for r_, row in enumerate(comm2)],
+        }
+        del u2, dev2, prior2
+        gc.collect()
+
     if rank != 0:
         comm.close()
         return
     ms_per_step = dt / args.steps * 1e3
     flops = wl.total_flops()
-    # distributed: all ranks work on ONE problem (strong scaling); replicas: one problem per rank
+    # distributed: all ranks work on ONE problem; replicas: one problem per rank
     value = (world if replicas else 1) * flops / (dt / args.steps) / 1e9
 
-    syrk = prof["syrk_trailing"]
+    sha = csrc_sha16()
+    syrk = prof[ROOFLINE_SLOT]
     asm = prof["assemble"]
     achieved = syrk["flops"] / (syrk["ms"] * 1e-3) / 1e12 if syrk["ms"] > 0 else 0.0
+    roof_symbol = ctx.roofline_kernel_symbol() if hasattr(ctx, "roofline_kernel_symbol") else "gemm_f64_kernel<false, false, 1>"
     out = {
         "metric": "condition+predict fp64 GFLOP/s (algorithmic), N=16384 Poisson-2D",
         "value": value,
@@ -297,7 +448,7 @@ def main():
         "higher_is_better": True,
         # the N = 1, 2, 4, 8 series of the default mode grows the problem with N (flops per GPU fixed): weak scaling, and the
         # N = 1 line is the first point of that series; "strong" only for LPGP_BENCH_STRONG=1 / an explicit --n-side
-        "scaling": "strong" if (strong or (world > 1 and not replicas and not weak)) else "weak",
+        "scaling": "strong" if (strong or (distributed and not weak)) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -312,6 +463,7 @@ def main():
             "algorithmic_flops_per_step": flops,
             "multi_gpu": ((dist_note or "single GPU") if world == 1 else
                           (dist_note or "independent replicas (one problem per GPU)") if replicas else
+                          (dist_note or "") +
                           f"one problem, Gram matrix / factor sharded in 2-D block-cyclic tiles (blocks of 512) over a "
                           f"{ctx.grid[0]} x {ctx.grid[1]} process grid, "
                           + {"host": "HOST-STAGED panel exchange (bring-up transport, not a benchmark configuration)",
@@ -321,22 +473,26 @@ def main():
                                         "bring-up aid, not a benchmark configuration)" if loopback else "")}[transport]
                           + ", prediction points sharded over the ranks, factor streamed for the solves"
                           + (f"; weak scaling: grid side {n_side} so that flops per GPU equal c3's" if weak else "")),
-            "rccl_ranks": world if (world > 1 and not replicas and transport == "rccl") else 0,
-            "transport": None if (world == 1 or replicas) else transport,
-            "process_grid": None if (world == 1 or replicas) else list(ctx.grid),
-            "comm_per_rank_per_step": None if (world == 1 or replicas) else [
+            "rccl_ranks": world if (distributed and transport == "rccl") else 0,
+            "transport": None if not distributed else transport,
+            "process_grid": None if not distributed else list(ctx.grid),
+            "link_probe": link_probe,
+            "trials": None if trials is None else {"variants": trials, "chosen": chosen,
+                                                   "note": "two timed steps of the bench workload per variant, during warm-up; the fastest runs the timed region"},
+            "comm_per_rank_per_step": None if not distributed else [
                 {"rank": r, "bytes_sent": row[0], "bytes_received": row[1], "seconds_in_comm": row[2] * 1e-3}
                 for r, row in enumerate(comm_rows)],
             "device": info["name"].strip(),
+            "csrc_sha16": sha,
         },
         "roofline": {
-            "kernel": "gemm_f64_kernel<false,false,1> (SYRK: rank-512 trailing update of the blocked Cholesky, remainder half of the look-ahead split, ~90 % of the factorisation flops)",
+            "kernel": f"{roof_symbol} (SYRK: rank-512 trailing update of the blocked Cholesky, remainder half of the look-ahead split, ~90 % of the factorisation flops)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": _pmc_traffic(),
+            **pmc_traffic(sha, roof_symbol),
             "launches_per_step": syrk["launches"] / max(args.steps, 1),
             "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
         },
@@ -354,6 +510,8 @@ def main():
                              "(cross-covariance, streamed solve, read-outs) of two extra steps; best of two, max over ranks"},
         "posterior": {"mean_max": float(np.max(mean)), "var_min": float(np.min(var)), "var_max": float(np.max(var))},
     }
+    if configs:
+        out["configs"] = configs
     # assembly kernels, one entry per kernel symbol (HBM-write bound by design; bytes = entries stored x 8,
     # lower triangle only for diagonal blocks)
     asm_kernels = {"assemble": "assemble_kernel<D> (one fused evaluation per entry: boundary / cross blocks, cross-covariance)",
@@ -368,15 +526,12 @@ def main():
                 "frac": gbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": p["bytes"] / args.steps,
                 "launches_per_step": p["launches"] / args.steps,
             }
+    del asm
     if args.workload != "poisson2d" or wl.n_total != 16896:
         out["metric"] = f"condition+predict fp64 GFLOP/s (algorithmic), {wl.name} (N_tot={wl.n_total})"
-    ref = None
-    if not args.no_cpu and world == 1:
-        out["cpu_baseline"], ref = cpu_baseline(problems, wl, args.cpu_side)
-    if args.check or ref is not None:
-        if ref is None:
-            from oracle import workloads as owl
-            ref = owl.run(wl, want_cond=True)
+    if cpu_json is not None:
+        out["cpu_baseline"] = cpu_json
+    if ref is not None:
         out["parity"] = parity_report(mean, var, ref, wl)
     _libc.fflush(None)
     sys.stdout.flush()

@@ -70,6 +70,7 @@ int  lpgp_sync(lpgp_ctx* ctx);                       /* hipDeviceSynchronize */
 /* tuning knobs (env LPGP_NB / LPGP_LOOKAHEAD give the defaults): panel width of the
  * blocked Cholesky (multiple of 128) and look-ahead on/off                              */
 int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
+int  lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
  * Pr x Pc process grid (rank = r * Pc + c), 2-D block-cyclic tiles: tile (i, j) of the padded matrix lives on
@@ -80,8 +81,8 @@ int  lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value);
  * every rank then updates its own tiles.  Solves stream the factor panel by panel against right-hand sides that
  * are sharded by column (csrc/dist.hip).
  * Rank 0 creates the id, the caller ships the 128 bytes to the other ranks (any control plane), every rank then
- * calls lpgp_dist_init before its first lpgp_mat_create.  lpgp_dist_set_grid (optional, before lpgp_dist_init /
- * lpgp_dist_init_host, the same on every rank) fixes Pr x Pc; the default is Pr = world, Pc = 1: on the
+ * calls lpgp_dist_init before its first lpgp_mat_create.  lpgp_dist_set_grid (optional, the same on every rank: before
+ * lpgp_dist_init / lpgp_dist_init_host, or later while no matrix / right-hand side is alive) fixes Pr x Pc; the default is Pr = world, Pc = 1: on the
  * full mesh of xGMI links every link then carries 1 / world of a panel.
  * All lpgp_* calls that touch a distributed matrix are COLLECTIVE: every rank makes them in the same order.   */
 int  lpgp_dist_unique_id(char* out128);
@@ -92,6 +93,14 @@ int  lpgp_dist_grid(lpgp_ctx* ctx, int32_t* pr, int32_t* pc);
 /* bytes this rank has sent / received in panel exchanges since lpgp_init (or the last call with reset != 0);
  * the time inside them is profiling slot LPGP_K_COMM                                                        */
 int  lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, int32_t reset);
+/* Link probe: what the panel exchanges can expect from the fabric, measured through the calls they use (RCCL
+ * ncclSend / ncclRecv groups, or device-to-device copies into IPC-mapped windows) with HIP events on the panel stream.
+ * out: world*world + world + 1 doubles in GB/s (0 = not measured on this rank): [s*world + d] the ordered pair s -> d
+ * alone; [world*world + s] one link of s while s sends to every peer at once; [world*world + world] total inbound rate
+ * of this rank while every rank sends to every peer at once (the pattern of a Pr x 1 panel gather).  Collective.  The
+ * reference has no counterpart (single process, host BLAS); it exists so that ONE run on an 8-GPU node can be held
+ * against the communication model of DESIGN.md section 7 (bench.py: config.link_probe).                        */
+int  lpgp_dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out);
 /* Bring-up / test transport: the same distributed algorithms with every message staged through the host and
  * handed to a caller-supplied exchange (op 0: broadcast `bytes` bytes of buf from rank `root`; op 1: element-wise
  * max all-reduce of one int32 in buf; return 0 on success) instead of RCCL.  Ranks may then share ONE GPU (RCCL

@@ -376,7 +376,10 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_DENSE_TILES")) ctx->dense_tiles = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_GEMM3_MARGIN")) ctx->gemm3_margin = std::atof(e);
+  if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_DIST_CHAIN_US_COMM")) ctx->dist_chain_us_comm = std::atof(e);
   if (const char* e = std::getenv("LPGP_GEMM_BAND")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ctx->gemm_band = v; }
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
     long v = std::atol(e);
@@ -457,6 +460,20 @@ int lpgp_sync(lpgp_ctx* ctx) {
   return 0;
 }
 
+int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
+  LPGP_CHECK(ctx && key && value, "lpgp_get_option: null argument");
+  if (std::strcmp(key, "nb") == 0) *value = ctx->nb;
+  else if (std::strcmp(key, "gemm3") == 0) *value = ctx->gemm3;
+  else if (std::strcmp(key, "dist_bcast") == 0) *value = ctx->dist_bcast;
+  else if (std::strcmp(key, "split_gather") == 0) *value = ctx->split_gather;
+  else if (std::strcmp(key, "lookahead") == 0) *value = ctx->lookahead;
+  else if (std::strcmp(key, "fused_solve") == 0) *value = ctx->fused_solve;
+  else if (std::strcmp(key, "small_tiles_max") == 0) *value = ctx->small_tiles_max;
+  else if (std::strcmp(key, "live_mats") == 0) *value = ctx->live_mats;
+  else LPGP_CHECK(false, "unknown option %s", key);
+  return 0;
+}
+
 int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   LPGP_DEVICE(ctx);
   if (std::strcmp(key, "nb") == 0) {
@@ -474,6 +491,10 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->dense_tiles = (int)value;
   } else if (std::strcmp(key, "fused_solve") == 0) {
     ctx->fused_solve = (int)value;
+  } else if (std::strcmp(key, "dist_bcast") == 0) {
+    ctx->dist_bcast = value != 0;           // (the same on every rank)
+  } else if (std::strcmp(key, "split_gather") == 0) {
+    ctx->split_gather = value != 0;
   } else if (std::strcmp(key, "gemm3") == 0) {
     ctx->gemm3 = value < 0 ? lpgp_ctx().gemm3 : (int)value;       // (negative: back to the built-in default)
   } else if (std::strcmp(key, "min_supertiles") == 0) {
@@ -519,13 +540,27 @@ static void choose_grid(lpgp_ctx* ctx, int world) {
   ctx->pc = 1;
 }
 
+static int dist_fail(lpgp_ctx* ctx, int rc);
+
 int lpgp_dist_set_grid(lpgp_ctx* ctx, int32_t pr, int32_t pc) {
   LPGP_CHECK(ctx && pr >= 1 && pc >= 1 && pr <= 8 && pc <= 8, "lpgp_dist_set_grid: bad grid %d x %d", pr, pc);
-  LPGP_CHECK(!ctx->distributed(), "lpgp_dist_set_grid: call before lpgp_dist_init");
+  // before the bring-up, or afterwards while no matrix or right-hand side exists (their storage is laid out for the
+  // grid they were created under): bench.py times the same workload on two grids during warm-up and keeps the faster
+  if (ctx->distributed()) {
+    LPGP_CHECK(pr * pc == ctx->world, "lpgp_dist_set_grid: grid %d x %d does not match %d ranks", pr, pc, ctx->world);
+    LPGP_CHECK(ctx->live_mats == 0, "lpgp_dist_set_grid: %d matrices / right-hand sides of the current grid are still alive", ctx->live_mats);
+  }
   ctx->pr = pr;
   ctx->pc = pc;
   ctx->grid_set = 1;
   return 0;
+}
+
+int lpgp_dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
+  LPGP_CHECK(ctx && out && bytes >= 8 && reps >= 1, "lpgp_dist_link_probe: bad argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(ctx->distributed() && !ctx->dist_broken, "lpgp_dist_link_probe: no multi-GPU job (call lpgp_dist_init first)");
+  return dist_fail(ctx, dist_link_probe(ctx, bytes, reps, out));
 }
 
 int lpgp_dist_grid(lpgp_ctx* ctx, int32_t* pr, int32_t* pc) {
@@ -542,8 +577,6 @@ int lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, i
   if (reset) ctx->comm_bytes_sent = ctx->comm_bytes_recv = 0.0;
   return 0;
 }
-
-static int dist_fail(lpgp_ctx* ctx, int rc);
 
 int lpgp_dist_init(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* uid128) {
   LPGP_CHECK(ctx && uid128 && world >= 1 && rank >= 0 && rank < world, "lpgp_dist_init: bad argument");
@@ -686,6 +719,7 @@ int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
     delete m;
     return rc;
   }
+  ++ctx->live_mats;
   *out = m;
   return 0;
 }
@@ -694,6 +728,7 @@ int lpgp_mat_destroy(lpgp_mat* m) {
   if (!m) return 0;
   (void)hipSetDevice(m->ctx->device);
   mat_release(m->ctx, m);
+  --m->ctx->live_mats;
   delete m;
   return 0;
 }
@@ -1088,6 +1123,7 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
       LPGP_HIP(hipMemset2DAsync(r->v + b.poff + b.n, (size_t)r->ld * sizeof(double), 0, (size_t)(b.pn - b.n) * sizeof(double),
                                 (size_t)m, ctx->s_main));
   r->assembled.assign(mat->blocks.size(), 0);
+  ++ctx->live_mats;
   *out = r;
   return 0;
 }
@@ -1109,6 +1145,7 @@ int lpgp_rhs_destroy(lpgp_rhs* r) {
   if (!r) return 0;
   (void)hipSetDevice(r->ctx->device);
   pool_free(r->ctx, r->v, (size_t)r->ld * r->m_pad * sizeof(double));
+  --r->ctx->live_mats;
   delete r;
   return 0;
 }

@@ -39,9 +39,52 @@ struct AsmArgs {
   Layout2D lay;                 // where element (row_off + i, col_off + j) lives on this rank (multi-GPU: only the owned tiles are written)
 };
 
+// Per-point exponential factors of the Matern dimensions (eval_entries.h: `Fac`): for group g, dimension j and point p of
+// the tile, E+ = e^{-a (x_p - x0)} and E- = e^{+a (x_p - x0)} with the tile's own origin x0 (its first column point), rows
+// and columns in LDS: [g][j][sign][AT].  Used while |a (x - x0)| <= FACT_TMAX for every point of the tile (argument rounding
+// then stays below 32 eps ~ 7e-15 relative, the size of the error of exp itself times a few); otherwise -- points spread over
+// hundreds of length scales inside one 64 x 64 tile -- the tile falls back to one exp per entry.
+constexpr double FACT_TMAX = 32.0;
+constexpr int AEK = 4;          // entries per thread per pass in the kernels below (1 row x 4 columns; 16 columns per thread)
+
+template <int D>
+struct LdsFactors {
+  static constexpr bool enabled = true;
+  const double* rowf;           // row factors, already offset by this lane's row
+  const double* colf;           // column factors, already offset by the first column of the pass
+  __device__ __forceinline__ double pair(int g, int j, int e) const {
+    const double* r = rowf + (size_t)((g * D + j) * 2) * AT;
+    const double* c = colf + (size_t)((g * D + j) * 2) * AT + e;
+    return fmin(r[0] * c[AT], r[AT] * c[0]);      // E+(row) E-(col)  vs  E-(row) E+(col)
+  }
+};
+
+// factors of the point this lane stands for (coordinate xp[j], `valid` false: treated as the origin) for every Matern
+// dimension of every product-form group; items (g, j) are dealt to the four waves.  Clears *fast if the range bound fails.
+template <int D>
+__device__ __forceinline__ void stage_factors(const DevDesc* __restrict__ desc, const double (&xp)[D], const double (&x0)[D], bool valid,
+                                              double* dst /* [g][j][2][AT] */, int lane, int w, int wstep, int* fast) {
+  const int nitems = desc->ngroups * D;
+  for (int it = w; it < nitems; it += wstep) {
+    const int g = it / D, j = it - g * D;
+    const DevGroup& G = desc->g[g];
+    if (G.iso || G.expkind[j] != 1) continue;
+    double x = 0.0, o = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj)
+      if (jj == j) { x = xp[jj]; o = x0[jj]; }
+    const double t = valid ? G.a[j] * (x - o) : 0.0;
+    if (!(fabs(t) <= FACT_TMAX)) *fast = 0;
+    dst[(size_t)((g * D + j) * 2) * AT + lane] = exp(-t);
+    dst[(size_t)((g * D + j) * 2 + 1) * AT + lane] = exp(t);
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
   __shared__ double sx1[D][AT];
+  __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
+  __shared__ int s_fast;
   const int tr = blockIdx.x % a.tiles_r;   // row tile fastest: consecutive blocks write neighbouring rows
   const int tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
@@ -50,29 +93,45 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
   const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
   if (lrow0 < 0 || lcol0 < 0) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // stage column coordinates
-  if (threadIdx.x < AT) {
-    int64_t c = c0 + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-  }
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  // column coordinates: every wave reads them (cached), wave 0 stages them for the entry loop
+  const int64_t col = c0 + lane;
   const int64_t row = r0 + lane;
-  double xr[D];
+  double xr[D], xc[D], x0[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  for (int j = 0; j < D; ++j) {
+    xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+    xc[j] = (col < a.n1) ? a.x1[j * a.n1_pad + col] : 0.0;
+    x0[j] = a.x1[j * a.n1_pad + c0];                     // the tile's origin: its first column point (c0 < n1)
+  }
+  if (threadIdx.x < AT) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = xc[j];
+  }
+  if (threadIdx.x == 0) s_fast = 1;
   __syncthreads();
+  // waves 0,1: row factors; waves 2,3: column factors
+  if (wu < 2) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 2, &s_fast);
+  else stage_factors<D>(desc, xc, x0, col < a.n1, sfc, lane, wu - 2, 2, &s_fast);
+  __syncthreads();
+  const bool fast = s_fast != 0;
 #pragma unroll 1
-  for (int pass = 0; pass < 16 / AE; ++pass) {
-    const int cb = w * 16 + pass * AE;
-    double dx[D][AE], res[AE];
+  for (int pass = 0; pass < 16 / AEK; ++pass) {
+    const int cb = w * 16 + pass * AEK;
+    double dx[D][AEK], res[AEK];
 #pragma unroll
     for (int j = 0; j < D; ++j)
 #pragma unroll
-      for (int e = 0; e < AE; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-    eval_entries<D>(desc, dx, res);
+      for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
+    if (fast) {
+      LdsFactors<D> fac{sfr + lane, sfc + cb};
+      eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
+    } else {
+      eval_entries<D, AEK>(desc, dx, res);
+    }
     if (row < a.n0) {
 #pragma unroll
-      for (int e = 0; e < AE; ++e) {
+      for (int e = 0; e < AEK; ++e) {
         int64_t c = c0 + cb + e;
         if (c < a.n1) a.out[(lrow0 + lane) + (lcol0 + cb + e) * a.ld] = res[e];
       }
@@ -179,36 +238,59 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   __shared__ double sx1[D][AT];
   __shared__ double sv[MV_R][AT];
   __shared__ double red[3][MV_R][AT];
+  // per-point exponential factors (see assemble_kernel): origin = the first row of this workgroup's row tile; the row
+  // factors are computed once, the column factors per column tile, and a tile whose points lie more than FACT_TMAX scaled
+  // units from the origin falls back to one exp per entry
+  __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
+  __shared__ int s_fast_r, s_fast_c[2];
   const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
   const int64_t row = (int64_t)tr * AT + lane;
-  double xr[D];
+  double xr[D], x0[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  for (int j = 0; j < D; ++j) {
+    xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+    x0[j] = a.x0[j * a.n0_pad + (int64_t)tr * AT];
+  }
   double y[MV_R];
 #pragma unroll
   for (int r = 0; r < MV_R; ++r) y[r] = 0.0;
   const int per = (a.tiles_c + a.splits - 1) / a.splits;
   const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
+  if (threadIdx.x == 0) { s_fast_r = 1; s_fast_c[0] = 1; s_fast_c[1] = 1; }
+  __syncthreads();
+  stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
   for (int tc = sp * per; tc < tc_end; ++tc) {
-    __syncthreads();                                   // previous tile consumed
+    __syncthreads();                                   // previous tile consumed (first tile: flags initialised)
     {
       const int64_t c = (int64_t)tc * AT + lane;       // wave w stages coordinate / vector row w, w+4, ...
       for (int j = w; j < D; j += 4) sx1[j][lane] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
       for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.n1_pad + c] : 0.0;
+      double xc[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) xc[j] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+      stage_factors<D>(desc, xc, x0, c < a.n1, sfc, lane, wu, 4, &s_fast_c[tc & 1]);
+      if (threadIdx.x == 0) s_fast_c[(tc + 1) & 1] = 1;       // the next tile's flag (read two barriers from now)
     }
     __syncthreads();
+    const bool fast = s_fast_r != 0 && s_fast_c[tc & 1] != 0;
 #pragma unroll 1
-    for (int pass = 0; pass < 16 / AE; ++pass) {
-      const int cb = w * 16 + pass * AE;
-      double dx[D][AE], res[AE];
+    for (int pass = 0; pass < 16 / AEK; ++pass) {
+      const int cb = w * 16 + pass * AEK;
+      double dx[D][AEK], res[AEK];
 #pragma unroll
       for (int j = 0; j < D; ++j)
 #pragma unroll
-        for (int e = 0; e < AE; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-      eval_entries<D>(desc, dx, res);
+        for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
+      if (fast) {
+        LdsFactors<D> fac{sfr + lane, sfc + cb};
+        eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
+      } else {
+        eval_entries<D, AEK>(desc, dx, res);
+      }
 #pragma unroll
-      for (int e = 0; e < AE; ++e)
+      for (int e = 0; e < AEK; ++e)
 #pragma unroll
         for (int r = 0; r < MV_R; ++r) y[r] = fma(res[e], sv[r][cb + e], y[r]);   // columns >= n1 carry v = 0
     }

@@ -238,7 +238,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
     LPGP_CHECK(comm != nullptr && ctx->nccl_comm != nullptr, "panel exchange: no communicator (aborted after an earlier failure?)");
     // LPGP_DIST_COLLECTIVE=bcast: one ncclBroadcast per piece instead of the point-to-point group (a fallback to compare
     // with on the 8-GPU node, which the builder has no access to; RCCL then picks its own ring / tree)
-    static const bool use_bcast = [] { const char* e = std::getenv("LPGP_DIST_COLLECTIVE"); return e && std::string(e) == "bcast"; }();
+    const bool use_bcast = ctx->dist_bcast != 0;
     DTRACE(ctx, "exchange: group of %zu pieces", pieces.size());
     LPGP_NCCL(ncclGroupStart());
     for (const auto& p : pieces) {
@@ -322,6 +322,100 @@ int dist_warm_up(lpgp_ctx* ctx) {
   } while (0);
   (void)hipFree(d);
   return rc;
+}
+
+// ---- link probe ---------------------------------------------------------------------------------------------------
+// What the panel exchanges can expect from the fabric, measured through the very calls they use (RCCL: ncclSend / ncclRecv
+// groups on the panel stream; direct-peer transport: hipMemcpyAsync into the peer's IPC-mapped window), timed with HIP
+// events on that stream.  out (W*W + W + 1 doubles, GB/s, 0 = not measured on this rank):
+//   out[s*W + d]   s -> d alone                     (RCCL: measured by the receiver d; IPC: by the sender s)
+//   out[W*W + s]   s -> every peer at once: rate of ONE of its links (RCCL: inbound at this rank; IPC: at the sender, per peer)
+//   out[W*W + W]   every rank -> every peer at once: total inbound rate of this rank (the pattern of a P x 1 panel gather)
+// Collective; every rank passes the same bytes / reps.  bench.py gathers the rows and prints the matrix (config.link_probe).
+int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
+  const int W = ctx->world, me = ctx->rank;
+  for (int i = 0; i < W * W + W + 1; ++i) out[i] = 0.0;
+  if (W <= 1 || (ctx->host_xfer && !ctx->ipc())) return 0;       // host-staged bring-up transport: nothing to measure
+  hipStream_t st = ctx->s_main;
+  size_t count = (size_t)bytes / sizeof(double);
+  if (ctx->ipc()) count = std::min(count, ctx->ipc_window_doubles / (size_t)W);
+  void *ps = nullptr, *pr = nullptr;
+  const size_t sb = count * sizeof(double), rb = sb * (size_t)(W - 1);
+  if (pool_alloc(ctx, &ps, sb, nullptr) != 0) return -1;
+  if (pool_alloc(ctx, &pr, rb, nullptr) != 0) { pool_free(ctx, ps, sb); return -1; }
+  double* dsend = (double*)ps;
+  double* drecv = (double*)pr;
+  struct Release { lpgp_ctx* c; void *a, *b; size_t sa, sb_; ~Release() { pool_free(c, a, sa); pool_free(c, b, sb_); } } release{ctx, ps, pr, sb, rb};
+  LPGP_HIP(hipMemsetAsync(dsend, 0, sb, st));
+  hipEvent_t e0, e1;
+  LPGP_HIP(hipEventCreate(&e0));
+  LPGP_HIP(hipEventCreate(&e1));
+  struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evs{e0, e1};
+  auto barrier = [&]() -> int {
+    int v = 0;
+    return allreduce_max_int(ctx, st, &v);
+  };
+  // one pattern: rank s sends `count` doubles to every d with sends(s, d); returns the seconds per repetition seen by this rank
+  auto run = [&](auto&& sends, double* seconds) -> int {
+    *seconds = 0.0;
+    bool involved = false;
+    for (int s_ = 0; s_ < W && !involved; ++s_)
+      for (int d_ = 0; d_ < W; ++d_)
+        if (s_ != d_ && sends(s_, d_) && (s_ == me || d_ == me)) { involved = true; break; }
+    for (int r = 0; r <= reps; ++r) {          // r == 0: untimed (connection set-up, both ends in step)
+      if (r == 1 && involved) LPGP_HIP(hipEventRecord(e0, st));
+      if (ctx->ipc()) {
+        LPGP_HIP(hipStreamSynchronize(st));
+        LPGP_TRY(barrier());
+        for (int d_ = 0; d_ < W; ++d_)
+          if (d_ != me && sends(me, d_))
+            LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[d_] + (size_t)me * count, dsend, sb, hipMemcpyDeviceToDevice, st));
+      } else {
+        ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+        LPGP_CHECK(comm != nullptr, "link probe: no communicator");
+        if (involved) {
+          LPGP_NCCL(ncclGroupStart());
+          int slot = 0;
+          for (int p = 0; p < W; ++p) {
+            if (p == me) continue;
+            if (sends(me, p)) LPGP_NCCL(ncclSend(dsend, count, ncclDouble, p, comm, st));
+            if (sends(p, me)) LPGP_NCCL(ncclRecv(drecv + (size_t)slot * count, count, ncclDouble, p, comm, st));
+            ++slot;
+          }
+          LPGP_NCCL(ncclGroupEnd());
+        }
+      }
+    }
+    if (involved) {
+      LPGP_HIP(hipEventRecord(e1, st));
+      LPGP_TRY(sync_stream(ctx, st));
+      float ms = 0.f;
+      LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      *seconds = (double)ms * 1e-3 / reps;
+    }
+    if (ctx->ipc()) LPGP_TRY(barrier());
+    return 0;
+  };
+  const double gb = (double)sb * 1e-9;
+  double sec = 0.0;
+  for (int s_ = 0; s_ < W; ++s_)
+    for (int d_ = 0; d_ < W; ++d_) {
+      if (s_ == d_) continue;
+      LPGP_TRY(run([&](int a, int b) { return a == s_ && b == d_; }, &sec));
+      const bool mine = ctx->ipc() ? me == s_ : me == d_;
+      if (mine && sec > 0.0) out[s_ * W + d_] = gb / sec;
+    }
+  LPGP_TRY(barrier());
+  for (int s_ = 0; s_ < W; ++s_) {
+    LPGP_TRY(run([&](int a, int) { return a == s_; }, &sec));
+    const bool mine = ctx->ipc() ? me == s_ : me != s_;
+    if (mine && sec > 0.0) out[W * W + s_] = gb / sec;
+    LPGP_TRY(barrier());
+  }
+  LPGP_TRY(run([&](int, int) { return true; }, &sec));
+  if (sec > 0.0) out[W * W + W] = gb * (W - 1) / sec;
+  LPGP_TRY(barrier());
+  return 0;
 }
 
 // ---- panel gather -------------------------------------------------------------------------------------------------
@@ -470,16 +564,21 @@ static int panel_rows_solve(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const 
 
 // The update of this rank's tiles by a gathered panel: local tile rows [rt0, LTr) x local tile columns [ct0, ct1),
 // valid where global row tile >= global column tile; `panel` holds global tile rows g0 ... (leading dimension ldp)
-static int update_local(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, const double* panel, int64_t ldp, int g0, int K128,
-                        int rt0, int rt1, int ct0, int ct1, int prof) {
-  if (rt1 <= rt0 || ct1 <= ct0) return 0;
+static GemmArgs update_args(lpgp_mat* mat, const Grid& G, const double* panel, int64_t ldp, int g0, int K128, int rt0, int rt1, int ct0,
+                            int ct1, int tri) {
   const int64_t ld = mat->lr_cap;
   GemmArgs g = mk(panel, ldp, panel, ldp, mat->a + (int64_t)rt0 * TILE + (int64_t)ct0 * TILE * ld, ld, rt1 - rt0, ct1 - ct0, K128, -1.0, 1.0,
-                  1);
+                  tri);
   g.cyc = 1;
   g.rowc = G.R; g.colc = G.C;
   g.rt0 = rt0; g.ct0 = ct0; g.g0 = g0;
-  return launch_gemm(ctx, st, 0, 0, g, prof);
+  return g;
+}
+static int update_local(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, const double* panel, int64_t ldp, int g0, int K128,
+                        int rt0, int rt1, int ct0, int ct1, int prof) {
+  if (rt1 <= rt0 || ct1 <= ct0) return 0;
+  // (the look-ahead half keeps its own kernel symbol and profiling slot, as on a single GPU)
+  return launch_gemm(ctx, st, 0, 0, update_args(mat, G, panel, ldp, g0, K128, rt0, rt1, ct0, ct1, prof == LPGP_K_SYRK_AHEAD ? 3 : 1), prof);
 }
 
 // Factor the diagonal block of panel [c0, c1) (owner only, in its local storage), copy it into the replicated
@@ -604,6 +703,7 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
   auto head_end_of = [&](size_t i) { return i + 1 < panels.size() ? panels[i + 1].c1 : T; };
 
   bool have_upd = false;
+  hipEvent_t last_upd = nullptr;
   for (size_t i = 0; i < panels.size(); ++i) {
     const Panel& p = panels[i];
     const int which = (int)(i & 1);
@@ -627,23 +727,39 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     // factorisation / solve / gather; (b) everything to the right of it meanwhile on the update stream
     const Panel& q = panels[i + 1];
     const int cta = cyc_before(G.C, q.c0), ctb = cyc_before(G.C, q.c1);      // local columns of the next panel (empty off its process column)
+    // The single-GPU scheduler's two rules (potrf.hip: factor_columns), priced with THIS rank's share of the update -- with P
+    // ranks the remainder update is P times shorter and the chain (diagonal block, broadcast, rows, gather) longer, so the
+    // chain bounds the pipeline from much earlier on: (1) while it does, (b) is released only when the look-ahead half (a) is
+    // complete (launched together they share the chip by workgroup count and (a), which the next panel waits for, crawls);
+    // (2) once (b) is shorter than the chain even on the narrow stream, it runs there and leaves a quarter of the CUs to the
+    // chain's kernels.
+    const double t_b_us = (double)gemm_valid_tiles(update_args(mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, 1)) *
+                          (2.0 * TILE * TILE * (double)K128 / 50e6);
+    const double t_chain_us = ctx->chain_us_tile * (double)(q.c1 - q.c0) + ctx->chain_us_fixed + (ctx->world > 1 ? ctx->dist_chain_us_comm : 0.0);
+    const bool chain_bound = t_b_us < t_chain_us;
     hipEvent_t evp = ctx->ev_panel[i & 1];
-    LPGP_HIP(hipEventRecord(evp, sP));                                       // panel p is gathered (split: its head)
+    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));                     // panel p is gathered (split: its head)
     if (have_upd) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(i + 1) & 1], 0));   // (a)'s columns were last written by the previous (b)
     LPGP_TRY(update_local(ctx, sP, mat, G, panel, ldp, p.c1, K128, rt0, LTr, cta, ctb, LPGP_K_SYRK_AHEAD));
-    LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
-    if (tail_pending[which]) LPGP_HIP(hipStreamWaitEvent(sU, ctx->ev_tail[which], 0));   // (b) reads every row of the panel
-    LPGP_TRY(update_local(ctx, sU, mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, LPGP_K_SYRK));
-    LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sU));
+    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
+    hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
+    if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));             // behind the previous remainder update (it may have run on the other update stream)
+    LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
+    if (tail_pending[which]) LPGP_HIP(hipStreamWaitEvent(sB, ctx->ev_tail[which], 0));   // (b) reads every row of the panel
+    {
+      GemmArgs gb = update_args(mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, 1);
+      gb.occ3 = t_b_us > ctx->gemm3_margin * t_chain_us;
+      if (gb.mt > 0 && gb.nt > 0) LPGP_TRY(launch_gemm(ctx, sB, 0, 0, gb, LPGP_K_SYRK));
+    }
+    LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sB));
+    last_upd = ctx->ev_upd[i & 1];
     have_upd = true;
     // the next gather writes panel buffer which ^ 1, last read by (b) of panel i - 1: that update has been waited
     // for above (ev_upd[(i + 1) & 1]) before anything of this step was enqueued on the panel stream
     LPGP_TRY(panel_part(q, which ^ 1, head_end_of(i + 1)));
   }
-  if (have_upd) {
-    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
-    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
-  }
+  if (have_upd && last_upd) LPGP_HIP(hipStreamWaitEvent(sP, last_upd, 0));      // join: every update is behind the panel stream
   LPGP_HIP(hipMemcpyAsync(ctx->h_info_pinned + 1, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_TRY(sync_stream(ctx, sP));
   int h_info = ctx->h_info_pinned[1];

@@ -43,9 +43,24 @@ LPGP_HD double lpgp_xor_sign(double v, unsigned s) {
 #endif
 }
 
-template <int D>
+// Where the exponential of a Matern dimension comes from.  A half-integer Matern factor decays like e^{-a |x - x'|}, and
+//   e^{-a |x - x'|} = min( e^{-a (x - x0)} e^{+a (x' - x0)},  e^{+a (x - x0)} e^{-a (x' - x0)} )       (any origin x0)
+// -- one of the two products is e^{-a |x - x'|} <= 1, the other its reciprocal -- so the per-ENTRY exponential of a tile of
+// the block collapses into per-POINT exponentials (64 rows + 64 columns instead of 4096 entries) and two multiplies and a
+// minimum per entry and dimension.  A provider with `enabled` hands out that minimum for (group, dimension, entry);
+// `NoFactors` (the default) evaluates exp(-sum r_d) per entry as before.  Dimensions of squared-exponential kind keep their
+// per-entry exponential (e^{-(u-u')^2/2} does not split without an exponential of the cross term), as do isotropic groups.
+// Rounding: the argument a (x - x0) carries a relative error of one ulp, i.e. |a (x - x0)| eps absolute in the exponent, so the
+// provider is only used while |a (x - x0)| stays below a small bound on the tile (assemble.hip: FACT_TMAX).
+struct NoFactors {
+  static constexpr bool enabled = false;
+  LPGP_HD double pair(int, int, int) const { return 1.0; }
+};
+
+template <int D, int NE = AE, class Fac = NoFactors>
 LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
-                                             const double (&dx)[D][AE], double (&res)[AE]) {
+                                             const double (&dx)[D][NE], double (&res)[NE], const Fac& fac = Fac()) {
+  constexpr int AE = NE;          // (entries per call: the name the body uses)
 #pragma unroll
   for (int e = 0; e < AE; ++e) res[e] = 0.0;
   for (int g = 0; g < desc->ngroups; ++g) {
@@ -104,9 +119,10 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
     }
     double r[D][AE];
     unsigned sg[D][AE];
-    double expo[AE];
+    double expo[AE], ef[AE];
+    bool per_entry_exp = !Fac::enabled;       // some dimension of the group still needs exp(-expo) per entry
 #pragma unroll
-    for (int e = 0; e < AE; ++e) expo[e] = 0.0;
+    for (int e = 0; e < AE; ++e) { expo[e] = 0.0; ef[e] = 1.0; }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const double a = G.a[j];
@@ -116,7 +132,14 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
         double v = a * dx[j][e];
         sg[j][e] = lpgp_hi32(v) & 0x80000000u;
         r[j][e] = fabs(v);
-        expo[e] += (kind == 1) ? r[j][e] : 0.5 * r[j][e] * r[j][e];
+      }
+      if (Fac::enabled && kind == 1) {
+#pragma unroll
+        for (int e = 0; e < AE; ++e) ef[e] *= fac.pair(g, j, e);
+      } else {
+        per_entry_exp = true;
+#pragma unroll
+        for (int e = 0; e < AE; ++e) expo[e] += (kind == 1) ? r[j][e] : 0.5 * r[j][e] * r[j][e];
       }
     }
     double tot[AE];
@@ -185,8 +208,13 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
         tot[e] += v;
       }
     }
+    if (per_entry_exp) {
 #pragma unroll
-    for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * exp(-expo[e]), tot[e], res[e]);
+      for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * (ef[e] * exp(-expo[e])), tot[e], res[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * ef[e], tot[e], res[e]);
+    }
   }
 }
 

@@ -437,23 +437,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 //     of the current one, each right behind the four MFMAs that read it last (t-major order in that chunk); the LDS latency
 //     that is left is covered by the two other waves of the SIMD instead of by registers;
 //   * same operand image (M image, [k][LDM]), same swapped-operand accumulator layout, same tile enumerations, same epilogue.
-// NT form only (both operands with the non-contracted index fastest): the symmetric rank-nb updates of the factorisation.
+// A always has its non-contracted index fastest (M image); B either way: NT form (TB = false: the symmetric rank-nb updates of
+// the factorisation) and NN form (TB = true: B k-fastest, the updates of the blocked forward substitution V <- V - L_panel V_p).
+// Launches with fewer than `gemm3` tiles (default 768 = three per CU) stay on the two-resident kernel: a workgroup that is
+// alone on its CU has nobody to cover its LDS latency (measured: the look-ahead half of the update, 4 tile columns, ran at 20
+// instead of 30 TFLOP/s on this kernel).  So do the updates that run BESIDE a panel chain that is not far shorter than they
+// are (GemmArgs::occ3, cleared by the schedulers): three resident waves of 168 registers fill a SIMD's register file, and
+// the chain's kernels then wait for a whole workgroup to retire before any of their waves fits -- measured in situ, the
+// update itself gains 5 % (50.5 -> 53.1 TFLOP/s by HIP events) and the c3 step nothing (56.5 vs 56.5 ms).
 // =========================================================================================
 constexpr int BK3 = 8;
 constexpr int STAGE3 = BK3 * LDM;        // doubles per operand per stage
 
+// T = false: M image [k][LDM] (one piece = one k-row).  T = true (k fastest in memory): image [idx][8] -- one piece = 16
+// index rows of 64 B; no swizzle needed: the only reader is the replicated n-side fragment, whose 16 distinct addresses
+// (4 indices x 4 k) fall into 32 distinct banks.
+template <bool T>
 __device__ __forceinline__ void dma_tile3(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0, int lane, int w,
                                           double* sdst) {
-  const unsigned voff = (unsigned)lane * 16u;
+  if constexpr (!T) {
+    const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int piece = q * 4 + w;                           // k-row, wave-uniform
-    const char* ub = reinterpret_cast<const char*>(P + idx0 + (k0 + piece) * ld);
-    __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * LDM), 16, 0, 0);
+    for (int q = 0; q < 2; ++q) {
+      const int piece = q * 4 + w;                         // k-row, wave-uniform
+      const char* ub = reinterpret_cast<const char*>(P + idx0 + (k0 + piece) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * LDM), 16, 0, 0);
+    }
+  } else {
+    const unsigned voff = (((unsigned)lane & 3u) * 2u + ((unsigned)lane >> 2) * (unsigned)ld) * 8u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int piece = q * 4 + w;                         // 16 index rows
+      const char* ub = reinterpret_cast<const char*>(P + k0 + (idx0 + (int64_t)piece * 16) * ld);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + voff), (lptr_t)(sdst + piece * 128), 16, 0, 0);
+    }
   }
 }
+template <bool T> __device__ __forceinline__ unsigned frag3_lane_n(int lane, int w) {
+  if constexpr (!T) return frag_lane_n<false>(lane, w);
+  else return (unsigned)((w * 64 + (lane & 3)) * BK3 + (lane >> 4));
+}
+template <bool T> constexpr int frag3_imm_n(int ks, int nf) { return T ? nf * 4 * BK3 + ks * 4 : frag_imm_n<false>(ks, nf); }
 
-template <int TRI>
+template <bool TB, int TRI>
 __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -473,15 +499,15 @@ __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
     if (!map_tile<(TRI != 0)>(g, (int)blockIdx.x, tr, tc)) return;
   }
   const unsigned laneM = lds_base + 8u * frag_lane_m<false>(lane, wm, 0);
-  const unsigned laneN = lds_base + (unsigned)(2 * STAGE3) * 8u + 8u * frag_lane_n<false>(lane, wn);
+  const unsigned laneN = lds_base + (unsigned)(2 * STAGE3) * 8u + 8u * frag3_lane_n<TB>(lane, wn);
 
   int64_t aidx = (int64_t)tr * BM, bidx = (int64_t)tc * BN;
   if (TRI != 0 && g.cyc) {
     aidx = (int64_t)(cyc_l2g(g.rowc, g.rt0 + tr) - g.g0) * BM;
     bidx = (int64_t)(cyc_l2g(g.colc, g.ct0 + tc) - g.g0) * BN;
   }
-  dma_tile3(g.A, g.lda, aidx, 0, lane, wu, sA);
-  dma_tile3(g.B, g.ldb, bidx, 0, lane, wu, sB);
+  dma_tile3<false>(g.A, g.lda, aidx, 0, lane, wu, sA);
+  dma_tile3<TB>(g.B, g.ldb, bidx, 0, lane, wu, sB);
 
   char* const cub = reinterpret_cast<char*>(g.C + ((int64_t)tc * BN + wun * 64) * g.ldc + (int64_t)tr * BM + wum * 64);
   const unsigned cvoff = ((unsigned)(lane >> 4) * (unsigned)g.ldc + (unsigned)(lane & 15)) * 8u;
@@ -506,8 +532,8 @@ __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
   for (int kt = 0; kt < KT; ++kt) {
     {
       const int knext = (kt + 1 < KT ? kt + 1 : kt) * BK3;      // (unconditional, see gemm_f64_kernel)
-      dma_tile3(g.A, g.lda, aidx, knext, lane, wu, sA + (cur ^ 1) * STAGE3);
-      dma_tile3(g.B, g.ldb, bidx, knext, lane, wu, sB + (cur ^ 1) * STAGE3);
+      dma_tile3<false>(g.A, g.lda, aidx, knext, lane, wu, sA + (cur ^ 1) * STAGE3);
+      dma_tile3<TB>(g.B, g.ldb, bidx, knext, lane, wu, sB + (cur ^ 1) * STAGE3);
     }
     const unsigned stoff = (unsigned)(cur * STAGE3) * 8u;
     const unsigned aM = laneM + stoff, aN = laneN + stoff;
@@ -519,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
     });
     static_for<0, 4>([&](auto V_) {
       constexpr int vv = decltype(V_)::value;
-      bn[0][vv] = lds_read_async<frag_imm_n<false>(0, vv)>(aN);
+      bn[0][vv] = lds_read_async<frag3_imm_n<TB>(0, vv)>(aN);
     });
     // 8 chunks of 16 MFMAs per stage (2 k-steps x 4 groups of 4 n-fragments); LDS operations return in order:
     // at the top of chunk c the n-fragments of chunk c + 1 are issued, and "all but the newest four" covers this chunk's
@@ -531,7 +557,7 @@ __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
         constexpr int ks2 = (c + 1) >> 2, uc2 = (c + 1) & 3;
         static_for<0, 4>([&](auto V_) {
           constexpr int vv = decltype(V_)::value;
-          bn[cb ^ 1][vv] = lds_read_async<frag_imm_n<false>(ks2, uc2 * 4 + vv)>(aN);
+          bn[cb ^ 1][vv] = lds_read_async<frag3_imm_n<TB>(ks2, uc2 * 4 + vv)>(aN);
         });
         LDS_WAIT(4);
       } else {
@@ -739,12 +765,12 @@ static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
 
 // the kernel of a launch: the three-resident variant for the NT form when the context asks for it (LPGP_GEMM3)
 template <bool TA, bool TB, int TRI>
-static void pick_kernel(const lpgp_ctx* ctx, void (**fn)(GemmArgs), size_t* shmem) {
+static void pick_kernel(const lpgp_ctx* ctx, int64_t ntiles, bool occ3, void (**fn)(GemmArgs), size_t* shmem) {
   *fn = gemm_f64_kernel<TA, TB, TRI>;
   *shmem = (size_t)4 * STAGE * sizeof(double);                  // 73 728 B: two workgroups per CU
-  if constexpr (!TA && !TB && TRI != 2) {
-    if (ctx->gemm3) {
-      *fn = gemm3_f64_kernel<TRI>;
+  if constexpr (!TA && TRI != 2 && !(TB && TRI != 0)) {
+    if (occ3 && ctx->gemm3 > 0 && ntiles >= ctx->gemm3) {
+      *fn = gemm3_f64_kernel<TB, TRI>;
       *shmem = (size_t)4 * STAGE3 * sizeof(double);             // 36 864 B: three workgroups per CU
     }
   }
@@ -754,7 +780,11 @@ template <bool TA, bool TB, int TRI>
 static int launch_impl(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
   void (*kfn)(GemmArgs) = nullptr;
   size_t shmem = 0;
-  pick_kernel<TA, TB, TRI>(ctx, &kfn, &shmem);
+  {
+    int64_t nt_est = (int64_t)g.mt * g.nt;               // (triangular shapes: the lower trapezoid; distributed staircase: an upper bound)
+    if (TRI != 0 && !g.cyc) nt_est = (int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt;
+    pick_kernel<TA, TB, TRI>(ctx, nt_est, g.occ3 != 0, &kfn, &shmem);
+  }
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(kfn), shmem));
   GemmArgs ga = g;
   const int BANDR = ctx->gemm_band;
@@ -822,6 +852,17 @@ int stair_enumerate_host(const GemmArgs& g, int32_t* out, int64_t cap) {
     }
   }
   return (int)n;
+}
+
+// number of 128 x 128 tiles a launch would work on (triangular shapes: the lower trapezoid; distributed update: the staircase
+// of this rank's valid tiles) -- what the schedulers price a trailing update with
+int64_t gemm_valid_tiles(const GemmArgs& g) {
+  if (g.mt <= 0 || g.nt <= 0) return 0;
+  if (!g.tri) return (int64_t)g.mt * g.nt;
+  if (!g.cyc) return (int64_t)g.nt * (g.nt + 1) / 2 + (int64_t)(g.mt - g.nt) * g.nt;
+  int64_t n = 0;
+  for (int r0 = 0; r0 < g.mt; r0 += BAND) n += stair_band_count(g, r0, std::min(BAND, g.mt - r0));
+  return n;
 }
 
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel) {

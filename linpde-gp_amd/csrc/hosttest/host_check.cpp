@@ -25,6 +25,39 @@ static void eval_block(const DevDesc& desc, const double* X0, int64_t n0, const 
     }
 }
 
+// The factored evaluation (eval_entries.h: `Fac`; on the device the per-point factors sit in LDS, assemble.hip:
+// LdsFactors): per-point exponentials e^{-+ a (x - x0)} of every Matern dimension relative to the first column point
+// of the 8-column strip, the per-entry exponential as the minimum of the two products -- the SAME eval_entries code path.
+template <int D>
+struct HostFactors {
+  static constexpr bool enabled = true;
+  const DevDesc* desc;
+  double xr[D], xc[D][AE], x0[D];
+  double pair(int g, int j, int e) const {
+    const double a = desc->g[g].a[j];
+    const double tr = a * (xr[j] - x0[j]), tc = a * (xc[j][e] - x0[j]);
+    const double p1 = std::exp(-tr) * std::exp(tc), p2 = std::exp(tr) * std::exp(-tc);
+    return p1 < p2 ? p1 : p2;
+  }
+};
+
+template <int D>
+static void eval_block_fact(const DevDesc& desc, const double* X0, int64_t n0, const double* X1, int64_t n1, double* out) {
+  for (int64_t i = 0; i < n0; ++i)
+    for (int64_t j0 = 0; j0 < n1; j0 += AE) {
+      double dx[D][AE], res[AE];
+      HostFactors<D> fac;
+      fac.desc = &desc;
+      for (int dd = 0; dd < D; ++dd) { fac.xr[dd] = X0[i * D + dd]; fac.x0[dd] = X1[j0 * D + dd]; }
+      for (int e = 0; e < AE; ++e) {
+        const int64_t j = (j0 + e < n1) ? j0 + e : n1 - 1;
+        for (int dd = 0; dd < D; ++dd) { dx[dd][e] = X0[i * D + dd] - X1[j * D + dd]; fac.xc[dd][e] = X1[j * D + dd]; }
+      }
+      eval_entries<D, AE, HostFactors<D>>(&desc, dx, res, fac);
+      for (int e = 0; e < AE && j0 + e < n1; ++e) out[i * n1 + j0 + e] = res[e];
+    }
+}
+
 extern "C" {
 
 const char* lpgp_host_last_error(void) { return last_error(); }
@@ -42,6 +75,23 @@ int lpgp_host_kernel_matrix(const lpgp_kdesc* kd, int32_t ngroups, const double*
     case 2: eval_block<2>(store[0], X0, n0, X1, n1, out); break;
     case 3: eval_block<3>(store[0], X0, n0, X1, n1, out); break;
     case 4: eval_block<4>(store[0], X0, n0, X1, n1, out); break;
+    default: return -2;
+  }
+  return 0;
+}
+
+// the same block through the factored evaluation path
+int lpgp_host_kernel_matrix_fact(const lpgp_kdesc* kd, int32_t ngroups, const double* X0, int64_t n0, const double* X1,
+                                 int64_t n1, double* out) {
+  std::vector<DevDesc> store(1);
+  int rc = lower_kdesc(kd, ngroups, &store[0]);
+  if (rc != 0) return rc;
+  if (n0 <= 0 || n1 <= 0) return 0;
+  switch (store[0].d) {
+    case 1: eval_block_fact<1>(store[0], X0, n0, X1, n1, out); break;
+    case 2: eval_block_fact<2>(store[0], X0, n0, X1, n1, out); break;
+    case 3: eval_block_fact<3>(store[0], X0, n0, X1, n1, out); break;
+    case 4: eval_block_fact<4>(store[0], X0, n0, X1, n1, out); break;
     default: return -2;
   }
   return 0;

@@ -106,7 +106,8 @@ struct lpgp_ctx {
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
-  int gemm3 = 0;                   // NT-form GEMM / SYRK launches use the three-workgroups-per-CU kernel (gemm3_f64_kernel)
+  double gemm3_margin = 2.0;       // ... and, inside the factorisation / forward substitution, only while the remainder update is estimated to take this many times longer than the panel chain beside it
+  int gemm3 = 768;                 // GEMM / SYRK launches (A not transposed) with at least this many 128 x 128 tiles use the three-workgroups-per-CU kernel (gemm3_f64_kernel); 0: never
   int small_tiles_max = 256;       // GEMM launches with at most this many 128x128 tiles use the 64x64-tile kernel
   // workspace
   // descriptor ring: an assembly launch copies its lowered descriptor into a pinned host slot,
@@ -129,6 +130,8 @@ struct lpgp_ctx {
   int pr = 1, pc = 1;
   int grid_set = 0;                // lpgp_dist_set_grid called (else a default grid is chosen at init)
   int dist_broken = 0;             // the communicator was aborted after a failure inside a collective call
+  int live_mats = 0;               // matrices / right-hand sides alive: their storage was laid out for the CURRENT grid (lpgp_dist_set_grid)
+  int dist_bcast = 0;              // panel exchanges as one ncclBroadcast per piece instead of the point-to-point group (LPGP_DIST_COLLECTIVE=bcast)
   double comm_bytes_sent = 0.0, comm_bytes_recv = 0.0;
   hipStream_t s_comm = nullptr;    // panel exchange (RCCL point-to-point group calls)
   hipEvent_t ev_comm[2] = {nullptr, nullptr};
@@ -137,6 +140,7 @@ struct lpgp_ctx {
                                    // beside the small exchanges of the panel chain (operations on ONE communicator are serialised)
   hipEvent_t ev_tail[2] = {nullptr, nullptr};   // the bulk part of the gather into panel buffer 0 / 1 has landed
   hipEvent_t ev_rows[2] = {nullptr, nullptr};   // the rows below panel i are solved (the bulk gather may read them)
+  double dist_chain_us_comm = 120.0;   // per-panel communication on the chain of a multi-GPU factorisation (diagonal-block broadcast + head gather), for the chain-bound / update-bound decision (LPGP_DIST_CHAIN_US_COMM)
   int split_gather = 1;            // P x 1 grids with look-ahead: gather the next diagonal block's rows first, the rest off the chain
   double* d_pack_bulk = nullptr;   // pack / receive buffer of the bulk part
   size_t pack_bulk_cap = 0;
@@ -243,6 +247,9 @@ int sync_stream(lpgp_ctx* ctx, hipStream_t stream);
 // rank is known to be alive): RCCL sets its connections up at first use, inside a BLOCKING host call -- later, with a peer
 // gone, that call would never return; after this every exchange only enqueues kernels, which sync_stream can watch.
 int dist_warm_up(lpgp_ctx* ctx);
+// Link probe (dist.hip; lpgp_dist_link_probe): measured unidirectional rate of every ordered pair of ranks, of one rank
+// sending to all others at once and of all ranks doing so at once, through the transport the panel exchanges use.
+int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out);
 
 // device memory pool (api.hip)
 int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh);
@@ -270,6 +277,7 @@ struct GemmArgs {
   int32_t k;
   double alpha, beta;
   int32_t tri;
+  int32_t occ3 = 1;                // the launch may use the three-workgroups-per-CU kernel (the schedulers clear it while the panel chain runs beside the update: see factor_columns)
   int32_t sshift = 3;              // log2 of the super-tile edge (set by launch_gemm; legacy mapping)
   // dense tile enumeration (set by launch_gemm; map_tile_dense in gemm.hip)
   int32_t dense = 0;
@@ -289,6 +297,7 @@ struct GemmArgs {
 };
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
 int stair_enumerate_host(const GemmArgs& g, int32_t* out, int64_t cap);
+int64_t gemm_valid_tiles(const GemmArgs& g);
 // Tile solves with one step of iterative refinement (gemm.hip: tile_solve_kernel); L = the 128 x 128 diagonal
 // tile of the factor (leading dimension ldl, zeros above the diagonal), linv its explicit inverse (ld 128):
 // X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place

@@ -422,9 +422,9 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       }
       const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
       LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
-      LPGP_TRY(launch_gemm(ctx, sB, 0, 0,
-                           mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, cl - p2, K, -1.0, 1.0, 1),
-                           LPGP_K_SYRK));
+      GemmArgs gb = mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, cl - p2, K, -1.0, 1.0, 1);
+      gb.occ3 = t_b_us > ctx->gemm3_margin * t_chain_us;       // three workgroups per CU only while the chain beside it has slack (gemm.hip)
+      LPGP_TRY(launch_gemm(ctx, sB, 0, 0, gb, LPGP_K_SYRK));
       LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
       have_upd_event = 1;
       last_upd = ctx->ev_upd[it & 1];
@@ -636,10 +636,9 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
     if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     if (p2 < T) {
       LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
-      LPGP_TRY(launch_gemm(ctx, sU, 0, 1,
-                           mk(a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p2 * tb, ldv,
-                              T - p2, mtl, K, -1.0, 1.0, 0),
-                           LPGP_K_GEMM));
+      GemmArgs gb = mk(a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p2 * tb, ldv, T - p2, mtl, K, -1.0, 1.0, 0);
+      gb.occ3 = t_b_us > ctx->gemm3_margin * (ctx->solve_chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed);
+      LPGP_TRY(launch_gemm(ctx, sU, 0, 1, gb, LPGP_K_GEMM));
       LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
       have_upd_event = true;
     } else {

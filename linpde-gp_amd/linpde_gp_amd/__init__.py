@@ -12,10 +12,11 @@ __version__ = "0.1.0"
 from . import _lib  # noqa: F401  (fails loudly when liblpgp.so is missing)
 from . import config  # noqa: E402
 from ._engine import to_device  # noqa: E402
+from ._spawn import spawn  # noqa: E402
 from . import domains, functions, linfuncops, linfunctls, problems, randprocs, randvars  # noqa: E402
 from .randprocs import ConditionalGaussianProcess, GaussianProcess  # noqa: E402
 
 __all__ = [
     "domains", "functions", "linfuncops", "linfunctls", "problems", "randprocs", "randvars",
-    "GaussianProcess", "ConditionalGaussianProcess", "to_device", "config",
+    "GaussianProcess", "ConditionalGaussianProcess", "to_device", "config", "spawn",
 ]

@@ -107,6 +107,29 @@ class Context:
         check(lib.lpgp_dist_grid(self._h, C.byref(a), C.byref(b)), "lpgp_dist_grid")
         return a.value, b.value
 
+    def dist_set_grid(self, pr: int, pc: int):
+        """Pr x Pc process grid (the same call on every rank; after the bring-up only while no matrix is alive)."""
+        check(lib.lpgp_dist_set_grid(self._h, int(pr), int(pc)), "lpgp_dist_set_grid")
+
+    def link_probe(self, nbytes: int = 32 << 20, reps: int = 3) -> dict:
+        """Measured rates of the panel-exchange transport (`lpgp_dist_link_probe`; collective), gathered over all ranks:
+        `pair_gbps[s][d]` (s -> d alone), `one_to_all_gbps[s]` (one link of s while it sends to every peer),
+        `all_to_all_inbound_gbps[r]` (total inbound of rank r while everybody sends to everybody)."""
+        W = self.world
+        out = np.zeros(W * W + W + 1)
+        check(lib.lpgp_dist_link_probe(self._h, int(nbytes), int(reps), as_pd(out)), "lpgp_dist_link_probe")
+        rows = self.comm.allgather(out)
+        best = np.max(np.stack(rows), axis=0)
+        pair = best[:W * W].reshape(W, W)
+        off = ~np.eye(W, dtype=bool)
+        return {"bytes": int(nbytes), "reps": int(reps),
+                "pair_gbps": [[round(float(v), 2) for v in r_] for r_ in pair],
+                "pair_min_gbps": float(pair[off].min()) if W > 1 else 0.0,
+                "pair_median_gbps": float(np.median(pair[off])) if W > 1 else 0.0,
+                "pair_max_gbps": float(pair[off].max()) if W > 1 else 0.0,
+                "one_to_all_gbps": [round(float(v), 2) for v in best[W * W:W * W + W]],
+                "all_to_all_inbound_gbps": [round(float(r_[W * W + W]), 2) for r_ in rows]}
+
     def dist_stats(self, reset: bool = False) -> dict:
         """Bytes this rank sent / received in panel exchanges (seconds inside them: `profile_get()["comm"]`)."""
         s, r = C.c_double(), C.c_double()
@@ -129,6 +152,15 @@ class Context:
 
     def set_option(self, key: str, value: int):
         check(lib.lpgp_set_option(self._h, key.encode(), int(value)), "lpgp_set_option")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        check(lib.lpgp_get_option(self._h, key.encode(), C.byref(v)), "lpgp_get_option")
+        return int(v.value)
+
+    def roofline_kernel_symbol(self) -> str:
+        """Symbol of the kernel behind profiling slot "syrk_trailing" (rank-nb trailing update, remainder half) as rocprofv3 prints it."""
+        return "gemm3_f64_kernel<false, 1>" if self.get_option("gemm3") > 0 else "gemm_f64_kernel<false, false, 1>"
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
@@ -239,6 +271,9 @@ class DeviceArray(np.ndarray):
 def to_device(X, input_shape=None, ctx: Context | None = None) -> DeviceArray:
     """Upload a point array of shape batch + input_shape once; returns an ndarray subclass
     that carries the device handle (and, for a `TensorProductGrid`, its factor point sets)."""
+    from . import _spawn
+    if ctx is None and _spawn.active() is not None:
+        return X                     # single-process multi-GPU front: this process holds no GPU; the workers upload their own copies
     X_in = X
     X = np.ascontiguousarray(np.asarray(X, dtype=np.double))
     if input_shape is None:

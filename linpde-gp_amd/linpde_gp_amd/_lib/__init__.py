@@ -68,12 +68,14 @@ def _load() -> C.CDLL:
     sig("lpgp_device_info", C.c_int, vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64))
     sig("lpgp_sync", C.c_int, vp)
     sig("lpgp_set_option", C.c_int, vp, C.c_char_p, i64)
+    sig("lpgp_get_option", C.c_int, vp, C.c_char_p, C.POINTER(i64))
     sig("lpgp_dist_unique_id", C.c_int, C.c_char_p)
     sig("lpgp_dist_init", C.c_int, vp, i32, i32, C.c_char_p)
     sig("lpgp_dist_info", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
     sig("lpgp_dist_set_grid", C.c_int, vp, i32, i32)
     sig("lpgp_dist_grid", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
     sig("lpgp_dist_stats", C.c_int, vp, pd, pd, i32)
+    sig("lpgp_dist_link_probe", C.c_int, vp, i64, i32, pd)
     sig("lpgp_test_stair_enumerate", C.c_int, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), i64)
     sig("lpgp_dist_init_host", C.c_int, vp, i32, i32, HOST_EXCHANGE_FN, vp)
     sig("lpgp_dist_ipc_export", C.c_int, vp, i64, C.c_char_p)
@@ -127,8 +129,8 @@ lib = _load()
 
 EXPORTED = [
     "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
-    "lpgp_set_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_dist_init_host", "lpgp_dist_ipc_export", "lpgp_dist_init_ipc", "lpgp_dist_set_grid",
-    "lpgp_dist_grid", "lpgp_dist_stats", "lpgp_test_stair_enumerate", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
+    "lpgp_set_option", "lpgp_get_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_dist_init_host", "lpgp_dist_ipc_export", "lpgp_dist_init_ipc", "lpgp_dist_set_grid",
+    "lpgp_dist_grid", "lpgp_dist_stats", "lpgp_dist_link_probe", "lpgp_test_stair_enumerate", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_pop_block", "lpgp_mat_set_view", "lpgp_mat_num_blocks",
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",

@@ -21,6 +21,16 @@ class TensorProductGrid(np.ndarray):
     def __array_finalize__(self, obj):
         self.factors = getattr(obj, "factors", None)
 
+    # pickling (the single-process multi-GPU front ships observation points to its workers): keep the factors
+    def __reduce__(self):
+        fn, args, state = super().__reduce__()
+        return fn, args, (state, self.factors)
+
+    def __setstate__(self, state):
+        base, factors = state
+        super().__setstate__(base)
+        self.factors = factors
+
 
 class Domain:
     def __init__(self, shape, dtype=np.double):

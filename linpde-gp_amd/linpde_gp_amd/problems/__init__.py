@@ -5,16 +5,18 @@ from . import pde
 from ._workloads import (
     Observation,
     Workload,
+    analytic_solution,
     build_prior,
     condition_and_predict,
     heat_1d,
     operator_of,
     poisson_1d,
     poisson_2d,
+    row_residual,
     upload,
 )
 
 __all__ = [
     "pde", "Observation", "Workload", "build_prior", "condition_and_predict", "heat_1d",
-    "operator_of", "poisson_1d", "poisson_2d", "upload",
+    "operator_of", "poisson_1d", "poisson_2d", "upload", "row_residual", "analytic_solution",
 ]

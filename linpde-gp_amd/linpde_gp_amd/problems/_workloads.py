@@ -156,6 +156,35 @@ def operator_of(op: dict, d: int):
     return diffops.LinearDifferentialOperator(coeffs, input_shapes=(shape, ()))
 
 
+def row_residual(u, wl: Workload, rows) -> np.ndarray:
+    """(G w - r)[rows of the largest observation block] with those rows of the Gram matrix RE-EVALUATED through
+    `CovarianceFunction.matrix` (no noise on the collocation block's own rows): a size-independent check of the
+    factorisation and both solves.  Collective in a multi-GPU job (`representer_weights` streams the factor)."""
+    k = u.prior.cov
+    big = max(range(len(wl.observations)), key=lambda i: wl.observations[i].X.shape[0])
+    pde = wl.observations[big]
+    assert pde.noise_var is None
+    rows = np.asarray(rows)
+    D = operator_of(pde.op, wl.d)
+    parts = []
+    for o in wl.observations:
+        Dj = operator_of(o.op, wl.d)
+        kk = k if Dj is None else Dj(k, argnum=1)
+        kk = kk if D is None else D(kk, argnum=0)
+        parts.append(kk.matrix(pde.X[rows], o.X))
+    return np.concatenate(parts, axis=1) @ u.representer_weights - pde.Y[rows]
+
+
+def analytic_solution(wl: Workload):
+    """Closed-form solution of the workload's PDE on the prediction grid where this module knows one (the reference's
+    `problems/pde/_heat.py:96-132` sine series with one coefficient; the 1-D Poisson problem of `_poisson.py:98-134`)."""
+    if wl.name.startswith("heat1d"):
+        return np.exp(-0.1 * (np.pi / 2.0) ** 2 * wl.Xtest[:, 0]) * np.sin(np.pi * (wl.Xtest[:, 1] + 1.0) / 2.0)
+    if wl.name.startswith("poisson1d"):
+        return np.sin(np.pi * wl.Xtest[:, 0])
+    return None
+
+
 def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True, stamps: list | None = None):
     """The canonical user sequence (`experiments/0001_poisson_dirichlet_2d.ipynb` cells 6-22):
     condition block by block, then posterior mean and marginal variance on the test grid.

@@ -81,6 +81,10 @@ class GaussianProcess:
         return np.sqrt(np.maximum(self.var(x), 0.0))
 
     def condition_on_observations(self, Y, X=None, *, L=None, b=None):
+        from .. import _spawn
+        if _spawn.active() is not None:
+            # single-process front of the multi-GPU path: the posterior is built, sharded, by the worker processes
+            return _spawn.condition(self, Y, X, L=L, b=b)
         return ConditionalGaussianProcess.from_observations(self, Y, X, L=L, b=b)
 
 

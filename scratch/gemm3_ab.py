@@ -6,16 +6,16 @@ from linpde_gp_amd import _engine
 ctx = _engine.default_context()
 rng = np.random.default_rng(0)
 ctx.set_option("small_tiles_max", 0)
-def run(m, n, k, tri):
-    A = rng.standard_normal((m, k)); B = A if tri else rng.standard_normal((n, k))
+def run(m, n, k, tri, tb=0):
+    A = rng.standard_normal((m, k)); B = A if tri else (rng.standard_normal((k, n)) if tb else rng.standard_normal((n, k)))
     C = np.zeros((m, n), order="F")
     out = []
     for g3 in (0, 1, 0, 1):
         ctx.set_option("gemm3", g3)
-        _, ms = _engine.test_gemm(ctx, 0, 0, tri, -1.0, A, B, 1.0, C, k, reps=8)
+        _, ms = _engine.test_gemm(ctx, 0, tb, tri, -1.0, A, B, 1.0, C, k, reps=8)
         fl = (m * (m + 1.0) * k) if tri else 2.0 * m * n * k
         out.append(fl / ms / 1e9)
-    print(f"m={m} n={n} k={k} tri={tri}: two-resident {out[0]:.1f} / {out[2]:.1f} TF   three-resident {out[1]:.1f} / {out[3]:.1f} TF", flush=True)
+    print(f"m={m} n={n} k={k} tri={tri} tb={tb}: two-resident {out[0]:.1f} / {out[2]:.1f} TF   three-resident {out[1]:.1f} / {out[3]:.1f} TF", flush=True)
 # correctness first
 P = rng.standard_normal((640, 512)); C0 = rng.standard_normal((640, 640))
 ctx.set_option("gemm3", 1)
@@ -26,6 +26,12 @@ print("gemm3 syrk max err", np.max(np.abs((o - (C0 - P @ P.T))[low])), "upper un
 Bm = rng.standard_normal((384, 80)); Am = rng.standard_normal((256, 80)); C1 = rng.standard_normal((256, 384))
 o, _ = _engine.test_gemm(ctx, 0, 0, 0, -1.5, Am, Bm, 0.5, C1, 80)
 print("gemm3 gemm k=80 max err", np.max(np.abs(o - (0.5 * C1 - 1.5 * Am @ Bm.T))))
+Bk = rng.standard_normal((80, 384))
+o, _ = _engine.test_gemm(ctx, 0, 1, 0, -1.5, Am, Bk, 0.5, C1, 80)
+print("gemm3 gemm tb=1 k=80 max err", np.max(np.abs(o - (0.5 * C1 - 1.5 * Am @ Bk))))
+run(16384, 4224, 512, 0, 1)
+run(8192, 4224, 512, 0, 1)
+run(16384, 4224, 1024, 0, 1)
 run(16384, 16384, 512, 1)
 run(12288, 12288, 512, 1)
 run(8192, 8192, 512, 1)

@@ -24,6 +24,8 @@ lib = C.CDLL(sys.argv[1])
 pd = C.POINTER(C.c_double)
 lib.lpgp_host_kernel_matrix.restype = C.c_int
 lib.lpgp_host_kernel_matrix.argtypes = [C.POINTER(_lib.KDesc), C.c_int32, pd, C.c_int64, pd, C.c_int64, pd]
+lib.lpgp_host_kernel_matrix_fact.restype = C.c_int
+lib.lpgp_host_kernel_matrix_fact.argtypes = lib.lpgp_host_kernel_matrix.argtypes
 lib.lpgp_host_kernel_diag.restype = C.c_int
 lib.lpgp_host_kernel_diag.argtypes = [C.POINTER(_lib.KDesc), C.c_int32, pd]
 lib.lpgp_host_last_error.restype = C.c_char_p
@@ -36,6 +38,13 @@ def host_matrix(k, X0, X1):
     out = np.full((X0.shape[0], X1.shape[0]), np.nan)
     rc = lib.lpgp_host_kernel_matrix(arr, len(arr), _lib.as_pd(X0), X0.shape[0], _lib.as_pd(X1), X1.shape[0], _lib.as_pd(out))
     assert rc == 0, lib.lpgp_host_last_error()
+    # the factored evaluation (per-point exponentials; what the device kernels run on tiles of moderate extent) must agree
+    # with the per-entry one to rounding: |a (x - x0)| <= ~20 on these point sets -> a few 1e-15 relative
+    out_f = np.full_like(out, np.nan)
+    rc = lib.lpgp_host_kernel_matrix_fact(arr, len(arr), _lib.as_pd(X0), X0.shape[0], _lib.as_pd(X1), X1.shape[0], _lib.as_pd(out_f))
+    assert rc == 0, lib.lpgp_host_last_error()
+    scale = max(np.max(np.abs(out)), 1e-300)
+    assert np.max(np.abs(out_f - out)) <= 2e-13 * scale, ("factored vs per-entry evaluation", np.max(np.abs(out_f - out)) / scale)
     v = C.c_double()
     assert lib.lpgp_host_kernel_diag(arr, len(arr), C.byref(v)) == 0
     return out, v.value

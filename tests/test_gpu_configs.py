@@ -87,35 +87,18 @@ def test_c5_heat_mixed_blocks_vs_oracle(lp):
     _vs_oracle(lp, wl)
 
 
-def _row_residual(u, wl, op_of_block, rows):
-    """(G w - r)[rows of the collocation block], with the rows of G re-evaluated through `matrix`."""
-    k = u.prior.cov
-    big = max(range(len(wl.observations)), key=lambda i: wl.observations[i].X.shape[0])
-    pde = wl.observations[big]
-    D = op_of_block(pde)
-    parts = []
-    for i, o in enumerate(wl.observations):
-        Dj = op_of_block(o)
-        kk = k if Dj is None else Dj(k, argnum=1)
-        parts.append(D(kk, argnum=0).matrix(pde.X[rows], o.X))
-    Gr = np.concatenate(parts, axis=1)           # no noise on the collocation block's own rows
-    return Gr @ u.representer_weights - pde.Y[rows]
-
-
 def test_c5_heat_full_size_properties(lp):
     """c5 at full size (512x64 collocation, N_tot = 33 600): residual of G w = r on re-evaluated rows,
     variance inside [0, k(x,x)], and the analytic solution (`problems/pde/_heat.py:96-132`) within the
     reference's own accuracy bar (test_heat.py:25-28: 3e-2)."""
     from linpde_gp_amd import problems
-    from linpde_gp_amd.problems._workloads import operator_of
     wl = problems.heat_1d()
     assert wl.n_total == 33600
     u, mean, var = _run(lp, wl)
     assert np.all(np.isfinite(mean)) and np.all(var > -1e-10) and np.all(var < prior_variance(wl))
-    res = _row_residual(u, wl, lambda o: operator_of(o.op, 2), np.array([0, 63, 64 * 200 + 31, 32767]))
+    res = problems.row_residual(u, wl, np.array([0, 63, 64 * 200 + 31, 32767]))
     assert np.max(np.abs(res)) < 1e-6
-    sol = np.exp(-0.1 * (np.pi / 2.0) ** 2 * wl.Xtest[:, 0]) * np.sin(np.pi * (wl.Xtest[:, 1] + 1.0) / 2.0)
-    assert np.max(np.abs(mean - sol)) < 3e-2
+    assert np.max(np.abs(mean - problems.analytic_solution(wl))) < 3e-2
 
 
 @pytest.mark.slow
@@ -143,12 +126,11 @@ def test_c4_poisson2d_256_properties(lp):
     """c4 on one GPU (N_tot = 66 560: 35.4 GB factor in HBM): the properties of test_full_size_properties
     at four times the matrix order."""
     from linpde_gp_amd import problems
-    from linpde_gp_amd.problems._workloads import operator_of
     wl = problems.poisson_2d(256, m_side=24)
     assert wl.n_total == 66560
     u, mean, var = _run(lp, wl)
     assert np.all(np.isfinite(mean)) and np.all(var > -1e-9) and np.all(var < 4.0)
-    res = _row_residual(u, wl, lambda o: operator_of(o.op, 2), np.array([0, 255, 256 * 100 + 17, 65535]))
+    res = problems.row_residual(u, wl, np.array([0, 255, 256 * 100 + 17, 65535]))
     assert np.max(np.abs(res)) < 1e-5 * 2.0
     Xs = wl.Xtest[:8]
     C = u.cov.matrix(Xs)

@@ -280,3 +280,34 @@ def test_mean_functions_with_closed_form_derivatives():
         diffops.PartialDerivative(diffops.MultiIndex((1, 0)))(f)
     with pytest.raises(NotImplementedError):                       # no derivatives at all: the reference's JAX fallback
         diffops.Laplacian((2,))(F.LambdaFunction(lambda z: z[..., 0], (2,)))
+
+
+def test_spawn_front_reports_a_failed_bring_up():
+    """The single-process multi-GPU front (`_spawn.WorkerGroup`) on a box WITHOUT a GPU: the worker processes start (fresh
+    interpreters), fail to open a device, and the caller gets ONE error that names the cause -- no hang, no orphan."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {os.path.join(root, 'linpde-gp_amd')!r})
+        import linpde_gp_amd as lp
+        try:
+            lp.spawn(2, transport="host", timeout=120.0)
+        except RuntimeError as exc:
+            print("SPAWN-ERR", str(exc)[:300].replace("\\n", " "))
+        else:
+            print("SPAWN-UP")
+    """)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "SPAWN-ERR" in out.stdout and "bring-up failed" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_tensor_product_grid_survives_pickling():
+    import pickle
+    import numpy as np
+    from linpde_gp_amd.domains import TensorProductGrid
+    g = TensorProductGrid(np.linspace(0, 1, 3), np.linspace(-1, 1, 5))
+    h = pickle.loads(pickle.dumps(g))
+    assert type(h) is TensorProductGrid and h.shape == (3, 5, 2) and np.array_equal(h, g)
+    assert all(np.array_equal(a, b) for a, b in zip(h.factors, g.factors))
