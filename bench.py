@@ -336,9 +336,9 @@ def main():
             dev_t = problems.upload(wl)
             prior_t = problems.build_prior(wl)
             problems.condition_and_predict(wl, prior=prior_t, device_arrays=dev_t)       # untimed: allocation, connections
-            dt_t, _ = timed_steps(wl, prior_t, dev_t, 2)
+            dt_t, last_t = timed_steps(wl, prior_t, dev_t, 2)
             trials[name] = {"grid": list(grid), "collective": "bcast" if bc else "p2p", "ms_per_step": dt_t / 2 * 1e3}
-            del dev_t, prior_t
+            del dev_t, prior_t, last_t          # every matrix of this grid must be gone before the next lpgp_dist_set_grid
             gc.collect()
         chosen = min(trials, key=lambda k_: trials[k_]["ms_per_step"])
         _, grid, bc = next(v for v in variants if v[0] == chosen)

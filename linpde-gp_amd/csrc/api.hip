@@ -377,6 +377,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_GEMM3_MARGIN")) ctx->gemm3_margin = std::atof(e);
+  if (const char* e = std::getenv("LPGP_GEMM3_FACT")) ctx->gemm3_fact = std::atoi(e);
   if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_CHAIN_US_COMM")) ctx->dist_chain_us_comm = std::atof(e);
@@ -464,6 +465,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   LPGP_CHECK(ctx && key && value, "lpgp_get_option: null argument");
   if (std::strcmp(key, "nb") == 0) *value = ctx->nb;
   else if (std::strcmp(key, "gemm3") == 0) *value = ctx->gemm3;
+  else if (std::strcmp(key, "gemm3_fact") == 0) *value = ctx->gemm3_fact;
   else if (std::strcmp(key, "dist_bcast") == 0) *value = ctx->dist_bcast;
   else if (std::strcmp(key, "split_gather") == 0) *value = ctx->split_gather;
   else if (std::strcmp(key, "lookahead") == 0) *value = ctx->lookahead;

@@ -41,11 +41,23 @@ struct AsmArgs {
 
 // Per-point exponential factors of the Matern dimensions (eval_entries.h: `Fac`): for group g, dimension j and point p of
 // the tile, E+ = e^{-a (x_p - x0)} and E- = e^{+a (x_p - x0)} with the tile's own origin x0 (its first column point), rows
-// and columns in LDS: [g][j][sign][AT].  Used while |a (x - x0)| <= FACT_TMAX for every point of the tile (argument rounding
-// then stays below 32 eps ~ 7e-15 relative, the size of the error of exp itself times a few); otherwise -- points spread over
-// hundreds of length scales inside one 64 x 64 tile -- the tile falls back to one exp per entry.
+// and columns in LDS: [g][j][sign][AT].  The arguments are carried in double-double (lpgp_exp_factors), so the accuracy of an
+// entry does not depend on its distance from the origin; FACT_TMAX only keeps e^{+-t} far from overflow and the dropped
+// second-order term (t_lo^2 ~ (32 eps)^2) negligible.  Tiles whose points spread further -- dozens of length scales inside
+// one 64 x 64 tile -- fall back to one exp per entry.
 constexpr double FACT_TMAX = 32.0;
 constexpr int AEK = 4;          // entries per thread per pass in the kernels below (1 row x 4 columns; 16 columns per thread)
+
+// the descriptor's coefficient table in one register pair across the wave (eval_entries.h: `Coef`)
+struct LaneCoef {
+  double v;                     // lane i: coef[i]
+  __device__ __forceinline__ double operator()(int idx) const {
+    const int i = __builtin_amdgcn_readfirstlane(idx);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), i);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+    return __hiloint2double(hi, lo);
+  }
+};
 
 template <int D>
 struct LdsFactors {
@@ -73,10 +85,11 @@ __device__ __forceinline__ void stage_factors(const DevDesc* __restrict__ desc, 
 #pragma unroll
     for (int jj = 0; jj < D; ++jj)
       if (jj == j) { x = xp[jj]; o = x0[jj]; }
-    const double t = valid ? G.a[j] * (x - o) : 0.0;
-    if (!(fabs(t) <= FACT_TMAX)) *fast = 0;
-    dst[(size_t)((g * D + j) * 2) * AT + lane] = exp(-t);
-    dst[(size_t)((g * D + j) * 2 + 1) * AT + lane] = exp(t);
+    double ep, em, tabs;
+    lpgp_exp_factors(G.a[j], valid ? x : o, o, ep, em, tabs);
+    if (!(tabs <= FACT_TMAX)) *fast = 0;
+    dst[(size_t)((g * D + j) * 2) * AT + lane] = ep;
+    dst[(size_t)((g * D + j) * 2 + 1) * AT + lane] = em;
   }
 }
 
@@ -115,6 +128,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
   else stage_factors<D>(desc, xc, x0, col < a.n1, sfc, lane, wu - 2, 2, &s_fast);
   __syncthreads();
   const bool fast = s_fast != 0;
+  const int ncoef = desc->ncoef;
+  const bool lanes = ncoef <= 64;                       // the coefficient table fits one register pair across the wave
+  const LaneCoef lc{(lanes && lane < ncoef) ? desc->coef[lane] : 0.0};
 #pragma unroll 1
   for (int pass = 0; pass < 16 / AEK; ++pass) {
     const int cb = w * 16 + pass * AEK;
@@ -123,7 +139,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
     for (int j = 0; j < D; ++j)
 #pragma unroll
       for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-    if (fast) {
+    if (fast && lanes) {
+      LdsFactors<D> fac{sfr + lane, sfc + cb};
+      eval_entries<D, AEK, LdsFactors<D>, LaneCoef>(desc, dx, res, fac, lc);
+    } else if (fast) {
       LdsFactors<D> fac{sfr + lane, sfc + cb};
       eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
     } else {
@@ -173,6 +192,7 @@ static int stage_desc(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_des
   }
   const size_t bytes = offsetof(DevDesc, coef) + (size_t)ncoef * sizeof(double);
   std::memcpy(slot.h, &host_desc, bytes);
+  slot.h->ncoef = ncoef;
   LPGP_HIP(hipMemcpyAsync(slot.d, slot.h, bytes, hipMemcpyHostToDevice, stream));
   *out = &slot;
   return 0;
@@ -261,6 +281,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   if (threadIdx.x == 0) { s_fast_r = 1; s_fast_c[0] = 1; s_fast_c[1] = 1; }
   __syncthreads();
   stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
+  const int ncoef = desc->ncoef;
+  const bool lanes = ncoef <= 64;
+  const LaneCoef lc{(lanes && lane < ncoef) ? desc->coef[lane] : 0.0};
   for (int tc = sp * per; tc < tc_end; ++tc) {
     __syncthreads();                                   // previous tile consumed (first tile: flags initialised)
     {
@@ -283,7 +306,10 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
       for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-      if (fast) {
+      if (fast && lanes) {
+        LdsFactors<D> fac{sfr + lane, sfc + cb};
+        eval_entries<D, AEK, LdsFactors<D>, LaneCoef>(desc, dx, res, fac, lc);
+      } else if (fast) {
         LdsFactors<D> fac{sfr + lane, sfc + cb};
         eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
       } else {

@@ -52,14 +52,42 @@ LPGP_HD double lpgp_xor_sign(double v, unsigned s) {
 // per-entry exponential (e^{-(u-u')^2/2} does not split without an exponential of the cross term), as do isotropic groups.
 // Rounding: the argument a (x - x0) carries a relative error of one ulp, i.e. |a (x - x0)| eps absolute in the exponent, so the
 // provider is only used while |a (x - x0)| stays below a small bound on the tile (assemble.hip: FACT_TMAX).
+// The per-point factors E+ = e^{-a (x - x0)}, E- = e^{+a (x - x0)} with the argument carried in double-double: t = a (x - x0)
+// = t_hi + t_lo exactly (TwoSum of the difference, FMA residual of the product), E+- = exp(-+t_hi) (1 -+ t_lo).  Without
+// the low part the argument's rounding error, |t| eps, becomes a RELATIVE error of the entry -- also for near pairs x ~ x'
+// far from the origin, where the direct evaluation exp(-a |x - x'|) is exact to an ulp; on Gram matrices of condition 1e9
+// that moved the posterior by 3e-8 (tests/test_gpu_random.py, seed 107).  With it the entry carries the two exp roundings
+// and one multiply, whatever the distance to the origin.
+LPGP_HD void lpgp_exp_factors(double a, double x, double x0, double& ep, double& em, double& t_abs) {
+  const double d_hi = x - x0;
+  const double bb = d_hi - x;
+  const double d_lo = (x - (d_hi - bb)) + (-x0 - bb);          // x - x0 = d_hi + d_lo exactly
+  const double t_hi = a * d_hi;
+  const double t_lo = fma(a, d_hi, -t_hi) + a * d_lo;
+  const double e1 = exp(-t_hi), e2 = exp(t_hi);
+  ep = fma(-t_lo, e1, e1);
+  em = fma(t_lo, e2, e2);
+  t_abs = fabs(t_hi);
+}
+
 struct NoFactors {
   static constexpr bool enabled = false;
   LPGP_HD double pair(int, int, int) const { return 1.0; }
 };
 
-template <int D, int NE = AE, class Fac = NoFactors>
+// Where the polynomial coefficients come from.  `MemCoef` reads the descriptor's table (scalar loads on the device: one
+// load-to-use latency per coefficient inside the Horner loops -- measured to bound the assembly kernel); the device kernels
+// pass a provider that keeps the whole table in ONE register pair spread over the lanes of the wave (coefficient i in lane
+// i, a single coalesced load per kernel) and broadcasts coefficient i with two v_readlane (assemble.hip: LaneCoef) whenever
+// the table has at most 64 entries.
+struct MemCoef {
+  const double* base;
+  LPGP_HD double operator()(int idx) const { return base[idx]; }
+};
+
+template <int D, int NE, class Fac, class Coef>
 LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
-                                             const double (&dx)[D][NE], double (&res)[NE], const Fac& fac = Fac()) {
+                                             const double (&dx)[D][NE], double (&res)[NE], const Fac& fac, const Coef& coef) {
   constexpr int AE = NE;          // (entries per call: the name the body uses)
 #pragma unroll
   for (int e = 0; e < AE; ++e) res[e] = 0.0;
@@ -97,14 +125,12 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
           for (int e = 0; e < AE; ++e) quad[e] = fma(u[i][e], bu[e], quad[e]);
         }
       }
-      const double* __restrict__ q0 = desc->coef + G.coef_off[0];
-      const double* __restrict__ q1 = desc->coef + G.coef_off[1];
-      const double* __restrict__ q2 = desc->coef + G.coef_off[2];
+      const int q0 = G.coef_off[0], q1 = G.coef_off[1], q2 = G.coef_off[2];
       double sv[AE], v0[AE], v1[AE], v2[AE];
 #pragma unroll
       for (int e = 0; e < AE; ++e) { sv[e] = sqrt(s2[e]); v0[e] = 0.0; v1[e] = 0.0; v2[e] = 0.0; }
       for (int k = G.deg[0]; k >= 0; --k) {
-        const double c0 = q0[k], c1 = q1[k], c2 = q2[k];
+        const double c0 = coef(q0 + k), c1 = coef(q1 + k), c2 = coef(q2 + k);
 #pragma unroll
         for (int e = 0; e < AE; ++e) {
           v0[e] = fma(v0[e], sv[e], c0);
@@ -149,14 +175,14 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
     const int n2 = (D > 2) ? G.deg[D > 2 ? 2 : 0] + 1 : 1;
     const int n3 = (D > 3) ? G.deg[D > 3 ? 3 : 0] + 1 : 1;
     for (int c = 0; c < G.ncls; ++c) {
-      const double* __restrict__ cf = desc->coef + G.coef_off[c];
+      const int cf = G.coef_off[c];
       const int par = G.parity[c];
       double acc0[AE];
 #pragma unroll
       for (int e = 0; e < AE; ++e) acc0[e] = 0.0;
       for (int i0 = G.deg[0]; i0 >= 0; --i0) {
         if constexpr (D == 1) {
-          const double cv = cf[i0];
+          const double cv = coef(cf + i0);
 #pragma unroll
           for (int e = 0; e < AE; ++e) acc0[e] = fma(acc0[e], r[0][e], cv);
         } else {
@@ -165,7 +191,7 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
           for (int e = 0; e < AE; ++e) acc1[e] = 0.0;
           for (int i1 = n1 - 1; i1 >= 0; --i1) {
             if constexpr (D == 2) {
-              const double cv = cf[i0 * n1 + i1];
+              const double cv = coef(cf + i0 * n1 + i1);
 #pragma unroll
               for (int e = 0; e < AE; ++e) acc1[e] = fma(acc1[e], r[1][e], cv);
             } else {
@@ -174,7 +200,7 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
               for (int e = 0; e < AE; ++e) acc2[e] = 0.0;
               for (int i2 = n2 - 1; i2 >= 0; --i2) {
                 if constexpr (D == 3) {
-                  const double cv = cf[(i0 * n1 + i1) * n2 + i2];
+                  const double cv = coef(cf + (i0 * n1 + i1) * n2 + i2);
 #pragma unroll
                   for (int e = 0; e < AE; ++e) acc2[e] = fma(acc2[e], r[2][e], cv);
                 } else {
@@ -182,7 +208,7 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
 #pragma unroll
                   for (int e = 0; e < AE; ++e) acc3[e] = 0.0;
                   for (int i3 = n3 - 1; i3 >= 0; --i3) {
-                    const double cv = cf[((i0 * n1 + i1) * n2 + i2) * n3 + i3];
+                    const double cv = coef(cf + ((i0 * n1 + i1) * n2 + i2) * n3 + i3);
 #pragma unroll
                     for (int e = 0; e < AE; ++e) acc3[e] = fma(acc3[e], r[D - 1][e], cv);
                   }
@@ -216,6 +242,11 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
       for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * ef[e], tot[e], res[e]);
     }
   }
+}
+
+template <int D, int NE = AE, class Fac = NoFactors>
+LPGP_HD void eval_entries(const DevDesc* __restrict__ desc, const double (&dx)[D][NE], double (&res)[NE], const Fac& fac = Fac()) {
+  eval_entries<D, NE, Fac, MemCoef>(desc, dx, res, fac, MemCoef{desc->coef});
 }
 
 }  // namespace lpgp

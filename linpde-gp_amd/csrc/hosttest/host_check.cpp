@@ -35,8 +35,10 @@ struct HostFactors {
   double xr[D], xc[D][AE], x0[D];
   double pair(int g, int j, int e) const {
     const double a = desc->g[g].a[j];
-    const double tr = a * (xr[j] - x0[j]), tc = a * (xc[j][e] - x0[j]);
-    const double p1 = std::exp(-tr) * std::exp(tc), p2 = std::exp(tr) * std::exp(-tc);
+    double rp, rm, cp, cm, t;
+    lpgp_exp_factors(a, xr[j], x0[j], rp, rm, t);
+    lpgp_exp_factors(a, xc[j][e], x0[j], cp, cm, t);
+    const double p1 = rp * cm, p2 = rm * cp;
     return p1 < p2 ? p1 : p2;
   }
 };

@@ -160,7 +160,7 @@ class Context:
 
     def roofline_kernel_symbol(self) -> str:
         """Symbol of the kernel behind profiling slot "syrk_trailing" (rank-nb trailing update, remainder half) as rocprofv3 prints it."""
-        return "gemm3_f64_kernel<false, 1>" if self.get_option("gemm3") > 0 else "gemm_f64_kernel<false, false, 1>"
+        return "gemm3_f64_kernel<false, 1>" if (self.get_option("gemm3") > 0 and self.get_option("gemm3_fact")) else "gemm_f64_kernel<false, false, 1>"
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
