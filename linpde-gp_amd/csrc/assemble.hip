@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "lpgp_internal.h"
@@ -36,6 +37,7 @@ struct AsmArgs {
   int64_t row_off, col_off;
   int32_t lower_only;           // symmetric diagonal block: skip tiles strictly above diagonal
   int32_t tiles_r, tiles_c;
+  int32_t flags = 0;            // bit 0: per-point exponential factors (lpgp_ctx::asm_factors); measurement aids (LPGP_ASM_DIAG): bit 1 = no evaluation (stores only), bit 2 = no stores (evaluation only)
   Layout2D lay;                 // where element (row_off + i, col_off + j) lives on this rank (multi-GPU: only the owned tiles are written)
 };
 
@@ -47,17 +49,6 @@ struct AsmArgs {
 // one 64 x 64 tile -- fall back to one exp per entry.
 constexpr double FACT_TMAX = 32.0;
 constexpr int AEK = 4;          // entries per thread per pass in the kernels below (1 row x 4 columns; 16 columns per thread)
-
-// the descriptor's coefficient table in one register pair across the wave (eval_entries.h: `Coef`)
-struct LaneCoef {
-  double v;                     // lane i: coef[i]
-  __device__ __forceinline__ double operator()(int idx) const {
-    const int i = __builtin_amdgcn_readfirstlane(idx);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), i);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
-    return __hiloint2double(hi, lo);
-  }
-};
 
 template <int D>
 struct LdsFactors {
@@ -121,16 +112,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
 #pragma unroll
     for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = xc[j];
   }
-  if (threadIdx.x == 0) s_fast = 1;
+  if (threadIdx.x == 0) s_fast = a.flags & 1;
   __syncthreads();
-  // waves 0,1: row factors; waves 2,3: column factors
-  if (wu < 2) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 2, &s_fast);
-  else stage_factors<D>(desc, xc, x0, col < a.n1, sfc, lane, wu - 2, 2, &s_fast);
-  __syncthreads();
+  if (a.flags & 1) {
+    // waves 0,1: row factors; waves 2,3: column factors
+    if (wu < 2) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 2, &s_fast);
+    else stage_factors<D>(desc, xc, x0, col < a.n1, sfc, lane, wu - 2, 2, &s_fast);
+    __syncthreads();
+  }
   const bool fast = s_fast != 0;
-  const int ncoef = desc->ncoef;
-  const bool lanes = ncoef <= 64;                       // the coefficient table fits one register pair across the wave
-  const LaneCoef lc{(lanes && lane < ncoef) ? desc->coef[lane] : 0.0};
+  double sink = 0.0;
 #pragma unroll 1
   for (int pass = 0; pass < 16 / AEK; ++pass) {
     const int cb = w * 16 + pass * AEK;
@@ -139,16 +130,19 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
     for (int j = 0; j < D; ++j)
 #pragma unroll
       for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-    if (fast && lanes) {
-      LdsFactors<D> fac{sfr + lane, sfc + cb};
-      eval_entries<D, AEK, LdsFactors<D>, LaneCoef>(desc, dx, res, fac, lc);
+    if (a.flags & 2) {
+#pragma unroll
+      for (int e = 0; e < AEK; ++e) res[e] = dx[0][e];
     } else if (fast) {
       LdsFactors<D> fac{sfr + lane, sfc + cb};
       eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
     } else {
       eval_entries<D, AEK>(desc, dx, res);
     }
-    if (row < a.n0) {
+    if (a.flags & 4) {
+#pragma unroll
+      for (int e = 0; e < AEK; ++e) sink += res[e];
+    } else if (row < a.n0) {
 #pragma unroll
       for (int e = 0; e < AEK; ++e) {
         int64_t c = c0 + cb + e;
@@ -156,6 +150,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
       }
     }
   }
+  if ((a.flags & 4) && sink == 0.12345 && row < a.n0) a.out[lrow0 + lane + lcol0 * a.ld] = sink;
 }
 
 __global__ void add_diag_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar, Layout2D lay) {
@@ -214,6 +209,8 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
+  static const int diag = [] { const char* e = std::getenv("LPGP_ASM_DIAG"); return e ? std::atoi(e) : 0; }();
+  a.flags = (ctx->asm_factors ? 1 : 0) | ((diag & 3) << 1);
   dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
   double entries = lower_only ? 0.5 * (double)n0 * ((double)n0 + 1.0) : (double)n0 * (double)n1;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
@@ -250,6 +247,7 @@ struct MvArgs {
   const double* v;               // device, [r][n1_pad]
   double* part;                  // device, [split][r][n0_pad]
   int32_t nr;                    // right-hand sides in this pass (<= MV_R)
+  int32_t factors;               // per-point exponential factors (lpgp_ctx::asm_factors)
   int32_t tiles_r, tiles_c, splits;
 };
 
@@ -278,12 +276,10 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   for (int r = 0; r < MV_R; ++r) y[r] = 0.0;
   const int per = (a.tiles_c + a.splits - 1) / a.splits;
   const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
-  if (threadIdx.x == 0) { s_fast_r = 1; s_fast_c[0] = 1; s_fast_c[1] = 1; }
+  if (threadIdx.x == 0) { s_fast_r = a.factors; s_fast_c[0] = 1; s_fast_c[1] = 1; }
   __syncthreads();
-  stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
-  const int ncoef = desc->ncoef;
-  const bool lanes = ncoef <= 64;
-  const LaneCoef lc{(lanes && lane < ncoef) ? desc->coef[lane] : 0.0};
+  if (a.factors) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
+
   for (int tc = sp * per; tc < tc_end; ++tc) {
     __syncthreads();                                   // previous tile consumed (first tile: flags initialised)
     {
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
       double xc[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) xc[j] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-      stage_factors<D>(desc, xc, x0, c < a.n1, sfc, lane, wu, 4, &s_fast_c[tc & 1]);
+      if (a.factors) stage_factors<D>(desc, xc, x0, c < a.n1, sfc, lane, wu, 4, &s_fast_c[tc & 1]);
       if (threadIdx.x == 0) s_fast_c[(tc + 1) & 1] = 1;       // the next tile's flag (read two barriers from now)
     }
     __syncthreads();
@@ -306,10 +302,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
       for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
-      if (fast && lanes) {
-        LdsFactors<D> fac{sfr + lane, sfc + cb};
-        eval_entries<D, AEK, LdsFactors<D>, LaneCoef>(desc, dx, res, fac, lc);
-      } else if (fast) {
+      if (fast) {
         LdsFactors<D> fac{sfr + lane, sfc + cb};
         eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
       } else {
@@ -354,6 +347,7 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   MvArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.v = v; a.part = part; a.nr = nr;
+  a.factors = ctx->asm_factors ? 1 : 0;
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   a.splits = splits;

@@ -75,11 +75,10 @@ struct NoFactors {
   LPGP_HD double pair(int, int, int) const { return 1.0; }
 };
 
-// Where the polynomial coefficients come from.  `MemCoef` reads the descriptor's table (scalar loads on the device: one
-// load-to-use latency per coefficient inside the Horner loops -- measured to bound the assembly kernel); the device kernels
-// pass a provider that keeps the whole table in ONE register pair spread over the lanes of the wave (coefficient i in lane
-// i, a single coalesced load per kernel) and broadcasts coefficient i with two v_readlane (assemble.hip: LaneCoef) whenever
-// the table has at most 64 entries.
+// Where the polynomial coefficients come from.  `MemCoef` reads the descriptor's table (scalar loads on the device).  Round 3
+// tried a provider that keeps the whole table in ONE register pair spread over the lanes of the wave (a single coalesced load
+// per kernel, two v_readlane per coefficient: no load-to-use latency inside the Horner loops): 2.81 against 2.89 TB/s on the
+// 4096 x 16384 cross-covariance -- the scalar loads are not what bounds the kernel -- and it was removed again.
 struct MemCoef {
   const double* base;
   LPGP_HD double operator()(int idx) const { return base[idx]; }

@@ -106,6 +106,8 @@ struct lpgp_ctx {
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
+  int asm_factors = 0;             // per-entry assembly / matrix-free product: exponentials of Matern dimensions from per-point factors (eval_entries.h);
+                                   // +13 % on the kernel, ~4x the rounding noise of the entries (two exps and a product instead of one exp): off by default
   int gemm3_fact = 0;              // ... inside the FACTORISATION only if set: beside the panel chain the third resident workgroup costs the chain what it gains the update (c3: condition phase 33.6 -> 34.1 ms with it, predict phase 22.9 -> 22.6 ms: the forward substitution keeps it)
   double gemm3_margin = 2.0;       // ... and, inside the factorisation / forward substitution, only while the remainder update is estimated to take this many times longer than the panel chain beside it
   int gemm3 = 768;                 // GEMM / SYRK launches (A not transposed) with at least this many 128 x 128 tiles use the three-workgroups-per-CU kernel (gemm3_f64_kernel); 0: never

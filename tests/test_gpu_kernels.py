@@ -135,6 +135,49 @@ def test_matrix_free_product_matches_dense(ctx):
     np.testing.assert_allclose(k3.linop(Y) @ np.arange(70.0), k3.matrix(Y) @ np.arange(70.0), rtol=1e-12)
 
 
+def test_per_point_exponential_factors_option(ctx):
+    """Option `asm_factors` (off by default): the exponential of every Matern dimension from per-point factors
+    `e^{-+a(x - x0)}` (two multiplies and a minimum per entry instead of an exp; eval_entries.h).  Entries against the
+    oracle and against the default per-entry evaluation on the reference's kind of point set, on a grid-like set (tiles of
+    small extent), on a product of Matern and ExpQuad dimensions (the ExpQuad keeps its per-entry exp), on an isotropic
+    Matern (untouched), and on points spread over hundreds of length scales (per-tile fallback to the per-entry exp)."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd.linfuncops import diffops
+    from oracle import covfuncs as ocf
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(5)
+    k2 = 4.0 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=3.5, lengthscales=0.6))
+    ok2 = [(4.0, [("matern", 2.5, 1.0), ("matern", 3.5, 0.6)])]
+    D = -1.0 * diffops.Laplacian((2,))
+    lap, ident = {(2, 0): -1.0, (0, 2): -1.0}, ocf.identity(2)
+    km = 1.5 * cf.TensorProduct(cf.ExpQuad((), lengthscales=0.5), cf.Matern((), nu=1.5, lengthscales=0.8))
+    okm = [(1.5, [("expquad", 0.5), ("matern", 1.5, 0.8)])]
+    kiso = cf.Matern((2,), nu=2.5, lengthscales=[0.7, 1.1])
+    g = np.linspace(-1, 1, 40)
+    sets = [(rng.uniform(-3, 3, (150, 2)), rng.uniform(-3, 3, (77, 2))),
+            (np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)[:300], np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2)),
+            (rng.uniform(-150, 150, (130, 2)), rng.uniform(-150, 150, (90, 2)))]
+    try:
+        for X0, X1 in sets:
+            for k, ok, L0, L1 in [(k2, ok2, ident, ident), (D(k2, argnum=1), ok2, ident, lap), (D(D(k2, argnum=1), argnum=0), ok2, lap, lap),
+                                  (km, okm, ident, ident)]:
+                ctx.set_option("asm_factors", 0)
+                K0 = k.matrix(X0, X1)
+                ctx.set_option("asm_factors", 1)
+                K1 = k.matrix(X0, X1)
+                ref = ocf.LkL(ok, L0, L1, X0, X1)
+                scale = np.max(np.abs(ref))
+                assert np.max(np.abs(K1 - ref)) <= 1e-13 * scale and np.max(np.abs(K1 - K0)) <= 2e-14 * scale
+                V = rng.standard_normal((X1.shape[0], 3))
+                np.testing.assert_allclose(k.linop(X0, X1) @ V, K1 @ V, rtol=0, atol=1e-11 * scale * X1.shape[0])
+            ctx.set_option("asm_factors", 0)
+            Ki0 = kiso.matrix(X0, X1)
+            ctx.set_option("asm_factors", 1)
+            np.testing.assert_array_equal(kiso.matrix(X0, X1), Ki0)
+    finally:
+        ctx.set_option("asm_factors", 0)
+
+
 def test_matrix_free_product_throughput(ctx):
     import time
     import linpde_gp_amd as lp
