@@ -365,6 +365,11 @@ int lpgp_init(int device, lpgp_ctx** out) {
     long v = std::atol(e);
     if (v >= TILE && v % TILE == 0) ctx->nb = v;
   }
+  if (const char* e = std::getenv("LPGP_NB_OUTER_SOLVE")) {
+    long v = std::atol(e);
+    if (v >= 0 && v % TILE == 0) ctx->nb_outer_solve = v;
+  }
+  if (const char* e = std::getenv("LPGP_NB_OUTER_SOLVE_MIN_TILES")) ctx->nb_outer_solve_min_tiles = std::atoi(e);
   if (const char* e = std::getenv("LPGP_NB_SOLVE")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_solve = v;
@@ -507,6 +512,9 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   } else if (std::strcmp(key, "nb_solve") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_solve must be a multiple of %d (0: nb)", TILE);
     ctx->nb_solve = value;
+  } else if (std::strcmp(key, "nb_outer_solve") == 0) {
+    LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer_solve must be a multiple of %d (0 disables)", TILE);
+    ctx->nb_outer_solve = value;
   } else if (std::strcmp(key, "nb_outer") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer must be a multiple of %d (0 disables)", TILE);
     ctx->nb_outer = value;

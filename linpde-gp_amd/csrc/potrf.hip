@@ -186,40 +186,33 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           piv = 1.0;
         }
         // inv = piv^{-1/2}: hardware estimate + one Newton step; l = piv*inv refined once more; inv kept consistent with
-        // the refined l.  (Round 3 tried scaling the column with the once-refined inv, the second refinement only for the
-        // diagonal entry, off the pivot-to-pivot chain: four dependent fp64 operations fewer per pivot, 41 -> 39 us per
-        // tile -- and a backward error of the factor of 1.0e-15 instead of ~3e-16, which on Gram matrices of condition 1e9
-        // moved the posterior mean from < 1e-8 to 1.3e-8 of the refined solution (tests/test_gpu_random.py, seed 107).
-        // The last ulp of the column scaling is worth its 2 us.)
+        // the refined l.  (Round 3 tried scaling the column with the once-refined inv and refining only the diagonal entry,
+        // off the pivot-to-pivot chain: four dependent fp64 operations fewer per pivot, 41 -> 39 us per tile.  The tile's own
+        // backward error did not move (1.0e-15 of max |A| either way), but tests/test_gpu_random.py seed 107 -- a Gram
+        // matrix of condition ~1e9 -- went from inside the 1e-8 bar to 1.3e-8 of the refined posterior with nothing else
+        // changed: the last ulp of the column scaling is worth its 2 us.)
         double inv = __builtin_amdgcn_rsq(piv);
         inv = fma(inv, 0.5 * fma(-piv * inv, inv, 1.0), inv);
         double l = piv * inv;
         const double res = fma(-l, l, piv);
         l = fma(0.5 * inv, res, l);
         inv = fma(inv, -0.5 * inv * inv * res, inv);       // keep inv consistent with the refined l
-        const double scaled = row[j] * inv;
-        row[j] = (i == j) ? l : scaled;
+        row[j] = (i == j) ? l : row[j] * inv;
         x[j] = (j >= c) ? x[j] * inv : 0.0;                // (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]
-        // two columns per round: the broadcast of the second is issued before the first is consumed (a v_readlane result
-        // needs two wait states before a VALU operation may read it)
 #pragma unroll
-        for (int k = j + 1; k < 16; k += 2) {
-          const double lkj = bcast_lane(scaled, k);        // L[k][j]
-          const double lkj2 = (k + 1 < 16) ? bcast_lane(scaled, k + 1 < 16 ? k + 1 : k) : 0.0;
-          row[k] = fma(-scaled, lkj, row[k]);
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = bcast_lane(row[j], k);        // L[k][j]
+          row[k] = fma(-row[j], lkj, row[k]);
           x[k] = fma(-lkj, x[j], x[k]);
-          if (k + 1 < 16) {
-            row[k + 1] = fma(-scaled, lkj2, row[k + 1]);
-            x[k + 1] = fma(-lkj2, x[j], x[k + 1]);
-          }
-          // pin the updates here: left alone, the compiler sinks all updates of x[k] and row[k]
+          // pin both updates here: left alone, the compiler sinks all updates of x[k] and row[k]
           // down to pivot step k (their first use) and either parks the broadcast L[k][j] in VGPR
           // lanes until then (264 v_writelane / v_readlane spill pairs) or broadcasts it twice.
           // (Tried and measured equal or slower: one instruction stream for both recurrences with
           // factor rows on lanes 0-15 and inverse columns on lanes 16-31; s_setprio for this wave;
-          // keeping its SIMD free of background waves.)
-          if (k + 1 < 16) asm volatile("" : "+v"(x[k]), "+v"(row[k]), "+v"(x[k + 1]), "+v"(row[k + 1]));
-          else asm volatile("" : "+v"(x[k]), "+v"(row[k]));
+          // keeping its SIMD free of background waves; round 3: two columns per round with their broadcasts issued back
+          // to back -- 84 of the 113 s_nop disappear from the listing and the kernel takes 44.2 instead of 41.0 us.
+          // ~450 cycles per pivot step remain.)
+          asm volatile("" : "+v"(x[k]), "+v"(row[k]));
         }
       }
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
@@ -584,6 +577,70 @@ int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t 
   return 0;
 }
 
+// Two-level forward substitution (round 3).  The right-looking solve below applies every panel of 512 columns to ALL rows
+// beneath it: each update reads and writes the whole remaining right-hand side for 512 steps of contraction, and runs at
+// the K = 512 rate of the GEMM (51-52 TFLOP/s in situ against 57 at K = 1024 and 61+ at K = 2048: every C tile is loaded
+// and stored once per launch).  Here `NBt` tile rows (2048 rows) form an OUTER block: inside it the
+// fused panel chains (panel_solve_kernel, 512 rows each) and their rank-512 updates touch the block's own rows only --
+// short launches on the panel stream -- and everything below the block is updated ONCE per block with K = 2048, split
+// like every update of this file into the next block's rows (a), on the panel stream, and the rest (b), on the update
+// stream, underneath which the next block's inner work runs.  7/8 of the flops move to the long-K launches.  Unlike the
+// factorisation -- where the same idea (`nb_outer`) loses at c3 sizes because workgroups of a long-K update hold their CU
+// slots four times longer and starve the panel chain's many small kernels -- the substitution's chain is one fused launch
+// per panel, and the inner work of a block has a whole outer update to hide under.
+// Measured (bench.py, predict phase; LPGP_NB_OUTER_SOLVE = 0 / 1024 / 2048 / 4096): c4 (520 tile rows) 1113 / - / 1075 /
+// 1063 ms; c5 (263) 80.2 / 78.8 / 80.9 / - ms; c3 (132) 22.9 / 22.7 / 23.6 / - ms; c2 (65) 2.80 / 2.69 / 2.87 / - ms: the
+// outer updates do run at the long-K rate, but with few outer blocks the inner work of the first block and the tail are not
+// hidden, and (a), (b) and the inner launches share one chip.  Used from 384 tile rows on, with blocks of 4096 rows.
+static int trsm_lower_two_level(lpgp_ctx* ctx, lpgp_mat* mat, int T, double* v, int64_t ldv, int mtl, int nbt, int NBt) {
+  const int64_t ld = mat->cap, tb = TILE;
+  const double* a = mat->a;
+  hipStream_t sP = ctx->s_main, sU = ctx->s_upd_all;
+  auto upd = [&](hipStream_t st, int c0, int c1, int r0, int r1) -> int {        // rows [r0, r1) -= L[rows, c0:c1] V[c0:c1]
+    if (r1 <= r0) return 0;
+    GemmArgs g = mk(a + (int64_t)r0 * tb + (int64_t)c0 * tb * ld, ld, v + (int64_t)c0 * tb, ldv, v + (int64_t)r0 * tb, ldv, r1 - r0, mtl,
+                    (c1 - c0) * TILE, -1.0, 1.0, 0);
+    return launch_gemm(ctx, st, 0, 1, g, LPGP_K_GEMM);
+  };
+  bool have_upd_event = false;
+  int it = 0;
+  for (int q0 = 0; q0 < T; q0 += NBt, ++it) {
+    const int q1 = (q0 + NBt < T) ? q0 + NBt : T;
+    // inner: the block's own rows, right-looking by fused panels
+    for (int p0 = q0; p0 < q1; p0 += nbt) {
+      const int p1 = (p0 + nbt < q1) ? p0 + nbt : q1;
+      LPGP_TRY(launch_trsv_panel(ctx, sP, v + (int64_t)p0 * tb, ldv, mat->linv + (int64_t)p0 * tb * tb, a + (int64_t)p0 * tb * (ld + 1), ld,
+                                 p1 - p0, mtl, LPGP_K_PANEL));
+      LPGP_TRY(upd(sP, p0, p1, p1, q1));
+    }
+    if (q1 >= T) break;
+    const int q2 = (q1 + NBt < T) ? q1 + NBt : T;
+    // outer update with K = (q1 - q0) * 128.  (b) is released with the block while it bounds the pipeline -- (a), too small
+    // to fill the chip alone, then runs underneath it -- and after (a) once the next block's inner work would be the bound
+    const double K = (double)(q1 - q0) * TILE;
+    const double t_b_us = (double)(T - q2) * mtl * (2.0 * TILE * TILE * K / 55e6);
+    const double t_inner_us = ctx->solve_chain_us_tile * (double)(q2 - q1) + ctx->chain_us_fixed * (double)((q2 - q1 + nbt - 1) / nbt) +
+                              0.5 * (double)(q2 - q1) * mtl * (2.0 * TILE * TILE * (double)(nbt * TILE) / 45e6);
+    const bool chain_bound = t_b_us < t_inner_us;
+    hipEvent_t evp = ctx->ev_panel[it & 1];
+    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));      // (a)'s rows: last written by the previous (b)
+    LPGP_TRY(upd(sP, q0, q1, q1, q2));
+    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    if (q2 < T) {
+      LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+      LPGP_TRY(upd(sU, q0, q1, q2, T));
+      LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+      have_upd_event = true;
+    } else {
+      have_upd_event = false;
+    }
+  }
+  LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
+  LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
+  return 0;
+}
+
 // V <- L^{-1} V for a padded (T*128) x m_pad block, column-major with leading dim ldv.
 // Right-looking by panels with the same look-ahead as the factorisation: the latency-bound
 // tile steps of panel p+1 (products with tile inverses, K = 128) run on the panel stream while
@@ -605,6 +662,11 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   const bool fused = ctx->fused_solve && nbt <= 4;
   const double* a = mat->a;
   const bool la = ctx->lookahead != 0 && mtl >= 8;       // worth it only for wide right-hand sides
+  {
+    const int NBt = (int)(ctx->nb_outer_solve / TILE), nbi = (int)(ctx->nb / TILE);
+    if (la && ctx->fused_solve && ctx->nb_solve == 0 && nbi <= 4 && NBt > nbi && NBt % nbi == 0 && T >= ctx->nb_outer_solve_min_tiles && T >= 2 * NBt)
+      return trsm_lower_two_level(ctx, mat, T, v, ldv, mtl, nbi, NBt);
+  }
   hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
   bool have_upd_event = false;
   int it = 0;
