@@ -328,6 +328,14 @@ int lpgp_init(int device, lpgp_ctx** out) {
       *out = nullptr;
     }
   };
+  // LPGP_SINGLE_STREAM=1: every stream of the context is the panel stream (no concurrency between chain and update).  For
+  // jobs whose ranks SHARE one GPU (tests: eight processes x six queues oversubscribe the device's hardware queues and a
+  // small eight-rank case takes 300 s; with one queue per process it takes a fraction of that).  Never a production setting.
+  const bool single_stream = [] { const char* e = std::getenv("LPGP_SINGLE_STREAM"); return e && std::atoi(e) != 0; }();
+  if (single_stream) {
+    ctx->s_upd = ctx->s_upd_narrow = ctx->s_upd_all = ctx->s_outer = ctx->s_main;
+    ctx->single_stream = 1;
+  } else {
   masked_stream(reserve, &ctx->s_upd);
   if (!ctx->s_upd) LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd, hipStreamNonBlocking, lo));
   // While the panel chain bounds the pipeline (small trailing matrix) the update can spare a
@@ -340,6 +348,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_upd_all, hipStreamNonBlocking, lo));
   masked_stream(reserve, &ctx->s_outer);
   if (!ctx->s_outer) LPGP_HIP(hipStreamCreateWithPriority(&ctx->s_outer, hipStreamNonBlocking, lo));
+  }
   if (const char* e = std::getenv("LPGP_NB_OUTER")) {
     long v = std::atol(e);
     if (v >= 0 && v % TILE == 0) ctx->nb_outer = v;
@@ -440,11 +449,13 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   }
   for (auto& b : ctx->pool) (void)hipFree(b.p);
   ctx->pool.clear();
+  if (!ctx->single_stream) {
+    (void)hipStreamDestroy(ctx->s_upd);
+    if (ctx->s_upd_narrow) (void)hipStreamDestroy(ctx->s_upd_narrow);
+    (void)hipStreamDestroy(ctx->s_upd_all);
+    if (ctx->s_outer) (void)hipStreamDestroy(ctx->s_outer);
+  }
   (void)hipStreamDestroy(ctx->s_main);
-  (void)hipStreamDestroy(ctx->s_upd);
-  if (ctx->s_upd_narrow) (void)hipStreamDestroy(ctx->s_upd_narrow);
-  (void)hipStreamDestroy(ctx->s_upd_all);
-  if (ctx->s_outer) (void)hipStreamDestroy(ctx->s_outer);
   delete ctx;
   return 0;
 }

@@ -663,7 +663,12 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
   // communicator, beside the chain, awaited only by the remainder update (b).
   const bool split = la && G.Pc == 1 && ctx->split_gather != 0 && ctx->world > 1;
   hipStream_t sC = sP;
-  if (split) {
+  if (split && ctx->single_stream) {
+    for (int i = 0; i < 2; ++i) {
+      if (!ctx->ev_tail[i]) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
+      if (!ctx->ev_rows[i]) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_rows[i], hipEventDisableTiming));
+    }
+  } else if (split) {
     if (!ctx->s_comm) {
       int lo = 0, hi = 0;
       LPGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));

@@ -85,6 +85,7 @@ struct lpgp_ctx {
   hipStream_t s_upd_narrow = nullptr;  // same with `reserve_narrow` CUs (default 64) left to the panel chain
   hipStream_t s_upd_all = nullptr;     // unmasked update stream: the blocked solves have no whole-CU kernel to protect
   hipStream_t s_outer = nullptr;       // rank-nb_outer updates (a1), (b) of the factorisation (masked like s_upd)
+  int single_stream = 0;               // LPGP_SINGLE_STREAM: all of the above alias s_main (ranks sharing one GPU in tests)
   hipEvent_t ev_outer[2] = {nullptr, nullptr};
   hipEvent_t ev_outer_fact[2] = {nullptr, nullptr};
   hipEvent_t ev_outer_a1[2] = {nullptr, nullptr};
