@@ -393,6 +393,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_GEMM3_MARGIN")) ctx->gemm3_margin = std::atof(e);
   if (const char* e = std::getenv("LPGP_GEMM3_FACT")) ctx->gemm3_fact = std::atoi(e);
   if (const char* e = std::getenv("LPGP_ASM_FACTORS")) ctx->asm_factors = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_ASM_FAST")) ctx->asm_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_CHAIN_US_COMM")) ctx->dist_chain_us_comm = std::atof(e);
@@ -516,6 +517,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->split_gather = value != 0;
   } else if (std::strcmp(key, "asm_factors") == 0) {
     ctx->asm_factors = value != 0;
+  } else if (std::strcmp(key, "asm_fast") == 0) {
+    ctx->asm_fast = value != 0;
   } else if (std::strcmp(key, "gemm3") == 0) {
     ctx->gemm3 = value < 0 ? lpgp_ctx().gemm3 : (int)value;       // (negative: back to the built-in default)
   } else if (std::strcmp(key, "min_supertiles") == 0) {

@@ -153,6 +153,166 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
   if ((a.flags & 4) && sink == 0.12345 && row < a.n0) a.out[lrow0 + lane + lcol0 * a.ld] = sink;
 }
 
+// ---------------------------------------------------------------------------------------
+// The common descriptor shapes, specialised (round 3).  assemble_kernel above is written once for every D <= 4, any
+// number of groups, parity classes and degrees: its evaluation is a nest of tiny run-time loops (4 FMAs between a scalar
+// compare-and-branch per coefficient, scalar loads of group parameters per pass), and on the 4096 x 16384 cross-covariance
+// of c3 it spends 0.195 ms evaluating against 0.110 ms for the stores and the tile set-up.  Almost
+// every block of the BASELINE workloads has ONE product-form group, D <= 2, at most two parity classes and degrees <= 4
+// per dimension: for those the polynomial degrees become template parameters (fully unrolled nested Horner), the
+// coefficients, scales and exponent kinds travel BY VALUE in the kernel arguments (scalar registers for the whole
+// kernel: no load inside the entry loop), eight entries per thread run side by side, and the store address advances by one
+// add per entry.  The arithmetic per entry is the generic kernel's, operation for operation -- same association, same
+// exp -- so both paths give bit-identical blocks (tests/test_gpu_kernels.py::test_specialised_assembly_is_bit_identical).
+// ---------------------------------------------------------------------------------------
+constexpr int FAST_MAXC = 32;   // coefficient doubles over all classes
+struct FastDesc {
+  double scale;
+  double a[2];
+  int32_t kind[2];              // 1: exp(-r), 2: exp(-r^2/2)
+  int32_t ncls;
+  int32_t parity[2];
+  double coef[FAST_MAXC];       // class c at c * N0 * N1: [i0 * N1 + i1]
+};
+
+template <int D, int N0, int N1>
+__global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a) {
+  constexpr int FE = 8;         // entries per thread per pass
+  __shared__ double sx1[D][AT];
+  const int tr = blockIdx.x % a.tiles_r;
+  const int tc = blockIdx.x / a.tiles_r;
+  const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
+  if (a.lower_only && c0 > r0 + AT - 1) return;
+  const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
+  if (lrow0 < 0 || lcol0 < 0) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < AT) {
+    const int64_t c = c0 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+  }
+  const int64_t row = r0 + lane;
+  double xr[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  __syncthreads();
+  const unsigned m0 = (fd.parity[0] & 1) ? 0x80000000u : 0u, m1 = (D > 1 && (fd.parity[0] & 2)) ? 0x80000000u : 0u;
+  const unsigned n0m = (fd.parity[1] & 1) ? 0x80000000u : 0u, n1m = (D > 1 && (fd.parity[1] & 2)) ? 0x80000000u : 0u;
+#pragma unroll 1
+  for (int pass = 0; pass < 16 / FE; ++pass) {
+    const int cb = w * 16 + pass * FE;
+    double r[D][FE], expo[FE], tot[FE];
+    unsigned sg[D][FE];
+#pragma unroll
+    for (int e = 0; e < FE; ++e) expo[e] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double aj = fd.a[j];
+      const bool lin = fd.kind[j] == 1;
+#pragma unroll
+      for (int e = 0; e < FE; ++e) {
+        const double v = aj * (xr[j] - sx1[j][cb + e]);
+        sg[j][e] = lpgp_hi32(v) & 0x80000000u;
+        r[j][e] = fabs(v);
+        expo[e] += lin ? r[j][e] : 0.5 * r[j][e] * r[j][e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < FE; ++e) tot[e] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < fd.ncls) {
+        const double* cf = fd.coef + c * N0 * N1;
+        double acc0[FE];
+#pragma unroll
+        for (int e = 0; e < FE; ++e) acc0[e] = 0.0;
+#pragma unroll
+        for (int i0 = N0 - 1; i0 >= 0; --i0) {
+          if constexpr (D == 1) {
+#pragma unroll
+            for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], cf[i0]);
+          } else {
+            double acc1[FE];
+#pragma unroll
+            for (int e = 0; e < FE; ++e) acc1[e] = 0.0;
+#pragma unroll
+            for (int i1 = N1 - 1; i1 >= 0; --i1)
+#pragma unroll
+              for (int e = 0; e < FE; ++e) acc1[e] = fma(acc1[e], r[D - 1][e], cf[i0 * N1 + i1]);
+#pragma unroll
+            for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
+          }
+        }
+        const unsigned q0 = c == 0 ? m0 : n0m, q1 = c == 0 ? m1 : n1m;
+#pragma unroll
+        for (int e = 0; e < FE; ++e) {
+          unsigned sgn = sg[0][e] & q0;
+          if constexpr (D > 1) sgn ^= sg[D - 1][e] & q1;
+          tot[e] += lpgp_xor_sign(acc0[e], sgn);
+        }
+      }
+    }
+    if (row < a.n0) {
+      double* op = a.out + (lrow0 + lane) + (lcol0 + cb) * a.ld;
+#pragma unroll
+      for (int e = 0; e < FE; ++e) {
+        const double v = fma(fd.scale * exp(-expo[e]), tot[e], 0.0);
+        if (c0 + cb + e < a.n1) *op = v;
+        op += a.ld;
+      }
+    }
+  }
+}
+
+// host: does the lowered descriptor have the shape assemble_fast_kernel covers?  (D <= 2, one product-form group, <= 2
+// parity classes, <= 5 coefficients per dimension, <= FAST_MAXC coefficients in total)
+static bool fast_shape(const DevDesc& d, FastDesc* fd, int* n0, int* n1) {
+  if (d.d < 1 || d.d > 2 || d.ngroups != 1) return false;
+  const DevGroup& G = d.g[0];
+  if (G.iso || G.ncls < 1 || G.ncls > 2) return false;
+  const int N0 = G.deg[0] + 1, N1 = d.d > 1 ? G.deg[1] + 1 : 1;
+  if (N0 < 1 || N0 > 5 || N1 < 1 || N1 > 5 || G.ncls * N0 * N1 > FAST_MAXC) return false;
+  fd->scale = G.scale;
+  fd->ncls = G.ncls;
+  for (int j = 0; j < 2; ++j) {
+    fd->a[j] = j < d.d ? G.a[j] : 0.0;
+    fd->kind[j] = j < d.d ? G.expkind[j] : 1;
+    fd->parity[j] = j < G.ncls ? G.parity[j] : 0;
+  }
+  for (int i = 0; i < FAST_MAXC; ++i) fd->coef[i] = 0.0;
+  for (int c = 0; c < G.ncls; ++c)
+    for (int i = 0; i < N0 * N1; ++i) fd->coef[c * N0 * N1 + i] = d.coef[G.coef_off[c] + i];
+  *n0 = N0;
+  *n1 = N1;
+  return true;
+}
+
+template <int D, int N0>
+static void launch_fast_n1(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
+  switch (n1) {
+    case 1: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 1>), grid, dim3(256), 0, stream, fd, a); break;
+    case 2: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 2>), grid, dim3(256), 0, stream, fd, a); break;
+    case 3: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 3>), grid, dim3(256), 0, stream, fd, a); break;
+    case 4: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 4>), grid, dim3(256), 0, stream, fd, a); break;
+    default: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 5>), grid, dim3(256), 0, stream, fd, a); break;
+  }
+}
+template <int D, int N0>
+static void launch_fast_n0(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
+  if constexpr (D == 1) hipLaunchKernelGGL((assemble_fast_kernel<1, N0, 1>), grid, dim3(256), 0, stream, fd, a);
+  else launch_fast_n1<D, N0>(n1, grid, stream, fd, a);
+}
+template <int D>
+static void launch_fast(int n0, int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
+  switch (n0) {
+    case 1: launch_fast_n0<D, 1>(n1, grid, stream, fd, a); break;
+    case 2: launch_fast_n0<D, 2>(n1, grid, stream, fd, a); break;
+    case 3: launch_fast_n0<D, 3>(n1, grid, stream, fd, a); break;
+    case 4: launch_fast_n0<D, 4>(n1, grid, stream, fd, a); break;
+    default: launch_fast_n0<D, 5>(n1, grid, stream, fd, a); break;
+  }
+}
+
 __global__ void add_diag_kernel(double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar, Layout2D lay) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -197,11 +357,6 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
                     const Layout2D& lay) {
-  lpgp_ctx::DescSlot* slotp = nullptr;
-  int rc_ = stage_desc(ctx, stream, host_desc, &slotp);
-  if (rc_ != 0) return rc_;
-  lpgp_ctx::DescSlot& slot = *slotp;
-  const DevDesc* d_desc = slot.d;
   AsmArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.out = out; a.ld = ld; a.row_off = row_off; a.col_off = col_off; a.lower_only = lower_only;
@@ -213,6 +368,24 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   a.flags = (ctx->asm_factors ? 1 : 0) | ((diag & 3) << 1);
   dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
   double entries = lower_only ? 0.5 * (double)n0 * ((double)n0 + 1.0) : (double)n0 * (double)n1;
+  {
+    // the common shapes on the specialised kernel (descriptor by value: no staging, no slot)
+    FastDesc fd;
+    int N0 = 0, N1 = 0;
+    if (ctx->asm_fast && a.flags == 0 && fast_shape(host_desc, &fd, &N0, &N1)) {
+      prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+      if (host_desc.d == 1) launch_fast<1>(N0, N1, grid, stream, fd, a);
+      else launch_fast<2>(N0, N1, grid, stream, fd, a);
+      prof_end(ctx, stream);
+      LPGP_HIP(hipGetLastError());
+      return 0;
+    }
+  }
+  lpgp_ctx::DescSlot* slotp = nullptr;
+  int rc_ = stage_desc(ctx, stream, host_desc, &slotp);
+  if (rc_ != 0) return rc_;
+  lpgp_ctx::DescSlot& slot = *slotp;
+  const DevDesc* d_desc = slot.d;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
   switch (host_desc.d) {
     case 1: hipLaunchKernelGGL(assemble_kernel<1>, grid, dim3(256), 0, stream, d_desc, a); break;

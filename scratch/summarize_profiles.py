@@ -7,7 +7,8 @@ rnd, tag = sys.argv[1], sys.argv[2]
 D = f"gpurun_out/{rnd}_{tag}"
 OUT = f"{D}/profiles"
 os.makedirs(OUT, exist_ok=True)
-SYRK = "gemm_f64_kernel<false, false, 1>"
+SYRK_CANDIDATES = ("gemm_f64_kernel<false, false, 1>", "gemm3_f64_kernel<false, 1>")   # rank-nb trailing update, remainder half: two- / three-resident kernel
+SYRK = SYRK_CANDIDATES[0]
 commands = open(f"{D}/commands.txt").read().strip().split("\n")
 
 
@@ -29,6 +30,10 @@ if st:
     summary["stats_command"] = commands[0]
     summary["kernels"] = [{"name": r["Name"][:110], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                            "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])} for r in rows[:14]]
+    cand = [r for r in rows if any(c in r["Name"] for c in SYRK_CANDIDATES)]
+    if cand:                       # the one the run spent more time in is the roofline kernel of that run
+        best = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+        SYRK = next(c for c in SYRK_CANDIDATES if c in best["Name"])
     syrk = [r for r in rows if SYRK in r["Name"]]
     if syrk:
         summary.update(syrk_kernel=syrk[0]["Name"], syrk_calls=int(syrk[0]["Calls"]), syrk_avg_us=float(syrk[0]["AverageNs"]) / 1e3,

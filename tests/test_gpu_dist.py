@@ -96,6 +96,9 @@ comm.close()
 def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None, rank_env=None):
     env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0")
     env.pop("LOCAL_RANK", None)
+    # every rank runs the NumPy / LAPACK oracle: without a cap each of them starts one BLAS thread per host core (256 on the
+    # GPU box) and eight ranks spend their time spinning against each other -- 178 CPU-minutes for an N_tot = 864 problem
+    env.update(OPENBLAS_NUM_THREADS="4", OMP_NUM_THREADS="4", MKL_NUM_THREADS="4")
     if window_mb is not None:
         env["LPGP_IPC_WINDOW_MB"] = str(window_mb)
     procs = [subprocess.Popen([sys.executable, "-c", MULTI % {"root": ROOT, "workload": workload, "nb": nb, "grid": grid,
@@ -312,3 +315,69 @@ def test_multi_rank_views_rollback_and_small_prediction_sets(grid, port, transpo
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
         assert f"CHAIN {r} ok" in so
+
+
+CALIBRATE = r"""
+import gc, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine, problems
+from oracle import workloads as owl
+comm = _dist.Comm.from_env()
+ctx = _engine.default_context()
+ctx.set_option("nb", 128)
+ctx.dist_init(comm, transport=%(transport)r)
+assert ctx.grid == (4, 1)                                   # the library's default: P x 1
+probe = ctx.link_probe(1 << 20, 2)                          # what bench.py reports as config.link_probe
+W = comm.world
+pair = np.array(probe["pair_gbps"])
+assert pair.shape == (W, W) and np.all(np.diag(pair) == 0.0) and np.all(pair[~np.eye(W, dtype=bool)] > 0.0), probe
+assert len(probe["one_to_all_gbps"]) == W and min(probe["one_to_all_gbps"]) > 0.0 and min(probe["all_to_all_inbound_gbps"]) > 0.0, probe
+wl = problems.poisson_2d(n_side=26, n_bdry=20, m_side=6)     # 6 blocks of 128
+ref = owl.run(wl)
+for grid, bcast in (((4, 1), 0), ((2, 2), 0), ((4, 1), 1), ((1, 4), 0)):       # bench.py's trials: regrid between problems
+    ctx.dist_set_grid(*grid)
+    ctx.set_option("dist_bcast", bcast)
+    assert ctx.grid == grid
+    u, mean, var = problems.condition_and_predict(wl)
+    em = np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))
+    ev = np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))
+    assert em < 1e-8 and ev < 1e-8, (grid, bcast, em, ev)
+    try:
+        ctx.dist_set_grid(2, 2) if grid != (2, 2) else ctx.dist_set_grid(4, 1)
+        raise AssertionError("regrid accepted while a matrix of the old grid is alive")
+    except lp._lib.LpgpError as exc:
+        assert "still alive" in str(exc)
+    del u
+    gc.collect()
+print("CALIBRATE-OK", comm.rank, probe["pair_median_gbps"], flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("transport,port", [("ipc", 30111), ("rccl", 30121)])
+def test_link_probe_and_regrid_between_problems(transport, port):
+    """What `bench.py --gpus N` does before its timed region on a multi-GPU node ("first contact"): the
+    link probe through the transport the panels use, then the same problem on several process grids and with both
+    collectives, the grid changed AFTER the bring-up while no matrix is alive (`lpgp_dist_set_grid`) -- refused while one
+    is.  Four ranks sharing the one GPU; every variant against the oracle on every rank."""
+    env = dict(os.environ, WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0", LPGP_IPC_WINDOW_MB="8",
+               LPGP_SINGLE_STREAM="1", OPENBLAS_NUM_THREADS="4", OMP_NUM_THREADS="4")
+    env.pop("LOCAL_RANK", None)
+    extra = _rccl_as_if_on_separate_hosts if transport == "rccl" else (lambda r: {})
+    procs = [subprocess.Popen([sys.executable, "-c", CALIBRATE % {"root": ROOT, "transport": transport}], env=dict(env, RANK=str(r), **extra(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(4)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if transport == "rccl" and any("lpgp_dist_init failed" in so + se or "lpgp_dist_unique_id failed" in so + se for so, se in outs):
+        pytest.skip("RCCL could not be brought up over loopback sockets here")
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"CALIBRATE-OK {r}" in so, f"rank {r}: " + so[-1500:] + se[-3000:]

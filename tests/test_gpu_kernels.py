@@ -135,6 +135,46 @@ def test_matrix_free_product_matches_dense(ctx):
     np.testing.assert_allclose(k3.linop(Y) @ np.arange(70.0), k3.matrix(Y) @ np.arange(70.0), rtol=1e-12)
 
 
+def test_specialised_assembly_is_bit_identical(ctx):
+    """`assemble_fast_kernel` (one product-form group, D <= 2, <= 2 parity classes, degrees <= 4: polynomial degrees as
+    template parameters, descriptor by value) against the generic `assemble_kernel` (option `asm_fast` = 0): the same
+    arithmetic operation for operation, so the blocks must be IDENTICAL -- 1-D Matern of every order pair the lowering
+    produces (even and odd parity classes, degrees 0..4), ExpQuad, 2-D products incl. the heat operator (two classes),
+    ragged sizes, a symmetric diagonal block; and a descriptor outside the shape (two groups) takes the generic path."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(9)
+    cases = []
+    x0, x1 = rng.uniform(-2, 2, 150), rng.uniform(-2, 2, 77)
+    for nu in (0.5, 1.5, 2.5, 3.5, 4.5):
+        k = cf.Matern((), nu=nu, lengthscales=0.8)
+        p = int(nu - 0.5)
+        for a_, b_ in [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (2, 2), (2, 1)]:
+            if a_ + b_ <= 2 * p and max(a_, b_) <= p:
+                cases.append((diffops.Derivative(a_)(diffops.Derivative(b_)(k, argnum=1), argnum=0) if a_ + b_ else k, x0, x1))
+    ke = 2.0 * cf.ExpQuad((), lengthscales=0.4)
+    cases += [(ke, x0, x1), (diffops.Derivative(2)(diffops.Derivative(1)(ke, argnum=1), argnum=0), x0, x1)]
+    X0, X1 = rng.uniform(-1, 1, (130, 2)), rng.uniform(-1, 1, (200, 2))
+    k2 = 4.0 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=0.7))
+    D = -1.0 * diffops.Laplacian((2,))
+    kh = cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0))
+    H = diffops.HeatOperator((2,), alpha=0.1)
+    km = cf.TensorProduct(cf.ExpQuad((), lengthscales=0.5), cf.Matern((), nu=3.5, lengthscales=0.8))
+    cases += [(k2, X0, X1), (D(k2, argnum=1), X0, X1), (D(D(k2, argnum=1), argnum=0), X0, X1), (H(kh, argnum=0), X0, X1),
+              (H(H(kh, argnum=1), argnum=0), X0, X1), (km, X0, X1), (D(km, argnum=0), X0, X1), (k2, X0, None),
+              (k2 + kh, X0, X1)]                                     # (last: two groups -> generic path either way)
+    try:
+        for k, a0, a1 in cases:
+            ctx.set_option("asm_fast", 0)
+            ref = k.matrix(a0) if a1 is None else k.matrix(a0, a1)
+            ctx.set_option("asm_fast", 1)
+            got = k.matrix(a0) if a1 is None else k.matrix(a0, a1)
+            np.testing.assert_array_equal(got, ref)
+    finally:
+        ctx.set_option("asm_fast", 1)
+
+
 def test_per_point_exponential_factors_option(ctx):
     """Option `asm_factors` (off by default): the exponential of every Matern dimension from per-point factors
     `e^{-+a(x - x0)}` (two multiplies and a minimum per entry instead of an exp; eval_entries.h).  Entries against the

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("transport,ranks", [("rccl", 2), ("ipc", 3)])
 def test_single_process_front(transport, ranks):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LPGP_IPC_WINDOW_MB="8")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LPGP_IPC_WINDOW_MB="8", OPENBLAS_NUM_THREADS="8", OMP_NUM_THREADS="8")
     env.pop("LPGP_SPAWN", None)
     out = subprocess.run([sys.executable, os.path.join(HERE, "_spawn_script.py"), transport, str(ranks)], env=env, capture_output=True,
                          text=True, timeout=600)
