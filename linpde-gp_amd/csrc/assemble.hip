@@ -165,6 +165,20 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
 // add per entry.  The arithmetic per entry is the generic kernel's, operation for operation -- same association, same
 // exp -- so both paths give bit-identical blocks (tests/test_gpu_kernels.py::test_specialised_assembly_is_bit_identical).
 // ---------------------------------------------------------------------------------------
+// (arguments of the matrix-free product kernels, below)
+constexpr int MV_R = MV_RHS;
+
+struct MvArgs {
+  const double* x0;
+  const double* x1;
+  int64_t n0, n1, n0_pad, n1_pad;
+  const double* v;               // device, [r][n1_pad]
+  double* part;                  // device, [split][r][n0_pad]
+  int32_t nr;                    // right-hand sides in this pass (<= MV_R)
+  int32_t factors;               // per-point exponential factors (lpgp_ctx::asm_factors)
+  int32_t tiles_r, tiles_c, splits;
+};
+
 constexpr int FAST_MAXC = 32;   // coefficient doubles over all classes
 struct FastDesc {
   double scale;
@@ -174,6 +188,67 @@ struct FastDesc {
   int32_t parity[2];
   double coef[FAST_MAXC];       // class c at c * N0 * N1: [i0 * N1 + i1]
 };
+
+// FE entries of one row: columns cb .. cb + FE - 1 of the staged column tile.  res[e] = scale * exp(-expo) * sum_c sgn Poly_c
+template <int D, int N0, int N1, int FE>
+__device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&xr)[D], const double (*sx1)[AT], int cb,
+                                             double (&res)[FE]) {
+  const unsigned m0 = (fd.parity[0] & 1) ? 0x80000000u : 0u, m1 = (D > 1 && (fd.parity[0] & 2)) ? 0x80000000u : 0u;
+  const unsigned n0m = (fd.parity[1] & 1) ? 0x80000000u : 0u, n1m = (D > 1 && (fd.parity[1] & 2)) ? 0x80000000u : 0u;
+  double r[D][FE], expo[FE], tot[FE];
+  unsigned sg[D][FE];
+#pragma unroll
+  for (int e = 0; e < FE; ++e) expo[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const double aj = fd.a[j];
+    const bool lin = fd.kind[j] == 1;
+#pragma unroll
+    for (int e = 0; e < FE; ++e) {
+      const double v = aj * (xr[j] - sx1[j][cb + e]);
+      sg[j][e] = lpgp_hi32(v) & 0x80000000u;
+      r[j][e] = fabs(v);
+      expo[e] += lin ? r[j][e] : 0.5 * r[j][e] * r[j][e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < FE; ++e) tot[e] = 0.0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c < fd.ncls) {
+      const double* cf = fd.coef + c * N0 * N1;
+      double acc0[FE];
+#pragma unroll
+      for (int e = 0; e < FE; ++e) acc0[e] = 0.0;
+#pragma unroll
+      for (int i0 = N0 - 1; i0 >= 0; --i0) {
+        if constexpr (D == 1) {
+#pragma unroll
+          for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], cf[i0]);
+        } else {
+          double acc1[FE];
+#pragma unroll
+          for (int e = 0; e < FE; ++e) acc1[e] = 0.0;
+#pragma unroll
+          for (int i1 = N1 - 1; i1 >= 0; --i1)
+#pragma unroll
+            for (int e = 0; e < FE; ++e) acc1[e] = fma(acc1[e], r[D - 1][e], cf[i0 * N1 + i1]);
+#pragma unroll
+          for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
+        }
+      }
+      const unsigned q0 = c == 0 ? m0 : n0m, q1 = c == 0 ? m1 : n1m;
+#pragma unroll
+      for (int e = 0; e < FE; ++e) {
+        unsigned sgn = sg[0][e] & q0;
+        if constexpr (D > 1) sgn ^= sg[D - 1][e] & q1;
+        tot[e] += lpgp_xor_sign(acc0[e], sgn);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < FE; ++e) res[e] = fma(fd.scale * exp(-expo[e]), tot[e], 0.0);
+}
 
 template <int D, int N0, int N1>
 __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a) {
@@ -196,71 +271,70 @@ __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs
 #pragma unroll
   for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
   __syncthreads();
-  const unsigned m0 = (fd.parity[0] & 1) ? 0x80000000u : 0u, m1 = (D > 1 && (fd.parity[0] & 2)) ? 0x80000000u : 0u;
-  const unsigned n0m = (fd.parity[1] & 1) ? 0x80000000u : 0u, n1m = (D > 1 && (fd.parity[1] & 2)) ? 0x80000000u : 0u;
 #pragma unroll 1
   for (int pass = 0; pass < 16 / FE; ++pass) {
     const int cb = w * 16 + pass * FE;
-    double r[D][FE], expo[FE], tot[FE];
-    unsigned sg[D][FE];
-#pragma unroll
-    for (int e = 0; e < FE; ++e) expo[e] = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const double aj = fd.a[j];
-      const bool lin = fd.kind[j] == 1;
-#pragma unroll
-      for (int e = 0; e < FE; ++e) {
-        const double v = aj * (xr[j] - sx1[j][cb + e]);
-        sg[j][e] = lpgp_hi32(v) & 0x80000000u;
-        r[j][e] = fabs(v);
-        expo[e] += lin ? r[j][e] : 0.5 * r[j][e] * r[j][e];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < FE; ++e) tot[e] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (c < fd.ncls) {
-        const double* cf = fd.coef + c * N0 * N1;
-        double acc0[FE];
-#pragma unroll
-        for (int e = 0; e < FE; ++e) acc0[e] = 0.0;
-#pragma unroll
-        for (int i0 = N0 - 1; i0 >= 0; --i0) {
-          if constexpr (D == 1) {
-#pragma unroll
-            for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], cf[i0]);
-          } else {
-            double acc1[FE];
-#pragma unroll
-            for (int e = 0; e < FE; ++e) acc1[e] = 0.0;
-#pragma unroll
-            for (int i1 = N1 - 1; i1 >= 0; --i1)
-#pragma unroll
-              for (int e = 0; e < FE; ++e) acc1[e] = fma(acc1[e], r[D - 1][e], cf[i0 * N1 + i1]);
-#pragma unroll
-            for (int e = 0; e < FE; ++e) acc0[e] = fma(acc0[e], r[0][e], acc1[e]);
-          }
-        }
-        const unsigned q0 = c == 0 ? m0 : n0m, q1 = c == 0 ? m1 : n1m;
-#pragma unroll
-        for (int e = 0; e < FE; ++e) {
-          unsigned sgn = sg[0][e] & q0;
-          if constexpr (D > 1) sgn ^= sg[D - 1][e] & q1;
-          tot[e] += lpgp_xor_sign(acc0[e], sgn);
-        }
-      }
-    }
+    double res[FE];
+    fast_entries<D, N0, N1, FE>(fd, xr, sx1, cb, res);
     if (row < a.n0) {
       double* op = a.out + (lrow0 + lane) + (lcol0 + cb) * a.ld;
 #pragma unroll
       for (int e = 0; e < FE; ++e) {
-        const double v = fma(fd.scale * exp(-expo[e]), tot[e], 0.0);
-        if (c0 + cb + e < a.n1) *op = v;
+        if (c0 + cb + e < a.n1) *op = res[e];
         op += a.ld;
       }
     }
+  }
+}
+
+// the matrix-free product on the same specialised evaluation (matvec_kernel's structure: 64 rows per workgroup, a range of
+// column tiles, MV_R right-hand sides per evaluation, partial sums per split)
+template <int D, int N0, int N1>
+__global__ __launch_bounds__(256) void matvec_fast_kernel(FastDesc fd, MvArgs a) {
+  constexpr int FE = 8;
+  __shared__ double sx1[D][AT];
+  __shared__ double sv[MV_R][AT];
+  __shared__ double red[3][MV_R][AT];
+  const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)tr * AT + lane;
+  double xr[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
+  double y[MV_R];
+#pragma unroll
+  for (int r = 0; r < MV_R; ++r) y[r] = 0.0;
+  const int per = (a.tiles_c + a.splits - 1) / a.splits;
+  const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
+  for (int tc = sp * per; tc < tc_end; ++tc) {
+    __syncthreads();
+    {
+      const int64_t c = (int64_t)tc * AT + lane;
+      for (int j = w; j < D; j += 4) sx1[j][lane] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.n1_pad + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 16 / FE; ++pass) {
+      const int cb = w * 16 + pass * FE;
+      double res[FE];
+      fast_entries<D, N0, N1, FE>(fd, xr, sx1, cb, res);
+#pragma unroll
+      for (int e = 0; e < FE; ++e)
+#pragma unroll
+        for (int r = 0; r < MV_R; ++r) y[r] = fma(res[e], sv[r][cb + e], y[r]);
+    }
+  }
+  __syncthreads();
+  if (w > 0) {
+#pragma unroll
+    for (int r = 0; r < MV_R; ++r) red[w - 1][r][lane] = y[r];
+  }
+  __syncthreads();
+  if (w == 0 && row < a.n0) {
+#pragma unroll
+    for (int r = 0; r < MV_R; ++r)
+      if (r < a.nr) a.part[((int64_t)sp * MV_R + r) * a.n0_pad + row] = ((y[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
   }
 }
 
@@ -287,29 +361,34 @@ static bool fast_shape(const DevDesc& d, FastDesc* fd, int* n0, int* n1) {
   return true;
 }
 
-template <int D, int N0>
-static void launch_fast_n1(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
-  switch (n1) {
-    case 1: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 1>), grid, dim3(256), 0, stream, fd, a); break;
-    case 2: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 2>), grid, dim3(256), 0, stream, fd, a); break;
-    case 3: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 3>), grid, dim3(256), 0, stream, fd, a); break;
-    case 4: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 4>), grid, dim3(256), 0, stream, fd, a); break;
-    default: hipLaunchKernelGGL((assemble_fast_kernel<D, N0, 5>), grid, dim3(256), 0, stream, fd, a); break;
+// dispatch on the polynomial sizes (N0, N1 in 1..5; N1 = 1 for D = 1): KIND 0 = assembly, 1 = matrix-free product
+template <int KIND, int D, int N0, int N1, class Args>
+static void launch_fast_one(dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
+  if constexpr (KIND == 0) hipLaunchKernelGGL((assemble_fast_kernel<D, N0, N1>), grid, dim3(256), 0, stream, fd, a);
+  else hipLaunchKernelGGL((matvec_fast_kernel<D, N0, N1>), grid, dim3(256), 0, stream, fd, a);
+}
+template <int KIND, int D, int N0, class Args>
+static void launch_fast_n0(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
+  if constexpr (D == 1) {
+    launch_fast_one<KIND, 1, N0, 1>(grid, stream, fd, a);
+  } else {
+    switch (n1) {
+      case 1: launch_fast_one<KIND, D, N0, 1>(grid, stream, fd, a); break;
+      case 2: launch_fast_one<KIND, D, N0, 2>(grid, stream, fd, a); break;
+      case 3: launch_fast_one<KIND, D, N0, 3>(grid, stream, fd, a); break;
+      case 4: launch_fast_one<KIND, D, N0, 4>(grid, stream, fd, a); break;
+      default: launch_fast_one<KIND, D, N0, 5>(grid, stream, fd, a); break;
+    }
   }
 }
-template <int D, int N0>
-static void launch_fast_n0(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
-  if constexpr (D == 1) hipLaunchKernelGGL((assemble_fast_kernel<1, N0, 1>), grid, dim3(256), 0, stream, fd, a);
-  else launch_fast_n1<D, N0>(n1, grid, stream, fd, a);
-}
-template <int D>
-static void launch_fast(int n0, int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const AsmArgs& a) {
+template <int KIND, int D, class Args>
+static void launch_fast(int n0, int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
   switch (n0) {
-    case 1: launch_fast_n0<D, 1>(n1, grid, stream, fd, a); break;
-    case 2: launch_fast_n0<D, 2>(n1, grid, stream, fd, a); break;
-    case 3: launch_fast_n0<D, 3>(n1, grid, stream, fd, a); break;
-    case 4: launch_fast_n0<D, 4>(n1, grid, stream, fd, a); break;
-    default: launch_fast_n0<D, 5>(n1, grid, stream, fd, a); break;
+    case 1: launch_fast_n0<KIND, D, 1>(n1, grid, stream, fd, a); break;
+    case 2: launch_fast_n0<KIND, D, 2>(n1, grid, stream, fd, a); break;
+    case 3: launch_fast_n0<KIND, D, 3>(n1, grid, stream, fd, a); break;
+    case 4: launch_fast_n0<KIND, D, 4>(n1, grid, stream, fd, a); break;
+    default: launch_fast_n0<KIND, D, 5>(n1, grid, stream, fd, a); break;
   }
 }
 
@@ -374,8 +453,8 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
     int N0 = 0, N1 = 0;
     if (ctx->asm_fast && a.flags == 0 && fast_shape(host_desc, &fd, &N0, &N1)) {
       prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
-      if (host_desc.d == 1) launch_fast<1>(N0, N1, grid, stream, fd, a);
-      else launch_fast<2>(N0, N1, grid, stream, fd, a);
+      if (host_desc.d == 1) launch_fast<0, 1>(N0, N1, grid, stream, fd, a);
+      else launch_fast<0, 2>(N0, N1, grid, stream, fd, a);
       prof_end(ctx, stream);
       LPGP_HIP(hipGetLastError());
       return 0;
@@ -411,19 +490,6 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
 // slab of each 64-column tile, up to MV_R right-hand sides ride along per evaluation.
 // Partial sums per split go to `part`; mv_reduce_kernel adds them in a fixed order.
 // ---------------------------------------------------------------------------------------
-constexpr int MV_R = MV_RHS;
-
-struct MvArgs {
-  const double* x0;
-  const double* x1;
-  int64_t n0, n1, n0_pad, n1_pad;
-  const double* v;               // device, [r][n1_pad]
-  double* part;                  // device, [split][r][n0_pad]
-  int32_t nr;                    // right-hand sides in this pass (<= MV_R)
-  int32_t factors;               // per-point exponential factors (lpgp_ctx::asm_factors)
-  int32_t tiles_r, tiles_c, splits;
-};
-
 template <int D>
 __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__ desc, MvArgs a) {
   __shared__ double sx1[D][AT];
@@ -514,9 +580,6 @@ __global__ void mv_reduce_kernel(const double* __restrict__ part, double* __rest
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
                   double* part, int splits, double* out) {
-  lpgp_ctx::DescSlot* slot = nullptr;
-  int rc = stage_desc(ctx, stream, host_desc, &slot);
-  if (rc != 0) return rc;
   MvArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.v = v; a.part = part; a.nr = nr;
@@ -525,6 +588,24 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   a.splits = splits;
   dim3 grid((unsigned)((int64_t)a.tiles_r * splits));
+  {
+    FastDesc fd;
+    int N0 = 0, N1 = 0;
+    if (ctx->asm_fast && !a.factors && fast_shape(host_desc, &fd, &N0, &N1)) {      // the common shapes: specialised evaluation
+      prof_begin(ctx, stream, LPGP_K_MATVEC, 2.0 * (double)n0 * (double)n1 * nr, 0.0);
+      if (host_desc.d == 1) launch_fast<1, 1>(N0, N1, grid, stream, fd, a);
+      else launch_fast<1, 2>(N0, N1, grid, stream, fd, a);
+      prof_end(ctx, stream);
+      LPGP_HIP(hipGetLastError());
+      hipLaunchKernelGGL(mv_reduce_kernel, dim3((unsigned)((n0 + 255) / 256), (unsigned)nr), dim3(256), 0, stream,
+                         (const double*)part, out, n0, n0_pad, splits, nr);
+      LPGP_HIP(hipGetLastError());
+      return 0;
+    }
+  }
+  lpgp_ctx::DescSlot* slot = nullptr;
+  int rc = stage_desc(ctx, stream, host_desc, &slot);
+  if (rc != 0) return rc;
   prof_begin(ctx, stream, LPGP_K_MATVEC, 2.0 * (double)n0 * (double)n1 * nr, 0.0);
   switch (host_desc.d) {
     case 1: hipLaunchKernelGGL(matvec_kernel<1>, grid, dim3(256), 0, stream, slot->d, a); break;

@@ -166,11 +166,15 @@ def test_specialised_assembly_is_bit_identical(ctx):
               (k2 + kh, X0, X1)]                                     # (last: two groups -> generic path either way)
     try:
         for k, a0, a1 in cases:
+            V = rng.standard_normal(((a0 if a1 is None else a1).shape[0], 3))
             ctx.set_option("asm_fast", 0)
             ref = k.matrix(a0) if a1 is None else k.matrix(a0, a1)
+            ref_mv = (k.linop(a0) if a1 is None else k.linop(a0, a1)) @ V
             ctx.set_option("asm_fast", 1)
             got = k.matrix(a0) if a1 is None else k.matrix(a0, a1)
             np.testing.assert_array_equal(got, ref)
+            # the matrix-free product shares the specialised evaluation (matvec_fast_kernel): same entries, same order of sums
+            np.testing.assert_array_equal((k.linop(a0) if a1 is None else k.linop(a0, a1)) @ V, ref_mv)
     finally:
         ctx.set_option("asm_fast", 1)
 
