@@ -23,7 +23,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int TL = 136;                       // LDS leading dimension of the 128x128 tile (col-major)
-constexpr int TILE_LDS_DOUBLES = TILE * TL + 8 * 256 + 64;     // tile, 8 diagonal-block inverses, 4 x 16 panel entries of the micro-blocked diagonal phase
+constexpr int TILE_LDS_DOUBLES = TILE * TL + 8 * 256;
 constexpr int TILE_WAVES = 8;                 // wave 0: diagonal blocks (the serial chain); the others: everything off it
 
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
@@ -51,14 +51,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // where the single workgroup of the tile Cholesky ran (XCC id histogram; lpgp_debug_tile_xcc)
 __device__ int g_tile_xcc_hist[8];
 
-template <bool MICRO>
 __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __restrict__ a, int64_t lda,
                                                           double* __restrict__ linv, int* __restrict__ info,
                                                           int info_base) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* s = sm;                       // s[c*TL + r]
   double* sD = sm + TILE * TL;          // 8 diagonal-block inverses, column-major 16x16: Linv[r][c] at [c*16 + r]
-  double* sX = sD + 8 * 256;            // MICRO: panel entries X[i][m] of the current 4-column micro-step at [m*16 + i]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4, l3 = lane & 3;
   const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -180,7 +178,6 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
       const int c = r16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[j] = (j == c) ? 1.0 : 0.0;
-      if constexpr (!MICRO) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double piv = bcast_lane(row[j], j);
@@ -213,107 +210,15 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           // (Tried and measured equal or slower: one instruction stream for both recurrences with
           // factor rows on lanes 0-15 and inverse columns on lanes 16-31; s_setprio for this wave;
           // keeping its SIMD free of background waves; round 3: two columns per round with their broadcasts issued back
-          // to back -- 84 of the 113 s_nop disappear from the listing and the kernel takes 44.2 instead of 41.0 us.
-          // ~450 cycles per pivot step remain.)
+          // to back -- 84 of the 113 s_nop disappear from the listing and the kernel takes 44.2 instead of 41.0 us; round 3,
+          // 4 x 4 micro-blocks: the diagonal micro-block broadcast to all lanes and factored redundantly, the four new
+          // entries of every row by substitution against it, the trailing columns updated from LDS broadcast reads, factor
+          // rows and inverse columns in one register array (git 3de0b0c): correct, the same rounding, 44.6 instead of
+          // 40.9 us -- the pivot-to-pivot chain of dependent fp64 operations is unchanged and an LDS round trip per four
+          // pivots is added.  ~450 cycles per pivot step remain.)
           asm volatile("" : "+v"(x[k]), "+v"(row[k]));
         }
       }
-      } else {
-        // ---- 4 x 4 micro-blocks (round 3).  The scalar pivot loop above broadcasts one L[k][j] per (pivot, column) pair:
-        // 120 pairs x (2 v_readlane + wait states + 2 FMA) per 16 x 16 block, ~450 cycles per pivot on this one wave.  Here
-        // four pivots at a time: (a) the 4 x 4 diagonal micro-block is broadcast to ALL lanes (10 values), (b) every lane
-        // factors and inverts it redundantly -- uniform arithmetic, no cross-lane traffic inside the chain --, (c) each lane
-        // forms its four new entries (its row times the micro-block's inverse), (d) the panel entries of the rows below go
-        // through 512 B of LDS, and (e) the trailing columns are updated with LDS BROADCAST reads: the VALU keeps only the
-        // FMAs.  Factor and inverse share ONE register array and one instruction stream: lanes 0-15 hold factor rows
-        // (z[k] = A[i][k]), lanes 16-31 columns of the inverse (z[k] = x_c[k], c = lane - 16) -- both recurrences read
-        // z[k] -= own[m] * L[k][4J+m] with own[m] = sum_{q<=m} z[4J+q] Linv4[m][q] (lanes 32-63 repeat 0-31).
-        const bool inv_lane = (lane & 16) != 0;
-        // bit k: entry k of this lane's vector can be non-zero -- factor row i: k <= i; inverse column c: k >= c
-        const int keepmask = inv_lane ? (0xffff << c) & 0xffff : (2 << i) - 1;
-        double z[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) z[k] = inv_lane ? ((k == c) ? 1.0 : 0.0) : row[k];
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-          double d[4][4], ell[4][4], dinv[4];
-#pragma unroll
-          for (int p_ = 0; p_ < 4; ++p_)
-#pragma unroll
-            for (int q_ = 0; q_ <= p_; ++q_) d[p_][q_] = bcast_lane(z[4 * J + q_], 4 * J + p_);   // A[4J+p][4J+q] (a row lane)
-          // (b) 4 x 4 Cholesky of the micro-block, the same arithmetic in every lane
-#pragma unroll
-          for (int p_ = 0; p_ < 4; ++p_) {
-            double piv = d[p_][p_];
-            if (!(piv > 0.0)) {
-              if (!bad) bad = j0 + 4 * J + p_ + 1;
-              piv = 1.0;
-            }
-            double inv = __builtin_amdgcn_rsq(piv);
-            inv = fma(inv, 0.5 * fma(-piv * inv, inv, 1.0), inv);
-            double l = piv * inv;
-            const double res = fma(-l, l, piv);
-            l = fma(0.5 * inv, res, l);
-            inv = fma(inv, -0.5 * inv * inv * res, inv);
-            ell[p_][p_] = l;
-            dinv[p_] = inv;
-#pragma unroll
-            for (int r_ = p_ + 1; r_ < 4; ++r_) ell[r_][p_] = d[r_][p_] * inv;
-#pragma unroll
-            for (int r_ = p_ + 1; r_ < 4; ++r_)
-#pragma unroll
-              for (int c_ = p_ + 1; c_ <= r_; ++c_) d[r_][c_] = fma(-ell[r_][p_], ell[c_][p_], d[r_][c_]);
-          }
-          // (c) this lane's four new entries by forward SUBSTITUTION against the micro-block (never a product with its
-          // inverse: a 4 x 4 block of nearly coincident points has condition 1e4 and more), one recurrence for both kinds of
-          // lane: own[m] = (z[4J+m] - sum_{q<m} own[q] ell[m][q]) / ell[m][m] -- a row below the block gets L[i][4J+m], a row
-          // of the block its row of ell, an inverse lane x_c[4J+m].  Structural zeros (a factor row's upper part, computed
-          // from meaningless upper entries of z; an inverse column above its diagonal) are cleared with a per-lane bit mask,
-          // 0 / -1 from one v_bfe_i32 (lane predicates as SGPR pairs cost this kernel 120 scalar spills); the diagonal entry
-          // of a block row takes the refined uniform value.
-          double own[4];
-#pragma unroll
-          for (int m_ = 0; m_ < 4; ++m_) {
-            double acc = z[4 * J + m_];
-#pragma unroll
-            for (int q_ = 0; q_ < m_; ++q_) acc = fma(-own[q_], ell[m_][q_], acc);
-            acc *= dinv[m_];
-            if (lane == 4 * J + m_) acc = ell[m_][m_];
-            const int keep_ = __builtin_amdgcn_sbfe(keepmask, 4 * J + m_, 1);
-            own[m_] = __hiloint2double(__double2hiint(acc) & keep_, __double2loint(acc) & keep_);
-            z[4 * J + m_] = own[m_];
-          }
-          if (J < 3) {
-            // (d) panel entries of the 16 rows to LDS (rows above the trailing part are never read back)
-            if (lane < 16) {
-#pragma unroll
-              for (int m_ = 0; m_ < 4; ++m_) sX[m_ * 16 + i] = own[m_];
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // (e) trailing columns k > 4J+3: z[k] -= sum_m own[m] L[k][4J+m]
-#pragma unroll
-            for (int k = 4 * J + 4; k < 16; ++k) {
-#pragma unroll
-              for (int m_ = 0; m_ < 4; ++m_) z[k] = fma(-own[m_], sX[m_ * 16 + k], z[k]);      // uniform address: LDS broadcast
-              asm volatile("" : "+v"(z[k]));          // (keep the loads of column k next to their use)
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
-        // lanes 0-15: factor rows -> tile; lanes 16-31: inverse columns -> sD
-        if (lane < 16) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) s[(j0 + k) * TL + j0 + i] = z[k];        // (entries above the diagonal are zero by the mask)
-        } else if (lane < 32) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) sD[jb * 256 + c * 16 + k] = z[k];
-        }
-      }
-      if constexpr (!MICRO) {
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
       if (lane < 16) {
 #pragma unroll
@@ -321,7 +226,6 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           s[(j0 + k) * TL + j0 + i] = (k <= i) ? row[k] : 0.0;
           sD[jb * 256 + c * 16 + k] = x[k];
         }
-      }
       }
 #ifdef LPGP_TILE_STAMP
       { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); ts_[6] += tC_ - tA_; }
@@ -407,11 +311,9 @@ int debug_tile_xcc(int32_t* out8, int reset) {
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base) {
   const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
-  static const bool micro = [] { const char* e = std::getenv("LPGP_POTRF_MICRO"); return e ? std::atoi(e) != 0 : false; }();
-  auto kfn = micro ? potrf_tile_kernel<true> : potrf_tile_kernel<false>;
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(kfn), shmem));
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&potrf_tile_kernel), shmem));
   prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
-  hipLaunchKernelGGL(kfn, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
+  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;
