@@ -519,6 +519,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->asm_factors = value != 0;
   } else if (std::strcmp(key, "asm_fast") == 0) {
     ctx->asm_fast = value != 0;
+  } else if (std::strcmp(key, "gemm3_fact") == 0) {
+    ctx->gemm3_fact = value != 0;
   } else if (std::strcmp(key, "gemm3") == 0) {
     ctx->gemm3 = value < 0 ? lpgp_ctx().gemm3 : (int)value;       // (negative: back to the built-in default)
   } else if (std::strcmp(key, "min_supertiles") == 0) {

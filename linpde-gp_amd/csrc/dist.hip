@@ -754,7 +754,7 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     if (tail_pending[which]) LPGP_HIP(hipStreamWaitEvent(sB, ctx->ev_tail[which], 0));   // (b) reads every row of the panel
     {
       GemmArgs gb = update_args(mat, G, panel, ldp, p.c1, K128, rt0, LTr, ctb, LTc, 1);
-      gb.occ3 = ctx->gemm3_fact && t_b_us > ctx->gemm3_margin * t_chain_us;
+      gb.occ3 = t_b_us > ctx->gemm3_margin * t_chain_us;
       if (gb.mt > 0 && gb.nt > 0) LPGP_TRY(launch_gemm(ctx, sB, 0, 0, gb, LPGP_K_SYRK));
     }
     LPGP_HIP(hipEventRecord(ctx->ev_upd[i & 1], sB));

@@ -769,7 +769,9 @@ static void pick_kernel(const lpgp_ctx* ctx, int64_t ntiles, bool occ3, void (**
   *fn = gemm_f64_kernel<TA, TB, TRI>;
   *shmem = (size_t)4 * STAGE * sizeof(double);                  // 73 728 B: two workgroups per CU
   if constexpr (!TA && TRI != 2 && !(TB && TRI != 0)) {
-    if (occ3 && ctx->gemm3 > 0 && ntiles >= ctx->gemm3) {
+    // (symmetric updates -- the factorisation's -- only with gemm3_fact: there the third resident workgroup costs the panel
+    //  chain what it gains the update, and a profiling slot stays one kernel symbol)
+    if (occ3 && ctx->gemm3 > 0 && ntiles >= ctx->gemm3 && (TRI == 0 || ctx->gemm3_fact)) {
       *fn = gemm3_f64_kernel<TB, TRI>;
       *shmem = (size_t)4 * STAGE3 * sizeof(double);             // 36 864 B: three workgroups per CU
     }

@@ -434,7 +434,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
       LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
       GemmArgs gb = mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, cl - p2, K, -1.0, 1.0, 1);
-      gb.occ3 = ctx->gemm3_fact && t_b_us > ctx->gemm3_margin * t_chain_us;       // (lpgp_internal.h: gemm3_fact)
+      gb.occ3 = t_b_us > ctx->gemm3_margin * t_chain_us;       // (with gemm3_fact: three workgroups per CU only while the chain beside it has slack)
       LPGP_TRY(launch_gemm(ctx, sB, 0, 0, gb, LPGP_K_SYRK));
       LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
       have_upd_event = 1;

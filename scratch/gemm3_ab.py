@@ -6,6 +6,7 @@ from linpde_gp_amd import _engine
 ctx = _engine.default_context()
 rng = np.random.default_rng(0)
 ctx.set_option("small_tiles_max", 0)
+ctx.set_option("gemm3_fact", 1)
 def run(m, n, k, tri, tb=0):
     A = rng.standard_normal((m, k)); B = A if tri else (rng.standard_normal((k, n)) if tb else rng.standard_normal((n, k)))
     C = np.zeros((m, n), order="F")

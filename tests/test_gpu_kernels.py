@@ -27,9 +27,11 @@ def gemm_kernel(ctx, request):
     three-workgroups-per-CU kernel (`gemm3_f64_kernel`, option `gemm3`), whatever the default is."""
     ctx.set_option("small_tiles_max", 1 << 20 if request.param == "tile64" else 0)
     ctx.set_option("gemm3", {"tile128": 0, "tile64": 0, "tile128x3": 1}[request.param])
+    ctx.set_option("gemm3_fact", 1 if request.param == "tile128x3" else 0)     # (symmetric updates on the variant as well)
     yield request.param
     ctx.set_option("small_tiles_max", 256)
     ctx.set_option("gemm3", -1)
+    ctx.set_option("gemm3_fact", 0)
 
 
 @pytest.mark.parametrize("k", [16, 80, 512])
