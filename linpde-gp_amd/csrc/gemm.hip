@@ -1,19 +1,25 @@
-// fp64 MFMA GEMM / SYRK for the Cholesky trailing update, the panel triangular solves
-// (as products with explicit 128x128 inverses) and the multi-RHS forward substitution.
+// fp64 MFMA GEMM / SYRK: the Cholesky trailing update, the rank-128 updates inside a panel, the updates of the blocked
+// multi-RHS forward / backward substitution, V0^T V1.  (The refined tile solves live in solve.hip / solve_panel.h.)
 //
 // Replaces LAPACK dpotrf's trailing DSYRK/DGEMM and dpotrs/dtrtrs's DTRSM that the
 // reference reaches through probnum `LinearOperator.cholesky/solve`
 // (_conditional.py:44,108,228; linops/_block.py:192-207,233-251).
 //
-// Design (gfx950): 128x128 block tile, 256 threads = 2x2 waves, 64x64 per wave as 4x4
-// v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs), K staged 16 deep through LDS with a
-// register prefetch (one barrier per stage).  The MFMA operands are SWAPPED (B fragment as
-// the instruction's A operand) so that every accumulator register holds 16 consecutive
-// rows of one column of C: C is read and written in 128-byte row segments.  LDS images:
-// [k][144] for an operand whose non-contracted index is fastest in memory, [idx][18] for a
-// k-fastest operand; both are conflict-free for the one-ds_read_b64-per-fragment pattern.
-// Block ids are grouped into 8x8 super-tiles and dealt so that one XCD works on one
-// super-tile at a time (its 16 operand panels stay in that XCD's L2).
+// Three kernels, one operand machinery:
+//   gemm_f64_kernel    128 x 128 tile, 4 waves x (64 x 64) from v_mfma_f64_4x4x4_4b_f64 (16x16x4 never exceeds ~48 TFLOP/s
+//                      chip-wide, see below), K staged 16 deep by LDS-DMA (global_load_lds) into a double buffer, fragments
+//                      double-buffered in registers with hand-counted lgkmcnt waits, accumulators initialised from C (the
+//                      epilogue is stores only); 200 registers, 73.7 KB of LDS: two workgroups per CU.
+//   gemm3_f64_kernel   the same tile at THREE workgroups per CU (K staged 8 deep, single-buffered m-fragments, 168 registers,
+//                      36.9 KB): used where it pays end to end (forward substitution), see its header.
+//   gemm64_f64_kernel  64 x 64 tile, 4-stage LDS-DMA ring: launches that cannot fill the chip with 128 x 128 tiles.
+// The MFMA operands are SWAPPED (B fragment as the instruction's A operand) so that every accumulator register holds 16
+// consecutive rows of one column of C: C is read and written in 128-byte row segments.  LDS images: [k][144] ("M image")
+// for an operand whose non-contracted index is fastest in memory, [idx][16] with an XOR swizzle of the 16-byte chunks
+// ("K image") for a k-fastest operand; both conflict-free for the one-ds_read_b64-per-fragment pattern.
+// Tiles are enumerated densely, band by band, and dealt to the 8 XCDs in contiguous ranges (map_tile_dense): 64
+// consecutive entries are an 8 x 8 block of tiles whose 16 operand panels stay in one XCD's L2, and every XCD gets the same
+// number of tiles whatever the shape (triangle, trapezoid, or the staircase of a rank's tiles in the multi-GPU update).
 
 #include "lpgp_internal.h"
 #include "kernel_util.h"

@@ -305,7 +305,7 @@ struct GemmArgs {
 int launch_gemm(lpgp_ctx* ctx, hipStream_t stream, int ta, int tb, const GemmArgs& g, int prof_kernel);
 int stair_enumerate_host(const GemmArgs& g, int32_t* out, int64_t cap);
 int64_t gemm_valid_tiles(const GemmArgs& g);
-// Tile solves with one step of iterative refinement (gemm.hip: tile_solve_kernel); L = the 128 x 128 diagonal
+// Tile solves with one step of iterative refinement (solve.hip: tile_solve_kernel); L = the 128 x 128 diagonal
 // tile of the factor (leading dimension ldl, zeros above the diagonal), linv its explicit inverse (ld 128):
 // X (mt*128 rows x 128, column-major ldx) <- X L^{-T} in place
 // V (128 rows x nt*128 columns, column-major ldv) <- L^{-1} V in place (tile step of the forward substitution)
@@ -313,7 +313,7 @@ int launch_trsv_tile(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, 
                      int nt, int prof_kernel);
 int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
                      int mt, int prof_kernel);
-// the whole chain of a panel of the forward substitution in one launch (gemm.hip: panel_solve_kernel): V (nt_rows <= 4
+// the whole chain of a panel of the forward substitution in one launch (solve_panel.h: panel_solve_kernel): V (nt_rows <= 4
 // tiles of rows, top row at V) <- L_KK^{-1} V; linv: the panel's tile inverses (contiguous), L: its diagonal block
 int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
                       int nt_rows, int nt_cols, int prof_kernel);

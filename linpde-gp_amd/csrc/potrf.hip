@@ -6,8 +6,8 @@
 //
 // Structure per panel of `nb` columns (nb = 4 tiles of 128 by default):
 //   for each 128-wide tile column:  potrf_tile (one workgroup, LDS resident; also emits
-//   the explicit inverse of the diagonal tile)  ->  panel rows below: X = A * Linv^T as an
-//   in-place MFMA GEMM  ->  rank-128 update of the rest of the panel;
+//   the explicit inverse of the diagonal tile)  ->  panel rows below: X = A * L^-T in place, a product with that
+//   inverse refined once against the tile itself (tile_solve_kernel, solve.hip)  ->  rank-128 update of the rest of the panel;
 //   then the rank-nb SYRK trailing update (gemm.hip), split into the next panel's columns
 //   (high-priority stream, followed immediately by the next panel factorisation) and the
 //   remainder (second stream): look-ahead of one panel.
