@@ -368,7 +368,13 @@ def main():
     phase_rows = comm.gather([min(p_[0] for p_ in ph) * 1e3, min(p_[1] for p_ in ph) * 1e3])
     # ---- per-kernel HIP-event timing (same process, same workload, right after the timed
     #      region: event records between launches cost ~25 % wall time, so they stay out of it) ----
+    # (at least ~2.5 s of device time per pass on one GPU: more samples per kernel, and a GPU section long enough for an
+    #  external activity sampler to see whatever K the caller chose)
     prof_steps = max(1, min(args.steps, 3))
+    if os.environ.get("LPGP_BENCH_PROF_STEPS"):
+        prof_steps = max(1, int(os.environ["LPGP_BENCH_PROF_STEPS"]))          # (rocprofv3 counter passes: keep them short)
+    elif world == 1:
+        prof_steps = max(prof_steps, min(200, int(2.5 / max(dt / args.steps, 1e-4))))
 
     def profiled(which):
         ctx.profile_reset()

@@ -7,6 +7,7 @@ set -u
 ROUND=$1; TAG=$2; shift 2
 ARGS="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export LPGP_BENCH_PROF_STEPS=3      # bench.py's per-kernel HIP-event passes: short under the profiler (as in the committed r03 collections)
 D=gpurun_out/${ROUND}_${TAG}
 rm -rf "$D"; mkdir -p "$D"
 run() {   # run <subdir> <rocprofv3 options ...> -- <program ...>; logs the command line exactly as executed
