@@ -169,13 +169,14 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(sha, kernel_symbol):
+def pmc_traffic(sha, kernel_symbol, profiles_dir=None):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of the SAME command
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; scratch/collect_profiles.sh collects them and records
     the command and the source identity it ran on).  A summary collected on OTHER kernel sources is not reported as
     `traffic` (it is named under `traffic_stale`)."""
     out = {"traffic": None, "traffic_source": None}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c3_summary.json")), reverse=True):
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    for path in sorted(glob.glob(os.path.join(profiles_dir, "r*_bench_c3_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 summ = json.load(f)
@@ -185,7 +186,7 @@ def pmc_traffic(sha, kernel_symbol):
         if v is None:
             continue
         at = (summ.get("bench_line") or {}).get("config", {}).get("csrc_sha16")
-        rel = os.path.relpath(path, ROOT)
+        rel = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
         if at == sha and kernel_symbol.split("(")[0].strip() in (summ.get("syrk_kernel") or ""):
             return {"traffic": v, "traffic_source": rel, "traffic_collected_at_csrc": at,
                     "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command on these kernel sources; (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch"}

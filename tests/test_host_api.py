@@ -311,3 +311,34 @@ def test_tensor_product_grid_survives_pickling():
     h = pickle.loads(pickle.dumps(g))
     assert type(h) is TensorProductGrid and h.shape == (3, 5, 2) and np.array_equal(h, g)
     assert all(np.array_equal(a, b) for a, b in zip(h.factors, g.factors))
+
+
+def test_bench_reports_pmc_traffic_only_from_the_running_sources(tmp_path):
+    """`bench.py` cannot measure FETCH_SIZE / WRITE_SIZE in-process: `roofline.traffic` comes from a committed rocprofv3
+    summary -- and only from one collected on the kernel sources the process is running (`config.csrc_sha16`); a summary of
+    other sources, or of another roofline kernel, is named under `traffic_stale` instead."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lpgp_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.csrc_sha16()
+    assert len(sha) == 16 and sha == bench.csrc_sha16()
+    sym = "gemm_f64_kernel<false, false, 1>"
+
+    def write(name, at, kernel, value):
+        with open(tmp_path / name, "w") as f:
+            json.dump({"syrk_hbm_bytes_per_launch": value, "syrk_kernel": f"void lpgp::{kernel}(lpgp::GemmArgs)",
+                       "bench_line": {"config": {"csrc_sha16": at}}}, f)
+
+    write("r02_bench_c3_summary.json", None, sym, 1.9e9)                       # (round 2 recorded no source identity)
+    got = bench.pmc_traffic(sha, sym, str(tmp_path))
+    assert got["traffic"] is None and got["traffic_stale"]["value"] == 1.9e9
+    write("r03_bench_c3_summary.json", "0" * 16, sym, 1.8e9)                    # other sources
+    got = bench.pmc_traffic(sha, sym, str(tmp_path))
+    assert got["traffic"] is None and got["traffic_stale"]["collected_at_csrc"] == "0" * 16
+    write("r04_bench_c3_summary.json", sha, "gemm3_f64_kernel<false, 1>", 2.2e9)    # these sources, another roofline kernel
+    assert bench.pmc_traffic(sha, sym, str(tmp_path))["traffic"] is None
+    write("r05_bench_c3_summary.json", sha, sym, 1.7e9)
+    got = bench.pmc_traffic(sha, sym, str(tmp_path))
+    assert got["traffic"] == 1.7e9 and got["traffic_collected_at_csrc"] == sha and "r05_" in got["traffic_source"]
