@@ -13,6 +13,27 @@ def ctx():
     return _engine.default_context()
 
 
+def test_options_round_trip(ctx):
+    """`lpgp_set_option` / `lpgp_get_option`: the knobs bench.py and the tests flip, and what `roofline_kernel_symbol` (the
+    name bench.py reports for profiling slot "syrk_trailing") follows."""
+    from linpde_gp_amd import _lib
+    assert ctx.get_option("nb") == 512 and ctx.get_option("gemm3") == 768 and ctx.get_option("gemm3_fact") == 0
+    assert ctx.roofline_kernel_symbol() == "gemm_f64_kernel<false, false, 1>"
+    try:
+        ctx.set_option("gemm3_fact", 1)
+        assert ctx.get_option("gemm3_fact") == 1 and ctx.roofline_kernel_symbol() == "gemm3_f64_kernel<false, 1>"
+        ctx.set_option("gemm3", 0)
+        assert ctx.roofline_kernel_symbol() == "gemm_f64_kernel<false, false, 1>"
+    finally:
+        ctx.set_option("gemm3", -1)
+        ctx.set_option("gemm3_fact", 0)
+    assert ctx.get_option("gemm3") == 768
+    with pytest.raises(_lib.LpgpError):
+        ctx.get_option("no_such_option")
+    with pytest.raises(_lib.LpgpError):
+        ctx.set_option("nb", 100)                     # not a multiple of 128
+
+
 def test_probes(ctx):
     tf = ctx.probe_mfma_f64()
     gb = ctx.probe_hbm_write(1 << 30)
