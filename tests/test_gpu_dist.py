@@ -141,6 +141,7 @@ def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
     # to be eight oracles with 256 BLAS threads each spinning against one another, not the GPU: see _run_ranks.)
     ((8, 1), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29871),
     ((2, 4), "poisson_2d(n_side=28, n_bdry=20, m_side=7)", 128, 29881),
+    ((4, 2), "heat_1d(nt=30, nx=20, m_side=6)", 128, 29885),              # the P/2 x 2 grid bench.py tries at 8 GPUs; mixed blocks
 ])
 def test_eight_ranks_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(8, grid, workload, nb, port)
