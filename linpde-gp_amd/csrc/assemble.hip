@@ -88,6 +88,7 @@ template <int D>
 __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
   __shared__ double sx1[D][AT];
   __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
+  __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];      // table of lpgp_exp_neg (eval_entries.h)
   __shared__ int s_fast;
   const int tr = blockIdx.x % a.tiles_r;   // row tile fastest: consecutive blocks write neighbouring rows
   const int tc = blockIdx.x / a.tiles_r;
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
     for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = xc[j];
   }
   if (threadIdx.x == 0) s_fast = a.flags & 1;
+  s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];         // (256 threads, 256 entries)
+  const ExpTab etab{s_exp};
   __syncthreads();
   if (a.flags & 1) {
     // waves 0,1: row factors; waves 2,3: column factors
@@ -135,9 +138,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
       for (int e = 0; e < AEK; ++e) res[e] = dx[0][e];
     } else if (fast) {
       LdsFactors<D> fac{sfr + lane, sfc + cb};
-      eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
+      eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, etab, fac);
     } else {
-      eval_entries<D, AEK>(desc, dx, res);
+      eval_entries<D, AEK>(desc, dx, res, etab);
     }
     if (a.flags & 4) {
 #pragma unroll
@@ -190,9 +193,13 @@ struct FastDesc {
 };
 
 // FE entries of one row: columns cb .. cb + FE - 1 of the staged column tile.  res[e] = scale * exp(-expo) * sum_c sgn Poly_c
-template <int D, int N0, int N1, int FE>
+// LIN: every dimension decays like e^{-r} (a product of Matern factors): the run-time choice between r and r^2/2 per entry
+// and dimension (two multiplies and a 64-bit select) is compiled out.  EVEN (only with LIN): no parity class flips a sign
+// (even derivative orders in every dimension, e.g. Laplacians): the sign extraction and the sign products are compiled out.
+// Both only remove operations whose result the general form discards, so all three forms give the same bits.
+template <int D, int N0, int N1, int FE, bool LIN, bool EVEN>
 __device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&xr)[D], const double (*sx1)[AT], int cb,
-                                             double (&res)[FE]) {
+                                             const ExpTab& etab, double (&res)[FE]) {
   const unsigned m0 = (fd.parity[0] & 1) ? 0x80000000u : 0u, m1 = (D > 1 && (fd.parity[0] & 2)) ? 0x80000000u : 0u;
   const unsigned n0m = (fd.parity[1] & 1) ? 0x80000000u : 0u, n1m = (D > 1 && (fd.parity[1] & 2)) ? 0x80000000u : 0u;
   double r[D][FE], expo[FE], tot[FE];
@@ -202,11 +209,11 @@ __device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const double aj = fd.a[j];
-    const bool lin = fd.kind[j] == 1;
+    const bool lin = LIN || fd.kind[j] == 1;
 #pragma unroll
     for (int e = 0; e < FE; ++e) {
       const double v = aj * (xr[j] - sx1[j][cb + e]);
-      sg[j][e] = lpgp_hi32(v) & 0x80000000u;
+      sg[j][e] = EVEN ? 0u : (lpgp_hi32(v) & 0x80000000u);
       r[j][e] = fabs(v);
       expo[e] += lin ? r[j][e] : 0.5 * r[j][e] * r[j][e];
     }
@@ -240,32 +247,39 @@ __device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&
       const unsigned q0 = c == 0 ? m0 : n0m, q1 = c == 0 ? m1 : n1m;
 #pragma unroll
       for (int e = 0; e < FE; ++e) {
-        unsigned sgn = sg[0][e] & q0;
-        if constexpr (D > 1) sgn ^= sg[D - 1][e] & q1;
-        tot[e] += lpgp_xor_sign(acc0[e], sgn);
+        if constexpr (EVEN) {
+          tot[e] += acc0[e];
+        } else {
+          unsigned sgn = sg[0][e] & q0;
+          if constexpr (D > 1) sgn ^= sg[D - 1][e] & q1;
+          tot[e] += lpgp_xor_sign(acc0[e], sgn);
+        }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < FE; ++e) res[e] = fma(fd.scale * exp(-expo[e]), tot[e], 0.0);
+  for (int e = 0; e < FE; ++e) res[e] = fma(fd.scale * lpgp_exp_neg(expo[e], etab), tot[e], 0.0);
 }
 
-template <int D, int N0, int N1>
+template <int D, int N0, int N1, int MODE>       // MODE 0: general, 1: LIN, 2: LIN + EVEN (fast_entries)
 __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a) {
   constexpr int FE = 8;         // entries per thread per pass
   __shared__ double sx1[D][AT];
+  __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
   const int tr = blockIdx.x % a.tiles_r;
   const int tc = blockIdx.x / a.tiles_r;
   const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
   if (a.lower_only && c0 > r0 + AT - 1) return;
   const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
   if (lrow0 < 0 || lcol0 < 0) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (threadIdx.x < AT) {
     const int64_t c = c0 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
   }
+  s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];
+  const ExpTab etab{s_exp};
   const int64_t row = r0 + lane;
   double xr[D];
 #pragma unroll
@@ -275,12 +289,13 @@ __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs
   for (int pass = 0; pass < 16 / FE; ++pass) {
     const int cb = w * 16 + pass * FE;
     double res[FE];
-    fast_entries<D, N0, N1, FE>(fd, xr, sx1, cb, res);
+    fast_entries<D, N0, N1, FE, MODE >= 1, MODE == 2>(fd, xr, sx1, cb, etab, res);
     if (row < a.n0) {
       double* op = a.out + (lrow0 + lane) + (lcol0 + cb) * a.ld;
+      const int ncols = (int)(a.n1 - c0 < AT ? a.n1 - c0 : AT);        // valid columns of this tile: a scalar 32-bit compare per entry
 #pragma unroll
       for (int e = 0; e < FE; ++e) {
-        if (c0 + cb + e < a.n1) *op = res[e];
+        if (cb + e < ncols) *op = res[e];
         op += a.ld;
       }
     }
@@ -289,15 +304,18 @@ __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs
 
 // the matrix-free product on the same specialised evaluation (matvec_kernel's structure: 64 rows per workgroup, a range of
 // column tiles, MV_R right-hand sides per evaluation, partial sums per split)
-template <int D, int N0, int N1>
+template <int D, int N0, int N1, int MODE>
 __global__ __launch_bounds__(256) void matvec_fast_kernel(FastDesc fd, MvArgs a) {
   constexpr int FE = 8;
   __shared__ double sx1[D][AT];
+  __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
   __shared__ double sv[MV_R][AT];
   __shared__ double red[3][MV_R][AT];
   const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = (int64_t)tr * AT + lane;
+  s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];        // (visible behind the first barrier of the tile loop)
+  const ExpTab etab{s_exp};
   double xr[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(FastDesc fd, MvArgs a)
     for (int pass = 0; pass < 16 / FE; ++pass) {
       const int cb = w * 16 + pass * FE;
       double res[FE];
-      fast_entries<D, N0, N1, FE>(fd, xr, sx1, cb, res);
+      fast_entries<D, N0, N1, FE, MODE >= 1, MODE == 2>(fd, xr, sx1, cb, etab, res);
 #pragma unroll
       for (int e = 0; e < FE; ++e)
 #pragma unroll
@@ -362,10 +380,28 @@ static bool fast_shape(const DevDesc& d, FastDesc* fd, int* n0, int* n1) {
 }
 
 // dispatch on the polynomial sizes (N0, N1 in 1..5; N1 = 1 for D = 1): KIND 0 = assembly, 1 = matrix-free product
+// which of fast_entries' forms a descriptor allows: 2 = every dimension e^{-r} and no sign-flipping parity class, 1 = every
+// dimension e^{-r}, 0 = anything
+static int fast_mode(const FastDesc& fd, int d) {
+  for (int j = 0; j < d; ++j)
+    if (fd.kind[j] != 1) return 0;
+  const int mask = (1 << d) - 1;
+  for (int c = 0; c < fd.ncls; ++c)
+    if (fd.parity[c] & mask) return 1;
+  return 2;
+}
+template <int KIND, int D, int N0, int N1, int MODE, class Args>
+static void launch_fast_mode(dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
+  if constexpr (KIND == 0) hipLaunchKernelGGL((assemble_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a);
+  else hipLaunchKernelGGL((matvec_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a);
+}
 template <int KIND, int D, int N0, int N1, class Args>
 static void launch_fast_one(dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
-  if constexpr (KIND == 0) hipLaunchKernelGGL((assemble_fast_kernel<D, N0, N1>), grid, dim3(256), 0, stream, fd, a);
-  else hipLaunchKernelGGL((matvec_fast_kernel<D, N0, N1>), grid, dim3(256), 0, stream, fd, a);
+  switch (fast_mode(fd, D)) {
+    case 2: launch_fast_mode<KIND, D, N0, N1, 2>(grid, stream, fd, a); break;
+    case 1: launch_fast_mode<KIND, D, N0, N1, 1>(grid, stream, fd, a); break;
+    default: launch_fast_mode<KIND, D, N0, N1, 0>(grid, stream, fd, a); break;
+  }
 }
 template <int KIND, int D, int N0, class Args>
 static void launch_fast_n0(int n1, dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
@@ -500,6 +536,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   // units from the origin falls back to one exp per entry
   __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
   __shared__ int s_fast_r, s_fast_c[2];
+  __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
   const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -516,6 +553,8 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   const int per = (a.tiles_c + a.splits - 1) / a.splits;
   const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
   if (threadIdx.x == 0) { s_fast_r = a.factors; s_fast_c[0] = 1; s_fast_c[1] = 1; }
+  s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];
+  const ExpTab etab{s_exp};
   __syncthreads();
   if (a.factors) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
 
@@ -543,9 +582,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
         for (int e = 0; e < AEK; ++e) dx[j][e] = xr[j] - sx1[j][cb + e];
       if (fast) {
         LdsFactors<D> fac{sfr + lane, sfc + cb};
-        eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, fac);
+        eval_entries<D, AEK, LdsFactors<D>>(desc, dx, res, etab, fac);
       } else {
-        eval_entries<D, AEK>(desc, dx, res);
+        eval_entries<D, AEK>(desc, dx, res, etab);
       }
 #pragma unroll
       for (int e = 0; e < AEK; ++e)

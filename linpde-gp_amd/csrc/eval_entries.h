@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "lpgp_desc.h"
+#include "exp_table.h"
 
 #if defined(__HIPCC__)
 #define LPGP_HD __device__ __forceinline__
@@ -70,6 +71,44 @@ LPGP_HD void lpgp_exp_factors(double a, double x, double x0, double& ep, double&
   t_abs = fabs(t_hi);
 }
 
+// e^{-s} for s >= 0: the per-entry exponential of every assembly / matrix-free kernel.  The library exp costs 33 vector
+// operations per entry inside these kernels (degree-11 Horner whose coefficients the compiler re-materialises per entry, range
+// selects) out of ~71; this one costs 16 and one table read: s = r - k ln2/256 with |r| <= ln2/512, e^{-s} = 2^{k >> 8} T[k & 255]
+// (1 + p(r)), T[j] = 2^{j/256} held as head + tail (exp_table.h), p a degree-4 polynomial of e^r - 1 (error 2.4e-18): the only
+// rounding that matters is the final addition -- 0.51 ulp measured against quad precision over 2e7 arguments (the library's
+// exp: 0.51 on the host, <= 1 documented on the device).  s is clamped at 800 (result 0); a NaN / infinite s reaches the entry
+// through the polynomial factor that multiplies the exponential (its Horner chain starts from 0 * r), so it needs no branch
+// here.  `tab`: 256 {head, tail} pairs -- LDS on the device (staged per workgroup), the constant itself on the host.
+#if defined(__HIPCC__)
+__device__ const double g_exp_table[2 * EXP_TAB_N] = {LPGP_EXP_TABLE_VALUES};
+#else
+static const double g_exp_table[2 * EXP_TAB_N] = {LPGP_EXP_TABLE_VALUES};
+#endif
+
+struct ExpTab {
+  const double* t;
+};
+
+LPGP_HD double lpgp_exp_neg(double s, const ExpTab& tab) {
+  const double t = -fmin(s, 800.0);
+  const double kf = rint(t * EXP_N_OVER_LN2);
+  double r = fma(kf, -EXP_LN2_N_HI, t);
+  r = fma(kf, -EXP_LN2_N_LO, r);
+  const int k = (int)kf;
+  const double* tj = tab.t + 2 * (k & (EXP_TAB_N - 1));
+  const double Th = tj[0], Tl = tj[1];
+  double p = fma(r, EXP_C4, EXP_C3);
+  p = fma(r, p, EXP_C2);
+  p = fma(r, p, EXP_C1);
+  p *= r;
+  const double v = Th + fma(Th, p, Tl);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ldexp(v, k >> EXP_TAB_BITS);
+#else
+  return std::ldexp(v, k >> EXP_TAB_BITS);
+#endif
+}
+
 struct NoFactors {
   static constexpr bool enabled = false;
   LPGP_HD double pair(int, int, int) const { return 1.0; }
@@ -86,7 +125,8 @@ struct MemCoef {
 
 template <int D, int NE, class Fac, class Coef>
 LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
-                                             const double (&dx)[D][NE], double (&res)[NE], const Fac& fac, const Coef& coef) {
+                                             const double (&dx)[D][NE], double (&res)[NE], const Fac& fac, const Coef& coef,
+                                             const ExpTab& tab) {
   constexpr int AE = NE;          // (entries per call: the name the body uses)
 #pragma unroll
   for (int e = 0; e < AE; ++e) res[e] = 0.0;
@@ -139,7 +179,7 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
       }
 #pragma unroll
       for (int e = 0; e < AE; ++e)
-        res[e] = fma(G.scale * exp(-sv[e]), fma(quad[e], v2[e], fma(lin[e], v1[e], v0[e])), res[e]);
+        res[e] = fma(G.scale * lpgp_exp_neg(sv[e], tab), fma(quad[e], v2[e], fma(lin[e], v1[e], v0[e])), res[e]);
       continue;
     }
     double r[D][AE];
@@ -235,7 +275,7 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
     }
     if (per_entry_exp) {
 #pragma unroll
-      for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * (ef[e] * exp(-expo[e])), tot[e], res[e]);
+      for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * (ef[e] * lpgp_exp_neg(expo[e], tab)), tot[e], res[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < AE; ++e) res[e] = fma(G.scale * ef[e], tot[e], res[e]);
@@ -244,8 +284,9 @@ LPGP_HD void eval_entries(const DevDesc* __restrict__ desc,
 }
 
 template <int D, int NE = AE, class Fac = NoFactors>
-LPGP_HD void eval_entries(const DevDesc* __restrict__ desc, const double (&dx)[D][NE], double (&res)[NE], const Fac& fac = Fac()) {
-  eval_entries<D, NE, Fac, MemCoef>(desc, dx, res, fac, MemCoef{desc->coef});
+LPGP_HD void eval_entries(const DevDesc* __restrict__ desc, const double (&dx)[D][NE], double (&res)[NE], const ExpTab& tab,
+                          const Fac& fac = Fac()) {
+  eval_entries<D, NE, Fac, MemCoef>(desc, dx, res, fac, MemCoef{desc->coef}, tab);
 }
 
 }  // namespace lpgp

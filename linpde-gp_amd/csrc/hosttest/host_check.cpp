@@ -20,7 +20,7 @@ static void eval_block(const DevDesc& desc, const double* X0, int64_t n0, const 
         const int64_t j = (j0 + e < n1) ? j0 + e : n1 - 1;
         for (int dd = 0; dd < D; ++dd) dx[dd][e] = X0[i * D + dd] - X1[j * D + dd];
       }
-      eval_entries<D>(&desc, dx, res);
+      eval_entries<D>(&desc, dx, res, ExpTab{g_exp_table});
       for (int e = 0; e < AE && j0 + e < n1; ++e) out[i * n1 + j0 + e] = res[e];
     }
 }
@@ -55,7 +55,7 @@ static void eval_block_fact(const DevDesc& desc, const double* X0, int64_t n0, c
         const int64_t j = (j0 + e < n1) ? j0 + e : n1 - 1;
         for (int dd = 0; dd < D; ++dd) { dx[dd][e] = X0[i * D + dd] - X1[j * D + dd]; fac.xc[dd][e] = X1[j * D + dd]; }
       }
-      eval_entries<D, AE, HostFactors<D>>(&desc, dx, res, fac);
+      eval_entries<D, AE, HostFactors<D>>(&desc, dx, res, ExpTab{g_exp_table}, fac);
       for (int e = 0; e < AE && j0 + e < n1; ++e) out[i * n1 + j0 + e] = res[e];
     }
 }
@@ -105,6 +105,12 @@ int lpgp_host_kernel_diag(const lpgp_kdesc* kd, int32_t ngroups, double* out_val
   if (rc != 0) return rc;
   *out_value = desc_diag(store[0]);
   return 0;
+}
+
+// out[i] = lpgp_exp_neg(s[i]): the per-entry exponential of the assembly kernels (eval_entries.h), host instantiation
+void lpgp_host_exp_neg(const double* s, int64_t n, double* out) {
+  const ExpTab tab{g_exp_table};
+  for (int64_t i = 0; i < n; ++i) out[i] = lpgp_exp_neg(s[i], tab);
 }
 
 }  // extern "C"

@@ -154,7 +154,7 @@ class Posterior:
         return kxx - K0 @ scipy.linalg.cho_solve((self.chol, True), K1.T)
 
 
-def refined_posterior(post: "Posterior", Xtest, Ltest: dict | None = None, iters: int = 12):
+def refined_posterior(post: "Posterior", Xtest, Ltest: dict | None = None, iters: int = 12, K: np.ndarray | None = None):
     """Posterior mean and marginal variance of the fp64 Gram matrix to (nearly) working accuracy: every solve with `G` is
     refined with long-double residuals until it stops moving (LAPACK's factor as the preconditioner).  This is the yardstick
     for ill-conditioned problems, where LAPACK itself is cond(G) x eps away from the exact answer and a comparison of two fp64
@@ -174,7 +174,8 @@ def refined_posterior(post: "Posterior", Xtest, Ltest: dict | None = None, iters
                 break
         return X
 
-    K = cross_cov(post.kernel, post.blocks, Xtest, Ltest)                 # (M, N)
+    if K is None:                                                         # (a caller that refines with ITS OWN evaluation of the
+        K = cross_cov(post.kernel, post.blocks, Xtest, Ltest)             #  matrices passes `post.G` and `K` from there)  (M, N)
     w = solve(residual(post.blocks, post.mean_const))
     mean = prior_mean_L(post.mean_const, L0, K.shape[0]).astype(np.longdouble) + K.astype(np.longdouble) @ w
     W = solve(K.T)                                                        # (N, M)

@@ -158,6 +158,42 @@ def test_matrix_free_product_matches_dense(ctx):
     np.testing.assert_allclose(k3.linop(Y) @ np.arange(70.0), k3.matrix(Y) @ np.arange(70.0), rtol=1e-12)
 
 
+def test_device_exponential_is_correctly_rounded_to_half_an_ulp(ctx):
+    """`lpgp_exp_neg` (csrc/eval_entries.h: 256-entry head + tail table of 2^(j/256), degree-4 polynomial) ON THE DEVICE: the
+    Matern-1/2 kernel matrix of the origin against points s is e^{-s} with nothing else in the entry (scale 1, polynomial 1),
+    compared with 40-digit arithmetic.  Both assembly kernels (specialised and generic) and the matrix-free product share the
+    function; the ExpQuad factor exercises the r^2/2 argument."""
+    import mpmath as mp
+    import linpde_gp_amd as lp
+    cf = lp.randprocs.covfuncs
+    mp.mp.dps = 40
+    rng = np.random.default_rng(8)
+    s = np.concatenate([rng.uniform(0, 1e-3, 500), rng.uniform(0, 2, 1500), rng.uniform(0, 40, 1500), rng.uniform(0, 700, 500),
+                        np.arange(0, 64) * (np.log(2) / 256), [0.0, 708.0, 744.0, 800.0, 1e10]])
+    k = cf.Matern((), nu=0.5, lengthscales=1.0)
+    for fast in (1, 0):
+        ctx.set_option("asm_fast", fast)
+        try:
+            row = np.asarray(k.matrix(np.zeros(1), s))[0]
+        finally:
+            ctx.set_option("asm_fast", 1)
+        worst = 0.0
+        for si, oi in zip(s, row):
+            ex = mp.exp(-mp.mpf(float(si)))
+            exd = float(ex)
+            if exd < 2.3e-308:
+                assert 0.0 <= oi <= 2.3e-308
+                continue
+            worst = max(worst, float(abs(mp.mpf(float(oi)) - ex) / np.spacing(exd)))
+        assert worst <= 0.53, (fast, worst)
+        assert row[s == 0.0][0] == 1.0
+    q = cf.ExpQuad((), lengthscales=1.0)
+    u = rng.uniform(0, 8, 2000)
+    got = np.asarray(q.matrix(np.zeros(1), u))[0]
+    ref = np.array([float(mp.exp(-mp.mpf(float(x)) ** 2 / 2)) for x in u])
+    assert np.max(np.abs(got - ref) / ref) <= 4e-16 * 40        # the argument u^2/2 is rounded before the exponential: |arg| eps
+
+
 def test_specialised_assembly_is_bit_identical(ctx):
     """`assemble_fast_kernel` (one product-form group, D <= 2, <= 2 parity classes, degrees <= 4: polynomial degrees as
     template parameters, descriptor by value) against the generic `assemble_kernel` (option `asm_fast` = 0): the same
