@@ -394,6 +394,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_GEMM3_FACT")) ctx->gemm3_fact = std::atoi(e);
   if (const char* e = std::getenv("LPGP_ASM_FACTORS")) ctx->asm_factors = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_ASM_FAST")) ctx->asm_fast = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_ASM_CT")) ctx->asm_ct = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_CHAIN_US_COMM")) ctx->dist_chain_us_comm = std::atof(e);
@@ -490,6 +491,8 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "fused_solve") == 0) *value = ctx->fused_solve;
   else if (std::strcmp(key, "small_tiles_max") == 0) *value = ctx->small_tiles_max;
   else if (std::strcmp(key, "live_mats") == 0) *value = ctx->live_mats;
+  else if (std::strcmp(key, "asm_ct") == 0) *value = ctx->asm_ct;
+  else if (std::strcmp(key, "asm_fast") == 0) *value = ctx->asm_fast;
   else LPGP_CHECK(false, "unknown option %s", key);
   return 0;
 }
@@ -519,6 +522,9 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->asm_factors = value != 0;
   } else if (std::strcmp(key, "asm_fast") == 0) {
     ctx->asm_fast = value != 0;
+  } else if (std::strcmp(key, "asm_ct") == 0) {
+    LPGP_CHECK(value >= 1 && value <= 64, "asm_ct must be in 1 .. 64");
+    ctx->asm_ct = (int)value;
   } else if (std::strcmp(key, "gemm3_fact") == 0) {
     ctx->gemm3_fact = value != 0;
   } else if (std::strcmp(key, "gemm3") == 0) {

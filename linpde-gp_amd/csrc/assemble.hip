@@ -37,6 +37,7 @@ struct AsmArgs {
   int64_t row_off, col_off;
   int32_t lower_only;           // symmetric diagonal block: skip tiles strictly above diagonal
   int32_t tiles_r, tiles_c;
+  int32_t ct = 1;               // assemble_fast_kernel: column tiles per workgroup (consecutive tiles of one tile row)
   int32_t flags = 0;            // bit 0: per-point exponential factors (lpgp_ctx::asm_factors); measurement aids (LPGP_ASM_DIAG): bit 1 = no evaluation (stores only), bit 2 = no stores (evaluation only)
   Layout2D lay;                 // where element (row_off + i, col_off + j) lives on this rank (multi-GPU: only the owned tiles are written)
 };
@@ -264,39 +265,54 @@ __device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&
 template <int D, int N0, int N1, int MODE>       // MODE 0: general, 1: LIN, 2: LIN + EVEN (fast_entries)
 __global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a) {
   constexpr int FE = 8;         // entries per thread per pass
-  __shared__ double sx1[D][AT];
+  __shared__ double sx1[2][D][AT];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
+  // a workgroup owns `ct` consecutive column tiles of one tile row: the row coordinates and the exponential's table (4 KB
+  // against 32 KB of output per tile) are set up once, the column coordinates of the next tile are staged while this one
+  // is evaluated
   const int tr = blockIdx.x % a.tiles_r;
-  const int tc = blockIdx.x / a.tiles_r;
-  const int64_t r0 = (int64_t)tr * AT, c0 = (int64_t)tc * AT;
-  if (a.lower_only && c0 > r0 + AT - 1) return;
-  const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0), lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
-  if (lrow0 < 0 || lcol0 < 0) return;
+  const int tc0 = (blockIdx.x / a.tiles_r) * a.ct;
+  const int tc1 = tc0 + a.ct < a.tiles_c ? tc0 + a.ct : a.tiles_c;
+  const int64_t r0 = (int64_t)tr * AT;
+  if (a.lower_only && (int64_t)tc0 * AT > r0 + AT - 1) return;
+  const int64_t lrow0 = cyc_local(a.lay.rows, a.row_off + r0);
+  if (lrow0 < 0) return;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (threadIdx.x < AT) {
-    const int64_t c = c0 + threadIdx.x;
+  auto stage_cols = [&](int tc, int buf) {
+    if (threadIdx.x < AT) {
+      const int64_t c = (int64_t)tc * AT + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-  }
+      for (int j = 0; j < D; ++j) sx1[buf][j][threadIdx.x] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
+    }
+  };
+  stage_cols(tc0, 0);
   s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];
   const ExpTab etab{s_exp};
   const int64_t row = r0 + lane;
   double xr[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) xr[j] = (row < a.n0) ? a.x0[j * a.n0_pad + row] : 0.0;
-  __syncthreads();
+  for (int tc = tc0; tc < tc1; ++tc) {
+    const int buf = (tc - tc0) & 1;
+    __syncthreads();                                   // this tile's coordinates staged; the other buffer's readers are done
+    if (tc + 1 < tc1) stage_cols(tc + 1, buf ^ 1);
+    const int64_t c0 = (int64_t)tc * AT;
+    if (a.lower_only && c0 > r0 + AT - 1) break;       // (tiles further right lie above the diagonal too)
+    const int64_t lcol0 = cyc_local(a.lay.cols, a.col_off + c0);
+    if (lcol0 < 0) continue;
 #pragma unroll 1
-  for (int pass = 0; pass < 16 / FE; ++pass) {
-    const int cb = w * 16 + pass * FE;
-    double res[FE];
-    fast_entries<D, N0, N1, FE, MODE >= 1, MODE == 2>(fd, xr, sx1, cb, etab, res);
-    if (row < a.n0) {
-      double* op = a.out + (lrow0 + lane) + (lcol0 + cb) * a.ld;
-      const int ncols = (int)(a.n1 - c0 < AT ? a.n1 - c0 : AT);        // valid columns of this tile: a scalar 32-bit compare per entry
+    for (int pass = 0; pass < 16 / FE; ++pass) {
+      const int cb = w * 16 + pass * FE;
+      double res[FE];
+      fast_entries<D, N0, N1, FE, MODE >= 1, MODE == 2>(fd, xr, sx1[buf], cb, etab, res);
+      if (row < a.n0) {
+        double* op = a.out + (lrow0 + lane) + (lcol0 + cb) * a.ld;
+        const int ncols = (int)(a.n1 - c0 < AT ? a.n1 - c0 : AT);        // valid columns of this tile: a scalar 32-bit compare per entry
 #pragma unroll
-      for (int e = 0; e < FE; ++e) {
-        if (cb + e < ncols) *op = res[e];
-        op += a.ld;
+        for (int e = 0; e < FE; ++e) {
+          if (cb + e < ncols) *op = res[e];
+          op += a.ld;
+        }
       }
     }
   }
@@ -489,6 +505,11 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
     int N0 = 0, N1 = 0;
     if (ctx->asm_fast && a.flags == 0 && fast_shape(host_desc, &fd, &N0, &N1)) {
       prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+      // column tiles per workgroup: as many as leave >= 16 workgroups per CU in the launch (at most ctx->asm_ct)
+      int ct = 1;
+      while (ct < ctx->asm_ct && (int64_t)a.tiles_r * ((a.tiles_c + 2 * ct - 1) / (2 * ct)) >= 16 * (int64_t)(ctx->cus > 0 ? ctx->cus : 256)) ct *= 2;
+      a.ct = ct;
+      grid = dim3((unsigned)((int64_t)a.tiles_r * ((a.tiles_c + ct - 1) / ct)));
       if (host_desc.d == 1) launch_fast<0, 1>(N0, N1, grid, stream, fd, a);
       else launch_fast<0, 2>(N0, N1, grid, stream, fd, a);
       prof_end(ctx, stream);

@@ -110,6 +110,7 @@ struct lpgp_ctx {
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
   int asm_fast = 1;                // per-entry assembly: descriptors of the common shapes (D <= 2, one group, <= 2 parity classes, degrees <= 4) on the specialised kernel (assemble_fast_kernel; bit-identical to the generic one)
+  int asm_ct = 4;                  // assemble_fast_kernel: column tiles per workgroup, at most (LPGP_ASM_CT)
   int asm_factors = 0;             // per-entry assembly / matrix-free product: exponentials of Matern dimensions from per-point factors (eval_entries.h);
                                    // +13 % on the kernel, ~4x the rounding noise of the entries (two exps and a product instead of one exp): off by default
   int gemm3_fact = 0;              // ... inside the FACTORISATION only if set: beside the panel chain the third resident workgroup costs the chain what it gains the update (c3: condition phase 33.6 -> 34.1 ms with it, predict phase 22.9 -> 22.6 ms: the forward substitution keeps it)

@@ -238,6 +238,33 @@ def test_specialised_assembly_is_bit_identical(ctx):
         ctx.set_option("asm_fast", 1)
 
 
+def test_column_tiles_per_workgroup_give_the_same_bits(ctx):
+    """`asm_ct` (assemble_fast_kernel walks several consecutive column tiles per workgroup on large launches): a ragged
+    rectangular block, and a symmetric diagonal block written through the lower-triangle path of the Gram assembly (a
+    conditioning on 6 000 scattered points), against one tile per workgroup -- identical bits."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(21)
+    k = 1.5 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=0.9), cf.Matern((), nu=1.5, lengthscales=0.6))
+    kk = diffops.PartialDerivative(diffops.MultiIndex((1, 0)))(k, argnum=1)          # an odd parity class
+    X0, X1 = rng.uniform(-1, 1, (4096 - 29, 2)), rng.uniform(-1, 1, (9000 - 11, 2))
+    Xo, Y = rng.uniform(-1, 1, (6000, 2)), rng.standard_normal(6000)
+    Xt = rng.uniform(-1, 1, (33, 2))
+    got = {}
+    try:
+        for ct in (1, 4):
+            ctx.set_option("asm_ct", ct)
+            M = np.asarray(kk.matrix(X0, X1))
+            u = lp.GaussianProcess(lp.functions.Zero((2,)), k).condition_on_observations(
+                Y, Xo, b=lp.randvars.Normal(np.zeros(6000), np.full(6000, 1e-2)))
+            got[ct] = (M, *u.predict(Xt))
+    finally:
+        ctx.set_option("asm_ct", 4)
+    for a, b in zip(got[1], got[4]):
+        assert np.array_equal(a, b)
+
+
 def test_per_point_exponential_factors_option(ctx):
     """Option `asm_factors` (off by default): the exponential of every Matern dimension from per-point factors
     `e^{-+a(x - x0)}` (two multiplies and a minimum per entry instead of an exp; eval_entries.h).  Entries against the
