@@ -104,7 +104,7 @@ struct lpgp_ctx {
   // estimated duration of one tile step of the panel chain (factorisation / forward substitution) and of
   // the per-panel rest, in microseconds: decides whether the remainder update is released with the panel
   // (update-bound) or after the look-ahead half (chain-bound)
-  double chain_us_tile = 150.0, solve_chain_us_tile = 150.0, chain_us_fixed = 80.0;   // (re-swept after the tile solves got their refinement step: scratch/sweep_chain.sh)
+  double chain_us_tile = 150.0, solve_chain_us_tile = 30.0, chain_us_fixed = 80.0;   // (factorisation: re-swept after the tile solves got their refinement step, scratch/sweep_chain.sh; forward substitution: its fused panel chain takes 117 us per 4 tile rows + 65 us of look-ahead update at c3 -- with the factorisation's 150 us per tile row the second half of the c3 prediction held every remainder update back behind its look-ahead half, 100 us of idle update stream per panel: 23.3 -> 22.7 ms, profiles/r03_solve_chain_estimate.txt)
   int min_supertiles = 128;        // GEMM grid: shrink the super-tile edge until there are this many
   int dense_tiles = 1;             // GEMM grid: dense XCD-balanced tile enumeration (0: legacy super-tile dealing)
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
