@@ -200,9 +200,12 @@ def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var
     prior = build_prior(wl) if prior is None else prior
     u = prior
     for i, o in enumerate(wl.observations):
-        X, Y = o.X_as_given()
         if device_arrays is not None:
+            # the points are resident: only the shape the builders would give Y is needed (not the 100 us of meshgrid)
             X = device_arrays["obs"][i]
+            Y = o.Y if o.grid is None else o.Y.reshape(tuple(len(f) for f in o.grid))
+        else:
+            X, Y = o.X_as_given()
         n = o.X.shape[0]
         b = None if o.noise_var is None else randvars.Normal(np.zeros(Y.shape), np.full(n, o.noise_var))
         u = u.condition_on_observations(Y, X=X, L=operator_of(o.op, wl.d), b=b)

@@ -1,17 +1,21 @@
-# where the HOST time of a small step goes (N_tot = 1152: five conditionings + prediction)
+"""Where the HOST time of a c3 step goes (Python + ctypes), cProfile over 20 steps; the device runs asynchronously, so
+functions that wait for it (stream synchronisation inside the factorisation's status read-back, result read-backs) show up
+with their waiting time."""
 import cProfile, pstats, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "linpde-gp_amd")
+sys.path.insert(0, '.'); sys.path.insert(0, 'linpde-gp_amd')
+import numpy as np
 import linpde_gp_amd as lp
-from linpde_gp_amd import _engine, problems
-ctx = _engine.default_context()
-wl = problems.poisson_2d(32, m_side=16)
-lp.config.gram_capacity_hint = wl.n_total
-dev = problems.upload(wl); prior = problems.build_prior(wl)
-for _ in range(5): problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
-ctx.sync(); t0 = time.perf_counter()
-for _ in range(50): problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
-ctx.sync(); print("ms per step", (time.perf_counter() - t0) / 50 * 1e3)
-pr = cProfile.Profile(); pr.enable()
-for _ in range(50): problems.condition_and_predict(wl, prior=prior, device_arrays=dev)
+from linpde_gp_amd import problems
+wl = problems.poisson_2d() if len(sys.argv) < 2 else getattr(problems, sys.argv[1])()
+dev = problems.upload(wl)
+prior = problems.build_prior(wl)
+for _ in range(3):
+    u, m, v = problems.condition_and_predict(wl, prior=prior, device_arrays=dev); u = None
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+for _ in range(20):
+    u, m, v = problems.condition_and_predict(wl, prior=prior, device_arrays=dev); u = None
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+print(f"{(time.perf_counter() - t0) / 20 * 1e3:.2f} ms per step under cProfile")
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
