@@ -13,10 +13,11 @@ from ._workloads import (
     poisson_1d,
     poisson_2d,
     row_residual,
+    scattered_2d,
     upload,
 )
 
 __all__ = [
     "pde", "Observation", "Workload", "build_prior", "condition_and_predict", "heat_1d",
-    "operator_of", "poisson_1d", "poisson_2d", "upload", "row_residual", "analytic_solution",
+    "operator_of", "poisson_1d", "poisson_2d", "scattered_2d", "upload", "row_residual", "analytic_solution",
 ]

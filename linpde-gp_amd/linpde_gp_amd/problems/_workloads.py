@@ -118,6 +118,18 @@ def heat_1d(nt: int = 512, nx: int = 64, alpha: float = 0.1, m_side: int = 64) -
     return Workload(f"heat1d_{nt}x{nx}", 2, kernel, [ic, *bcs, pde, interior], Xt)
 
 
+def scattered_2d(n: int = 8192, m: int = 4096, noise_var: float = 1e-2, seed: int = 0) -> Workload:
+    """Noisy values at `n` scattered points of [-1,1]^2, prediction at `m` scattered points, prior 1.5^2 * M52(l=0.8) x
+    M32(l=0.6): no tensor grid anywhere, so every block goes through the per-entry assembly kernels (the BASELINE
+    workloads' large blocks are grids and take the Kronecker path)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1.0, 1.0, size=(n, 2))
+    Y = np.sin(2.0 * X[:, 0]) * np.cos(3.0 * X[:, 1]) + np.sqrt(noise_var) * rng.standard_normal(n)
+    Xt = rng.uniform(-1.0, 1.0, size=(m, 2))
+    kernel = [(2.25, [("matern", 2.5, 0.8), ("matern", 1.5, 0.6)])]
+    return Workload(f"scattered2d_{n}", 2, kernel, [Observation(X, Y, {(0, 0): 1.0}, noise_var)], Xt)
+
+
 # ---- host-object side ------------------------------------------------------------------------
 def build_prior(wl: Workload):
     """The `GaussianProcess` prior of a workload, from the reference-style constructors."""

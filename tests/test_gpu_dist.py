@@ -130,6 +130,9 @@ def _run_ranks(world, grid, workload, nb, port, transport="host", window_mb=None
     ((2, 2), "poisson_2d(n_side=40, n_bdry=33, m_side=9)", 256, 29741),      # the 2 x 2 grid of north_star
     ((2, 2), "heat_1d(nt=40, nx=24, m_side=8)", 256, 29751),                 # mixed functional / differential blocks
     ((1, 3), "heat_1d(nt=40, nx=24, m_side=8)", 128, 29761),
+    # 6 144 scattered points: the sharded per-entry assembly on a LARGE block (several column tiles per workgroup, `asm_ct`,
+    # with the ownership test per tile), 48 tile columns over two ranks
+    ((2, 1), "scattered_2d(n=6144, m=1024)", 512, 29771),
 ])
 def test_multi_rank_on_one_gpu_host_transport(grid, workload, nb, port):
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port)
