@@ -205,8 +205,10 @@ def main():
     ap.add_argument("--m-side", type=int, default=64, help="prediction grid side (c3: 64)")
     ap.add_argument("--cpu-side", type=int, default=0,
                     help="0 (default): time the CPU oracle on the bench workload itself; > 0: on a bounded sample of this grid side")
-    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson1d", "heat1d"],
-                    help="poisson2d = c3/c4 (the metric's workload), poisson1d = c2 (N=8192), heat1d = c5 (N=32768 + IC/BC/noisy interior)")
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson1d", "heat1d", "scattered2d"],
+                    help="poisson2d = c3/c4 (the metric's workload), poisson1d = c2 (N=8192), heat1d = c5 (N=32768 + IC/BC/noisy interior), "
+                         "scattered2d = 16 384 noisy values at scattered points (not a BASELINE config: every block through the "
+                         "per-entry assembly kernels, none through the Kronecker path)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare with the CPU oracle at full size")
     args = ap.parse_args()
@@ -231,6 +233,8 @@ def main():
             return problems.poisson_1d()            # c2
         if args.workload == "heat1d":
             return problems.heat_1d()               # c5
+        if args.workload == "scattered2d":
+            return problems.scattered_2d(n=16384, m=4096)
         return problems.poisson_2d(n_side=n_side, m_side=m_side)
 
     # ---- CPU baseline FIRST (N = 1 only): the host cores are idle, and the GPU section afterwards is one busy stretch ----
@@ -521,7 +525,7 @@ def main():
         out["configs"] = configs
     # assembly kernels, one entry per kernel symbol (HBM-write bound by design; bytes = entries stored x 8,
     # lower triangle only for diagonal blocks)
-    asm_kernels = {"assemble": "assemble_kernel<D> (one fused evaluation per entry: boundary / cross blocks, cross-covariance)",
+    asm_kernels = {"assemble": "assemble_fast_kernel<D,N0,N1,MODE> / assemble_kernel<D> (one fused evaluation per entry: boundary / cross blocks, cross-covariance, every block of scattered points)",
                    "assemble_grid": "kron2_kernel<NU> / kron_expand_kernel (tensor-grid blocks: Kronecker expansion of 1-D kernel matrices)"}
     out["roofline_assembly"] = {}
     for key, label in asm_kernels.items():
