@@ -506,8 +506,11 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
     if (ctx->asm_fast && a.flags == 0 && fast_shape(host_desc, &fd, &N0, &N1)) {
       prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
       // column tiles per workgroup: as many as leave >= 16 workgroups per CU in the launch (at most ctx->asm_ct)
+      // (rectangular blocks only: on a lower-triangle launch the groups that straddle the diagonal do one to four tiles and
+      //  the launch loses its balance -- Gram block of 16 384 scattered points: 3.6 TB/s with four tiles per workgroup, 4.3 with
+      //  one; scratch/assemble_lower.py)
       int ct = 1;
-      while (ct < ctx->asm_ct && (int64_t)a.tiles_r * ((a.tiles_c + 2 * ct - 1) / (2 * ct)) >= 16 * (int64_t)(ctx->cus > 0 ? ctx->cus : 256)) ct *= 2;
+      while (!lower_only && ct < ctx->asm_ct && (int64_t)a.tiles_r * ((a.tiles_c + 2 * ct - 1) / (2 * ct)) >= 16 * (int64_t)(ctx->cus > 0 ? ctx->cus : 256)) ct *= 2;
       a.ct = ct;
       grid = dim3((unsigned)((int64_t)a.tiles_r * ((a.tiles_c + ct - 1) / ct)));
       if (host_desc.d == 1) launch_fast<0, 1>(N0, N1, grid, stream, fd, a);
