@@ -249,8 +249,11 @@ __device__ __forceinline__ bool map_tile_dense(const GemmArgs& g, int v, int& tr
 // co-resident workgroups -- was measured and is 1-4 % SLOWER: the dispatcher already overlaps
 // one workgroup's prologue with its neighbour's k-loop.  In-kernel stamps (-DLPGP_STAMP,
 // scratch/stamp_test.hip) show the k-loop at 16.1 cycles per MFMA per SIMD, i.e. the matrix pipe
-// is saturated; what is left is the C prologue (~15k of ~280k cycles per tile at k = 512) and
-// the clock: 2.35 GHz on all-zero operands, 1.97-2.07 GHz on random data.  Folding C into the
+// is saturated; what is left is the C prologue (~15k of ~280k cycles per tile at k = 512) and, in
+// SHORT measurements, the clock: for the first ~40 ms after the onset of load the chip runs at
+// 1.7-2.07 GHz on random data (2.35 GHz on all-zero operands) -- a burst of five launches sees
+// 53-55 TFLOP/s at k = 512 -- and then settles at 2.4 GHz, where the same launch sustains 65 TFLOP/s
+// (68.5 at k = 2048; 59 on the CU-masked update stream; profiles/r03_clock_power.txt).  Folding C into the
 // first nine k-stages instead (accumulators from zero, 8 C values per lane loaded per stage and
 // added one stage later, so that the MFMAs start as soon as the first operand stage lands) was
 // built and measured: no gain either (51 vs 52 TFLOP/s at k = 512) -- the co-resident workgroup

@@ -495,11 +495,11 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   // ---- phase B: right-looking with look-ahead; on LARGE matrices the far columns are updated once
   //      per nb_outer columns ----
   // A trailing update costs more than its flops when K is short: every C tile is read and written
-  // once per launch (traffic that also pulls the core clock down: 1.83-1.94 GHz inside a K = 512
-  // launch against 2.12 GHz at K = 2048, in-kernel s_memtime / s_memrealtime) and while a workgroup
-  // loads C its CU has a single workgroup in the k-loop (27 % of the time at K = 512, 11 % at 2048;
-  // scratch/timeline.hip): the same output runs at 51-53 TFLOP/s with K = 512, 58 with K = 1024, 62
-  // with K = 2048.  Longer-K workgroups hold their CU slots longer, which slows every kernel of the
+  // once per launch and while a workgroup loads C its CU has a single workgroup in the k-loop (27 % of
+  // the time at K = 512, 11 % at 2048; scratch/timeline.hip): in steady state the same output runs at
+  // 65.1 TFLOP/s with K = 512, 67.1 with K = 1024, 68.5 with K = 2048 (profiles/r03_clock_power.txt; the
+  // 51-53 / 58 / 62 of rounds 1-2 were five-launch bursts inside the clock dip that follows the onset
+  // of load, which exaggerates the difference).  Longer-K workgroups hold their CU slots longer, which slows every kernel of the
   // panel chain next to them; at c3 sizes that costs more than the update gains,
   // so the schedule below is used only while more than nb_outer_min_tiles tile columns remain.
   // Then nb_outer / nb consecutive panels form an OUTER panel: inside it the rank-nb updates touch
