@@ -487,12 +487,15 @@ class ConditionalGaussianProcess(GaussianProcess):
         return (mean, var.reshape(batch)) if return_var else mean
 
     def _predict_local(self, x_original, X, return_var):
+        # the cross-covariance launches first: the device assembles it while the host stages the residual (a synchronous
+        # 135-KB upload at c3) or the weights are solved for
+        self._check_current()
+        pts = _engine.as_points(self._state.ctx, x_original, X)
+        rhs = self._cross(pts)
         if return_var and self._representer_weights is None:
             self._ensure_residual()
         else:
             self._ensure_weights()
-        pts = _engine.as_points(self._state.ctx, x_original, X)
-        rhs = self._cross(pts)
         pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])
         kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None
         return rhs.predict(pm, kxx, want_mean=True, want_var=return_var)
