@@ -310,11 +310,15 @@ int lpgp_init(int device, lpgp_ctx** out) {
   // The trailing-update stream may use all CUs except a few reserved ones, so that the
   // panel kernels of the look-ahead (a 156-KB-LDS tile Cholesky needs a whole CU) never queue
   // behind thousands of resident update workgroups.  LPGP_RESERVE_CUS=0 disables the mask.
-  int reserve = 8;
+  // 32 = four CUs per XCD.  In steady state the mask costs the rank-512 update 10 % whether 1, 8 or 32 CUs are missing (65.1 ->
+  // 58.8 / 58.5 TFLOP/s: the dispatcher feeds the shader engines evenly, so the first missing CU of an engine already sets
+  // its pace; 64 missing cost 22 %; profiles/r03_clock_power.txt) -- so the chain may as well have the 32: c3 55.03-55.21 ms
+  // against 55.18-55.64 with 8, c2 / c4 / c5 within their spread (MEASUREMENTS.md).
+  int reserve = 32;
   if (const char* e = std::getenv("LPGP_RESERVE_CUS")) reserve = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RESERVE_CUS_NARROW")) ctx->reserve_narrow = std::atoi(e);
   // mask bit i = CU (i / 8) of XCD (i % 8) (measured, scratch/cumask.hip): clearing the low
-  // `reserve` bits takes the CUs round-robin from the XCDs, one per XCD for reserve == 8,
+  // `reserve` bits takes the CUs round-robin from the XCDs, reserve / 8 per XCD,
   // so a single workgroup of the panel stream finds a free CU on whichever XCD it is dealt to
   auto masked_stream = [&](int nreserve, hipStream_t* out) {
     *out = nullptr;
