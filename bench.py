@@ -196,6 +196,117 @@ def pmc_traffic(sha, kernel_symbol, profiles_dir=None):
     return out
 
 
+def visible_gpus():
+    """Number of GPUs this process could open, WITHOUT a HIP call (the launcher never touches the GPU): KFD topology
+    nodes with SIMDs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when the
+    topology cannot be read (the ranks then find out themselves)."""
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return 0 if not os.path.exists("/dev/kfd") else None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([d for d in os.environ[var].split(",") if d.strip()]))
+    return n
+
+
+def _free_port_pair():
+    """MASTER_PORT with MASTER_PORT + 1 free as well (the control plane of `_dist.Comm` listens there)."""
+    import socket
+    for _ in range(64):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        if port + 1 < 65536:
+            try:
+                with socket.socket() as s2:
+                    s2.bind(("127.0.0.1", port + 1))
+                return port
+            except OSError:
+                continue
+    raise SystemExit("bench.py: no free port pair for the control plane")
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` called the way the reference is called -- from ONE process
+    (/root/reference/src/linpde_gp/randprocs/_gaussian_process/_conditional.py:253-294), no launcher around it.  This
+    process starts N fresh children of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / a free
+    MASTER_PORT: the environment `python -m torch.distributed.run` would give them), BEFORE it has imported the engine
+    or made any GPU call -- never a re-exec of a process that touched the GPU.  It relays rank 0's stdout (the ONE JSON
+    line), ends the other ranks as soon as one fails, and returns non-zero with ONE error line if a rank failed, if
+    fewer than N GPUs are visible, or if the line printed is not a line for N GPUs."""
+    import signal
+    import subprocess
+    import tempfile
+    shared = "LPGP_DEVICE" in os.environ        # bring-up on one GPU (tests): every rank opens that device
+    have = int(os.environ["LPGP_BENCH_ASSUME_GPUS"]) if "LPGP_BENCH_ASSUME_GPUS" in os.environ else visible_gpus()   # (tests: the ranks' own failure path)
+    if have is not None and have < (1 if shared else n):
+        sys.stderr.write(f"bench.py: --gpus {n} but {have} GPU(s) visible on this node: nothing measured\n")
+        return 2
+    port = _free_port_pair()
+    procs, errs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LPGP_BENCH_LAUNCHER="self")
+        # rank 0's stderr passes through; the other ranks' is kept and shown only for the rank that failed first
+        errs.append(None if r == 0 else tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
+
+    def end_all():
+        for p_ in procs:
+            if p_.poll() is None:
+                try:
+                    os.killpg(p_.pid, signal.SIGKILL)       # exactly the process groups started above
+                except OSError:
+                    pass
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("LPGP_BENCH_TIMEOUT", "1500")) + 60.0
+    t0, failed = time.time(), None
+    try:
+        while any(p_.poll() is None for p_ in procs):
+            bad = [(r, p_.returncode) for r, p_ in enumerate(procs) if p_.poll() not in (None, 0)]
+            if bad or time.time() - t0 > limit:
+                failed = bad[0] if bad else ("all", "timeout")
+                time.sleep(0.5)          # let the peers print what they know, then end them
+                break
+            time.sleep(0.05)
+    finally:
+        end_all()
+    reader.join(5.0)
+    bad = [(r, p_.returncode) for r, p_ in enumerate(procs) if p_.returncode != 0]
+    failed = failed or (bad[0] if bad else None)
+    if failed is not None:
+        if isinstance(failed[0], int) and errs[failed[0]] is not None:
+            errs[failed[0]].seek(0)
+            sys.stderr.write("".join(errs[failed[0]].read().decode(errors="replace").splitlines(True)[-30:]))
+        sys.stderr.write(f"bench.py: --gpus {n}: rank {failed[0]} ended with status {failed[1]}; the other ranks were stopped, no line printed\n")
+        return 1
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    try:
+        got = json.loads(lines[-1])["n_gpus"]
+    except (IndexError, ValueError, KeyError):
+        got = None
+    if got != n:
+        sys.stderr.write(f"bench.py: --gpus {n}: rank 0 printed no line for {n} GPUs (n_gpus = {got})\n")
+        return 1
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,10 +324,16 @@ def main():
     ap.add_argument("--check", action="store_true", help="also compare with the CPU oracle at full size")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher (no GPU call, no engine import) and exits
+        # with the job's status; the N ranks are fresh children that re-enter main() with WORLD_SIZE set
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a line for another GPU count than the one asked for is never printed")
 
     # a hung collective must not hold the node until the caller's own limit
     limit = float(os.environ.get("LPGP_BENCH_TIMEOUT", "1500"))
@@ -544,6 +661,7 @@ def main():
         out["cpu_baseline"] = cpu_json
     if ref is not None:
         out["parity"] = parity_report(mean, var, ref, wl)
+    assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
     _libc.fflush(None)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)

@@ -497,6 +497,11 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "live_mats") == 0) *value = ctx->live_mats;
   else if (std::strcmp(key, "asm_ct") == 0) *value = ctx->asm_ct;
   else if (std::strcmp(key, "asm_fast") == 0) *value = ctx->asm_fast;
+  else if (std::strcmp(key, "nb_outer_solve") == 0) *value = ctx->nb_outer_solve;
+  else if (std::strcmp(key, "nb_outer_solve_min_tiles") == 0) *value = ctx->nb_outer_solve_min_tiles;
+  else if (std::strcmp(key, "nb_solve") == 0) *value = ctx->nb_solve;
+  else if (std::strcmp(key, "solve_chain_us_tile") == 0) *value = (int64_t)ctx->solve_chain_us_tile;
+  else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
   else LPGP_CHECK(false, "unknown option %s", key);
   return 0;
 }
@@ -541,6 +546,9 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
   } else if (std::strcmp(key, "nb_outer_solve") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer_solve must be a multiple of %d (0 disables)", TILE);
     ctx->nb_outer_solve = value;
+  } else if (std::strcmp(key, "nb_outer_solve_min_tiles") == 0) {
+    LPGP_CHECK(value >= 0, "nb_outer_solve_min_tiles must be >= 0");
+    ctx->nb_outer_solve_min_tiles = (int)value;
   } else if (std::strcmp(key, "nb_outer") == 0) {
     LPGP_CHECK(value >= 0 && value % TILE == 0, "nb_outer must be a multiple of %d (0 disables)", TILE);
     ctx->nb_outer = value;

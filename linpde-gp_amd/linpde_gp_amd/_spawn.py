@@ -3,8 +3,9 @@
 The reference is called from ONE Python process (`prior.condition_on_observations(...)`, `_conditional.py:253-294`); the
 multi-GPU path of this library is one process per GPU, every rank making every collective call (`include/lpgp.h`).
 `spawn(n_gpus)` closes that gap without asking the user to launch the script SPMD: it starts `n_gpus` FRESH worker
-processes (multiprocessing "spawn" start method: a new interpreter each, started before this process has made any GPU
-call -- never a fork or re-exec of a process that has touched the GPU), every worker opens its GPU, joins the job
+processes (`python -m linpde_gp_amd._spawn_worker`: a new interpreter each that runs THAT module, never the caller's
+script -- an unguarded script, one without `if __name__ == "__main__":`, works -- started before this process has made
+any GPU call, never a fork or re-exec of a process that has touched the GPU), every worker opens its GPU, joins the job
 (`Context.dist_init`: RCCL over xGMI by default) and then replays the calls this process forwards to it.  From then on
 
     u = prior.condition_on_observations(Y, X, L=D, b=noise)      # returns a proxy; the factor lives sharded on the GPUs
@@ -12,8 +13,8 @@ call -- never a fork or re-exec of a process that has touched the GPU), every wo
     u2 = u.condition_on_observations(...)
 
 run on all GPUs while the calling script stays what it was.  What travels: the prior, operators, noise and point arrays
-(pickled over the private pipes multiprocessing creates between a parent and its own children -- not a network socket),
-results from rank 0.  The parent itself never opens a GPU.
+(pickled over an authenticated `multiprocessing.connection` on a private AF_UNIX socket in a 0700 temporary directory --
+not a network socket), results from rank 0.  The parent itself never opens a GPU.
 
     import linpde_gp_amd as lp
     lp.spawn(8)            # or: LPGP_SPAWN=8 in the environment, picked up at the first conditioning
@@ -23,10 +24,16 @@ from __future__ import annotations
 
 import atexit
 import itertools
-import multiprocessing as mp
 import os
+import secrets
+import shutil
 import socket
+import subprocess
+import sys
+import tempfile
+import time
 import traceback
+from multiprocessing.connection import Listener
 
 import numpy as np
 
@@ -51,7 +58,7 @@ def _free_port() -> int:
 
 
 def _worker_main(rank, world, port, conn, transport, device, grid, extra_env):
-    """Body of a worker process (fresh interpreter).  Environment first, GPU second."""
+    """Body of a worker process (fresh interpreter, entered from `_spawn_worker`).  Environment first, GPU second."""
     global _in_worker
     _in_worker = True
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(device), "LPGP_DEVICE": str(device),
@@ -128,20 +135,49 @@ class WorkerGroup:
         self.timeout = timeout
         devices = list(range(self.world)) if devices is None else list(devices)
         port = _free_port()
-        ctx = mp.get_context("spawn")
+        # Workers run `python -m linpde_gp_amd._spawn_worker` -- a module of this package, NOT the caller's __main__
+        # (multiprocessing's "spawn" start method re-imports the caller's script in every child: an unguarded script
+        # would call spawn() again there).  They dial back over an authenticated AF_UNIX connection.
+        self._tmp = tempfile.mkdtemp(prefix="lpgp-spawn-")
+        authkey = secrets.token_bytes(32)
+        listener = Listener(os.path.join(self._tmp, "ctl"), family="AF_UNIX", authkey=authkey)
+        pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         self._procs, self._conns = [], []
-        for r in range(self.world):
-            extra = dict(env or {})
-            if rccl_loopback:
-                # bring-up aid for ranks that SHARE one GPU (tests): RCCL takes them for different hosts and runs its socket
-                # transport over the loopback interface -- the product's RCCL code path, not the xGMI data path
-                extra.update(NCCL_HOSTID=f"lpgp-spawn-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
-            parent, child = ctx.Pipe()
-            p = ctx.Process(target=_worker_main, args=(r, self.world, port, child, transport, devices[r], grid, extra), daemon=True)
-            p.start()
-            child.close()
-            self._procs.append(p)
-            self._conns.append(parent)
+        try:
+            child_env = {k: v for k, v in os.environ.items() if k != "LPGP_SPAWN"}
+            child_env["PYTHONPATH"] = os.pathsep.join([pkg_parent] + [p_ for p_ in child_env.get("PYTHONPATH", "").split(os.pathsep) if p_])
+            child_env["LPGP_SPAWN_AUTHKEY"] = authkey.hex()
+            for r in range(self.world):
+                self._procs.append(subprocess.Popen([sys.executable, "-m", "linpde_gp_amd._spawn_worker", listener.address, str(r)],
+                                                    env=child_env, stdin=subprocess.DEVNULL))
+            listener._listener._socket.settimeout(0.5)
+            by_rank, t_end = {}, time.monotonic() + timeout
+            while len(by_rank) < self.world:
+                try:
+                    c = listener.accept()
+                except (socket.timeout, TimeoutError):
+                    dead = [r for r, p in enumerate(self._procs) if p.poll() is not None and r not in by_rank]
+                    if dead:
+                        raise RuntimeError(f"multi-GPU front: worker {dead[0]} died during bring-up (before it dialled back)") from None
+                    if time.monotonic() > t_end:
+                        raise RuntimeError(f"multi-GPU front: a worker did not dial back within {timeout:.0f} s") from None
+                    continue
+                by_rank[c.recv()] = c
+            for r in range(self.world):
+                extra = dict(env or {})
+                if rccl_loopback:
+                    # bring-up aid for ranks that SHARE one GPU (tests): RCCL takes them for different hosts and runs its socket
+                    # transport over the loopback interface -- the product's RCCL code path, not the xGMI data path
+                    extra.update(NCCL_HOSTID=f"lpgp-spawn-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
+                by_rank[r].send((r, self.world, port, transport, devices[r], grid, extra))
+                self._conns.append(by_rank[r])
+        except BaseException:
+            for p in self._procs:
+                p.kill()
+            shutil.rmtree(self._tmp, ignore_errors=True)
+            raise
+        finally:
+            listener.close()
         self._ids = itertools.count(1)
         self.info = self._collect("bring-up")
         atexit.register(self.close)
@@ -192,11 +228,17 @@ class WorkerGroup:
                 except Exception:  # noqa: BLE001
                     pass
         for p in self._procs:
-            p.join(timeout=5.0 if not force else 0.5)
-            if p.is_alive():
+            try:
+                p.wait(timeout=5.0 if not force else 0.5)
+            except subprocess.TimeoutExpired:
                 p.terminate()
+                try:
+                    p.wait(timeout=5.0)
+                except subprocess.TimeoutExpired:
+                    p.kill()
         for c in conns:
             c.close()
+        shutil.rmtree(self._tmp, ignore_errors=True)
         if _active is self:
             _active = None
 
@@ -281,7 +323,12 @@ def active():
     if _active is None and int(os.environ.get("LPGP_SPAWN", "0") or 0) > 1:
         from . import _engine
         if _engine._default_ctx is None:
-            _active = WorkerGroup(int(os.environ["LPGP_SPAWN"]))
+            kw = {}
+            if os.environ.get("LPGP_SPAWN_DEVICES"):            # e.g. "0,0": ranks sharing a device (bring-up / tests)
+                kw["devices"] = [int(d) for d in os.environ["LPGP_SPAWN_DEVICES"].split(",")]
+            if os.environ.get("LPGP_SPAWN_TRANSPORT"):
+                kw["transport"] = os.environ["LPGP_SPAWN_TRANSPORT"]
+            _active = WorkerGroup(int(os.environ["LPGP_SPAWN"]), **kw)
     return _active
 
 

@@ -39,3 +39,25 @@ def test_bench_prints_one_contract_line():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert line["parity"]["pass"] is True
     assert len(line["config"]["csrc_sha16"]) == 16
+
+
+def test_plain_call_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver calls N = 1, the way the reference is
+    called: one process, `_conditional.py:253-294`): the process starts its two ranks itself, before any GPU call, and
+    the line is a line for TWO ranks -- never a one-GPU line for a two-GPU request.  On the one GPU of the test box both
+    ranks open device 0 and RCCL runs over loopback sockets (bring-up aid: code path, not rates)."""
+    env = dict(os.environ, LPGP_DEVICE="0", LPGP_BENCH_RCCL_LOOPBACK="1", OPENBLAS_NUM_THREADS="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n-side", "48", "--m-side", "16"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["transport"] == "rccl"
+    assert line["config"]["process_grid"] == [2, 1]
+    assert len(line["config"]["comm_per_rank_per_step"]) == 2
+    assert all(r["bytes_received"] > 0 for r in line["config"]["comm_per_rank_per_step"])

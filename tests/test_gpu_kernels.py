@@ -386,3 +386,39 @@ def test_fused_panel_solve(nt, cols):
     np.testing.assert_allclose(got_r, exact.T, rtol=0, atol=1e-9 * np.abs(exact).max())
     res_r = np.abs(got_r @ L.T - V.T) / (np.abs(got_r) @ np.abs(L.T))
     assert np.max(res_r) < 5e-14, np.max(res_r)
+
+
+@pytest.mark.parametrize("chain_bound", [True, False])
+def test_two_level_forward_substitution_small(ctx, chain_bound):
+    """`trsm_lower_two_level` (potrf.hip; on by default from 384 tile rows on, i.e. only at c4's size) brought down to a
+    size the regular suite reaches: outer blocks of 1024 rows from 16 tile rows on, a RAGGED last outer block
+    (21 tile rows = 8 + 8 + 5), 1 156 right-hand-side columns, and both branches of its schedule -- the far update
+    released with the block (update-bound) and after the look-ahead half (chain-bound), forced through the chain estimate.
+    predict() must agree with the plain right-looking solve and with the oracle."""
+    from conftest import posterior_tolerances
+    from linpde_gp_amd import problems
+    from oracle import workloads as owl
+    wl = problems.poisson_2d(n_side=50, n_bdry=28, m_side=34)
+    assert wl.n_total > 20 * 128 and wl.Xtest.shape[0] >= 1024
+    ref = owl.run(wl)
+    saved = {k: ctx.get_option(k) for k in ("nb_outer_solve", "nb_outer_solve_min_tiles", "solve_chain_us_tile", "chain_us_fixed")}
+    try:
+        ctx.set_option("nb_outer_solve", 0)
+        u, mean0, var0 = problems.condition_and_predict(wl)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        ctx.set_option("nb_outer_solve", 1024)
+        ctx.set_option("nb_outer_solve_min_tiles", 16)
+        ctx.set_option("solve_chain_us_tile", 1000000 if chain_bound else 0)
+        ctx.set_option("chain_us_fixed", 0)
+        mean1, var1 = u.predict(wl.Xtest)
+        prof = ctx.profile_get(); ctx.profile_enable(False)
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+    # the two-level path ran: its far updates contract over 1024 rows (the plain path never exceeds its panel width)
+    assert prof["panel_fused"]["launches"] >= 6
+    ma, va = posterior_tolerances(ref["mean"], ref["var"])
+    assert np.max(np.abs(mean1 - ref["mean"])) <= ma and np.max(np.abs(var1 - ref["var"])) <= va
+    assert np.max(np.abs(mean0 - ref["mean"])) <= ma and np.max(np.abs(var0 - ref["var"])) <= va
+    np.testing.assert_allclose(mean1, mean0, rtol=0, atol=ma)
+    np.testing.assert_allclose(var1, var0, rtol=0, atol=va)

@@ -342,3 +342,34 @@ def test_bench_reports_pmc_traffic_only_from_the_running_sources(tmp_path):
     write("r05_bench_c3_summary.json", sha, sym, 1.7e9)
     got = bench.pmc_traffic(sha, sym, str(tmp_path))
     assert got["traffic"] == 1.7e9 and got["traffic_collected_at_csrc"] == sha and "r05_" in got["traffic_source"]
+
+
+def test_bench_gpus_n_without_launcher_fails_once_on_a_box_without_gpus():
+    """`python bench.py --gpus 2` called plainly starts its own ranks -- and on a box with fewer GPUs than asked for it
+    prints ONE error, no JSON line, and exits non-zero (round 3: it silently measured one GPU and printed n_gpus 1)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    spec = importlib.util.spec_from_file_location("lpgp_bench_l", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    if (bench.visible_gpus() or 0) >= 2:
+        pytest.skip("two GPUs visible: this is the failure-path test")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0
+    assert "{" not in res.stdout
+    assert len([ln for ln in res.stderr.splitlines() if ln.startswith("bench.py:")]) == 1
+    if (bench.visible_gpus() or 0) == 0:
+        # the ranks' own failure path: the launcher believes there are two GPUs, the ranks cannot open one
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                             env=dict(env, LPGP_BENCH_ASSUME_GPUS="2"), capture_output=True, text=True, timeout=120)
+        assert res.returncode != 0 and "{" not in res.stdout
+        assert len([ln for ln in res.stderr.splitlines() if ln.startswith("bench.py:")]) == 1
+        assert "no line printed" in res.stderr
+    # a launcher-given WORLD_SIZE that disagrees with --gpus is refused as well (never a line for another count)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "{" not in res.stdout
