@@ -620,7 +620,6 @@ __global__ __launch_bounds__(256, 3) void gemm3_f64_kernel(GemmArgs g) {
 // =========================================================================================
 constexpr int LDMP = 144;
 constexpr int SOPER = 8 * LDMP;          // doubles per operand per stage (K image uses 1024 of them)
-constexpr int SSTAGES = 4;
 
 template <bool T>
 __device__ __forceinline__ void dma_tile64(const double* __restrict__ P, int64_t ld, int64_t idx0, int64_t k0,
@@ -662,8 +661,12 @@ __device__ __forceinline__ unsigned frag64_lane_n(int lane, int w) {
 template <bool T> constexpr int frag64_imm_m(int ks, int t) { return T ? t * 256 : 2 * ks * LDMP + 16 * t; }
 template <bool T> constexpr int frag64_imm_n(int ks, int u) { return T ? u * 64 + (((ks ^ u) & 3) << 2) : 2 * ks * LDMP + 4 * u; }
 
-template <bool TA, bool TB, int TRI>
+// SS = stages of the ring: 4 (73.7 KB, three stages in flight, two workgroups per CU) or 2 (36.9 KB, four workgroups per
+// CU: round 4, for the rank-128 updates inside a panel -- K = 128 is 8 stages, and on the CUs the narrow update stream
+// leaves to the chain the launch is bound by how many workgroups fit, not by the depth of its prefetch).
+template <bool TA, bool TB, int TRI, int SS>
 __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
+  static_assert(SS == 2 || SS == 4, "gemm64: ring of 2 or 4 stages");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -677,13 +680,13 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
   auto sA = [&](int b) { return smem + (size_t)b * 2 * SOPER; };
   auto sB = [&](int b) { return smem + (size_t)b * 2 * SOPER + SOPER; };
   auto issue = [&](int kt) {
-    const int b = kt & (SSTAGES - 1);
+    const int b = kt & (SS - 1);
     dma_tile64<TA>(g.A, g.lda, (int64_t)tr * 64, (int64_t)kt * BK, lane, wu, sA(b));
     dma_tile64<TB>(g.B, g.ldb, (int64_t)tc * 64, (int64_t)kt * BK, lane, wu, sB(b));
   };
-  // three stages in flight before anything else (each wave: 4 DMA instructions per stage)
+  // SS - 1 stages in flight before anything else (each wave: 4 DMA instructions per stage)
 #pragma unroll
-  for (int kt = 0; kt < SSTAGES - 1; ++kt)
+  for (int kt = 0; kt < SS - 1; ++kt)
     if (kt < KT) issue(kt);
 
   unsigned laneM[4];
@@ -712,12 +715,12 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
   for (int kt = 0; kt < KT; ++kt) {
     // stage kt has landed once at most the stages issued after it are outstanding
     const int later = KT - 1 - kt;
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (SS == 4 && later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (SS == 4 && later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // ... for every wave; and stage kt-1 is consumed
-    if (kt + SSTAGES - 1 < KT) issue(kt + SSTAGES - 1);     // into the buffer stage kt-1 was read from
-    const unsigned stoff = (unsigned)((kt & (SSTAGES - 1)) * 2 * SOPER) * 8u;
+    if (kt + SS - 1 < KT) issue(kt + SS - 1);           // into the buffer stage kt-1 was read from
+    const unsigned stoff = (unsigned)((kt & (SS - 1)) * 2 * SOPER) * 8u;
     const unsigned aM0 = laneM[0] + stoff, aM1 = laneM[1] + stoff, aM2 = laneM[2] + stoff, aM3 = laneM[3] + stoff;
     const unsigned aN = laneN + stoff;
     double am[2][4], bn[2][4];
@@ -762,14 +765,22 @@ __global__ __launch_bounds__(256, 2) void gemm64_f64_kernel(GemmArgs g) {
       *reinterpret_cast<double*>(cub + ((int64_t)(4 * u) * g.ldc + t * 16) * 8 + cvoff) = alpha * acc[t][u];
 }
 
-template <bool TA, bool TB, int TRI>
-static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
-  const size_t shmem = (size_t)SSTAGES * 2 * SOPER * sizeof(double);      // 73 728 B
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm64_f64_kernel<TA, TB, TRI>), shmem));
+template <bool TA, bool TB, int TRI, int SS>
+static int launch_small_ss(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
+  const size_t shmem = (size_t)SS * 2 * SOPER * sizeof(double);      // 73 728 B / 36 864 B
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&gemm64_f64_kernel<TA, TB, TRI, SS>), shmem));
   const unsigned blocks = (unsigned)(g.mt * 2) * (unsigned)(g.nt * 2);
-  hipLaunchKernelGGL((gemm64_f64_kernel<TA, TB, TRI>), dim3(blocks), dim3(256), shmem, stream, g);
+  hipLaunchKernelGGL((gemm64_f64_kernel<TA, TB, TRI, SS>), dim3(blocks), dim3(256), shmem, stream, g);
   LPGP_HIP(hipGetLastError());
   return 0;
+}
+template <bool TA, bool TB, int TRI>
+static int launch_small(lpgp_ctx* ctx, hipStream_t stream, const GemmArgs& g) {
+  if constexpr (TRI == 2) {
+    // the rank-128 update inside a panel: wide (all rows below) and short (8 stages)
+    if (ctx->small_ring2 && g.k <= 128 && (int64_t)g.mt * g.nt >= ctx->small_ring2) return launch_small_ss<TA, TB, TRI, 2>(ctx, stream, g);
+  }
+  return launch_small_ss<TA, TB, TRI, 4>(ctx, stream, g);
 }
 
 // the kernel of a launch: the three-resident variant for the NT form when the context asks for it (LPGP_GEMM3)

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "lpgp_internal.h"
+#include "kernel_util.h"
 
 namespace lpgp {
 
@@ -32,8 +33,12 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+// lane K of every 16-lane row of the wave, broadcast to that row (DPP row_newbcast:K, one v_mov_b64_dpp)
+template <int K>
+__device__ __forceinline__ double bcast16(double v) {
+  static_assert(K >= 0 && K < 16, "row_newbcast lane");
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, true);
+}
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
@@ -178,9 +183,14 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
       const int c = r16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[j] = (j == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double piv = bcast_lane(row[j], j);
+      // Broadcasts by DPP `row_newbcast:k` (gfx90a+: lane k of every 16-lane row to the whole row, one 64-bit
+      // v_mov_b64_dpp; the four rows of the wave hold the same matrix rows, so the result equals a wave-wide broadcast of
+      // lane k): round 4.  Rounds 1-3 used two v_readlane_b32 per value -- a VGPR -> SGPR -> VALU round trip with its
+      // wait states (113 s_nop in the listing) -- and the pivot step was bound by the ISSUE of that sequence (~80
+      // instructions, ~450 cycles per pivot); the arithmetic, its order and its rounding are unchanged.
+      static_for<0, 16>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        double piv = bcast16<j>(row[j]);
         if (!(piv > 0.0)) {
           if (!bad) bad = j0 + j + 1;
           piv = 1.0;
@@ -199,26 +209,20 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
         inv = fma(inv, -0.5 * inv * inv * res, inv);       // keep inv consistent with the refined l
         row[j] = (i == j) ? l : row[j] * inv;
         x[j] = (j >= c) ? x[j] * inv : 0.0;                // (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = bcast_lane(row[j], k);        // L[k][j]
+        static_for<j + 1, 16>([&](auto K_) {
+          constexpr int k = decltype(K_)::value;
+          const double lkj = bcast16<k>(row[j]);           // L[k][j]
           row[k] = fma(-row[j], lkj, row[k]);
           x[k] = fma(-lkj, x[j], x[k]);
           // pin both updates here: left alone, the compiler sinks all updates of x[k] and row[k]
-          // down to pivot step k (their first use) and either parks the broadcast L[k][j] in VGPR
-          // lanes until then (264 v_writelane / v_readlane spill pairs) or broadcasts it twice.
-          // (Tried and measured equal or slower: one instruction stream for both recurrences with
-          // factor rows on lanes 0-15 and inverse columns on lanes 16-31; s_setprio for this wave;
-          // keeping its SIMD free of background waves; round 3: two columns per round with their broadcasts issued back
-          // to back -- 84 of the 113 s_nop disappear from the listing and the kernel takes 44.2 instead of 41.0 us; round 3,
-          // 4 x 4 micro-blocks: the diagonal micro-block broadcast to all lanes and factored redundantly, the four new
-          // entries of every row by substitution against it, the trailing columns updated from LDS broadcast reads, factor
-          // rows and inverse columns in one register array (git 3de0b0c): correct, the same rounding, 44.6 instead of
-          // 40.9 us -- the pivot-to-pivot chain of dependent fp64 operations is unchanged and an LDS round trip per four
-          // pivots is added.  ~450 cycles per pivot step remain.)
+          // down to pivot step k (their first use).
+          // (Tried and measured equal or slower in rounds 1-3, all with v_readlane broadcasts: one instruction stream for
+          // both recurrences with factor rows on lanes 0-15 and inverse columns on lanes 16-31; s_setprio for this wave;
+          // keeping its SIMD free of background waves; two columns per round with their broadcasts issued back to back;
+          // 4 x 4 micro-blocks (git 3de0b0c); factor on wave 0 and inverse on wave 1.)
           asm volatile("" : "+v"(x[k]), "+v"(row[k]));
-        }
-      }
+        });
+      });
       if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
       if (lane < 16) {
 #pragma unroll
@@ -310,7 +314,8 @@ int debug_tile_xcc(int32_t* out8, int reset) {
 
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base) {
-  const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
+  size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
+  if (const char* e = std::getenv("LPGP_EXPERIMENT_POTRF_LDS")) shmem = (size_t)std::atol(e);     // TIMING EXPERIMENT ONLY (wrong results)
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&potrf_tile_kernel), shmem));
   prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
   hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
@@ -557,6 +562,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   int h_info = 0;
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
+  if (std::getenv("LPGP_EXPERIMENT_POTRF_LDS")) h_info = 0;
   if (info) *info = h_info;
   return 0;
 }

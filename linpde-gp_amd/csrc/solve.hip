@@ -32,7 +32,7 @@ namespace lpgp {
 // 144 MFMAs per wave and product instead of 256; the fragments of a stage's own diagonal block meet the
 // explicit zeros above the diagonal of Linv / L.  The two groups take their classes in opposite order, so
 // every SIMD holds a wave with 4 cc and one with 4 (3 - cc) columns beyond the stage's diagonal.
-// LDS: 32 KB + 52 KB = 84 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup.
+// LDS: 32 KB + 48 KB = 80 KB -- a solve workgroup fits beside ONE 73-KB GEMM workgroup, and two fit on a free CU.
 // =========================================================================================
 
 // Stage s = (product s / 8, k-rows 16 kt .. 16 kt + 15, kt = s % 8) holds only the columns the lower triangle
@@ -46,6 +46,11 @@ namespace lpgp {
 // flight in the same 52 KB.  (Measured after that, scratch/tile_solve_time.py with diagnostic builds: 16 us for one
 // wave of workgroups, 14 us with the factor loads removed altogether: what is left is the matrix work itself,
 // 3 x 288 MFMAs per SIMD = 6.8 us, plus launch, the loads of A and 26 barriers.)
+// Round 4: the tile solve's own ring is 48 KB (6144 doubles; the fused panel kernels keep TSV_RING = 52 KB), so that the
+// workgroup takes 80 KB of LDS and TWO fit on a CU: on the CUs the narrow update stream leaves to the panel chain (64 in
+// the chain-bound regime: all of c2, the last third of c3) the rows below a tile take two rounds of workgroups instead
+// of three or four.
+constexpr int TSV_RING_TILE = 6144;
 constexpr int tsv_stride(int s) { return 136 - 16 * (s % 8); }
 constexpr int tsv_size(int s) { return 16 * tsv_stride(s); }
 struct TsvSched {
@@ -63,7 +68,7 @@ constexpr TsvSched tsv_make_sched() {
     while (next < TSV_NSTAGE) {
       const int sz = tsv_size(next);
       int o = head;
-      if (o + sz > TSV_RING) o = 0;
+      if (o + sz > TSV_RING_TILE) o = 0;
       bool ok = true;
       for (int l = live_lo; l < next; ++l)
         if (o < S.off[l] + tsv_size(l) && S.off[l] < o + sz) ok = false;
@@ -100,7 +105,7 @@ struct TileSolveArgs {
 
 
 template <bool KFAST>
-__global__ __launch_bounds__(512, 1) void tile_solve_kernel(TileSolveArgs g) {
+__global__ __launch_bounds__(512, 2) void tile_solve_kernel(TileSolveArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* xa = smem;
   double* ring = smem + TSV_XA;
@@ -246,7 +251,7 @@ template <bool KFAST>
 static int launch_tile_solve(lpgp_ctx* ctx, hipStream_t stream, double* P, int64_t ld, const double* linv, const double* L,
                              int64_t ldl, int64_t rows, int prof_kernel) {
   if (rows <= 0) return 0;
-  const size_t shmem = (size_t)(TSV_XA + TSV_RING) * sizeof(double);   // 86 016 B
+  const size_t shmem = (size_t)(TSV_XA + TSV_RING_TILE) * sizeof(double);   // 81 920 B: two workgroups per CU
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&tile_solve_kernel<KFAST>), shmem));
   TileSolveArgs a;
   a.P = P; a.ld = ld; a.linv = linv; a.L = L; a.ldl = ldl;

@@ -18,7 +18,9 @@ by independent high-precision evaluation, not by the oracle under test:
   base kernel in 50-digit mpmath (the reference's cases `cases_matern.py:19-89` with its seeds
   for the directions).
 
-Run:  python tests/golden/make_golden.py      (about a minute; `... iso` writes the last file only)
+* `posterior_noisy.npz`: the same posterior with observation noise (cond ~1e6): held to the plain 1e-8.
+
+Run:  python tests/golden/make_golden.py      (about a minute; `... iso` / `... noisy` write that one file only)
 """
 import os
 import sys
@@ -195,5 +197,48 @@ def main():
     print("wrote kernel_blocks.npz, posterior_small.npz")
 
 
+def posterior_noisy():
+    """`posterior_noisy.npz` (round 4): the 1-D Poisson-Dirichlet problem of `posterior_small.npz` with observation NOISE --
+    variance 1e-6 on the two boundary values, 1e-3 on the 14 PDE observations -- again solved in 50-digit mpmath.  With
+    the noise cond(G) drops from ~1e9 to ~1e6, so an fp64 path must reproduce these vectors to the plain 1e-8 criterion
+    (posterior_small is held to 1e-7: cond(G) eps, see tests/test_gpu_golden.py)."""
+    n = 14
+    Xp = np.linspace(-0.95, 0.95, n)[:, None]
+    Xb = np.array([[-1.0], [1.0]])
+    Xt = np.linspace(-0.9, 0.9, 7)[:, None] + 0.0123
+    fac = [("matern", (2.5, 1.0))]
+    lap1, id1 = {(2,): -1}, {(0,): 1}
+    nb, npde = mpmath.mpf("1e-6"), mpmath.mpf("1e-3")
+    Gbb = block(fac, 4.0, id1, id1, Xb, Xb)
+    Gpb = block(fac, 4.0, lap1, id1, Xp, Xb)
+    Gpp = block(fac, 4.0, lap1, lap1, Xp, Xp)
+    N = 2 + n
+    G = mpmath.zeros(N, N)
+    for i in range(2):
+        for j in range(2):
+            G[i, j] = Gbb[i, j] + (nb if i == j else 0)
+    for i in range(n):
+        for j in range(2):
+            G[2 + i, j] = Gpb[i, j]
+            G[j, 2 + i] = Gpb[i, j]
+        for j in range(n):
+            G[2 + i, 2 + j] = Gpp[i, j] + (npde if i == j else 0)
+    y = mpmath.matrix([0, 0] + [mpmath.pi**2 * mpmath.sin(mpmath.pi * mpmath.mpf(float(v))) for v in Xp[:, 0]])
+    w = mpmath.cholesky_solve(G, y)
+    Ktb = block(fac, 4.0, id1, id1, Xt, Xb)
+    Ktp = block(fac, 4.0, id1, lap1, Xt, Xp)
+    mean, var = [], []
+    for i in range(Xt.shape[0]):
+        krow = mpmath.matrix([Ktb[i, 0], Ktb[i, 1]] + [Ktp[i, j] for j in range(n)])
+        mean.append(float((krow.T * w)[0]))
+        z = mpmath.cholesky_solve(G, krow)
+        var.append(float(mpmath.mpf(4) - (krow.T * z)[0]))
+    np.savez(os.path.join(HERE, "posterior_noisy.npz"), Xp=Xp, Xb=Xb, Xt=Xt, Yp=np.array([float(v) for v in y[2:]]),
+             noise_b=float(nb), noise_p=float(npde), mean=np.array(mean), var=np.array(var), weights=np.array([float(v) for v in w]))
+    print("wrote posterior_noisy.npz")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "noisy":
+        sys.exit(posterior_noisy())
     sys.exit(main())

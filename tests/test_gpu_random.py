@@ -117,12 +117,25 @@ def device_matrices(u, oblocks, Xt, d, Ltest=None):
     return G, K
 
 
+# which of the three terms of the bar each check of each seed NEEDED (1: the plain 1e-8 criterion; 2: 4 x LAPACK's own distance;
+# 3: the forward-error scale 0.05 cond2 2^-53), filled by the test below and judged by test_zz_bound_usage at the end of the module
+_BOUND_USAGE = {}
+_current_seed = [None]
+
+
 def _assert_as_good_as_lapack(what, dev, lapack, exact, cond2=0.0):
     scale = float(np.max(np.abs(exact)))
     e_dev, e_lap = float(np.max(np.abs(dev - exact))), float(np.max(np.abs(lapack - exact)))
-    bound = max(POSTERIOR_RTOL * scale, 4.0 * e_lap, 0.05 * cond2 * 2.0**-53 * scale)
+    terms = (POSTERIOR_RTOL * scale, 4.0 * e_lap, 0.05 * cond2 * 2.0**-53 * scale)
+    bound = max(terms)
+    needed = 1 if e_dev <= terms[0] else (2 if e_dev <= terms[1] else 3)
+    rec = _BOUND_USAGE.setdefault(_current_seed[0], {"needed": 1, "worst": 0.0, "cond2": cond2, "what": ""})
+    if needed > rec["needed"] or (needed == rec["needed"] and e_dev / scale > rec["worst"]):
+        rec.update(needed=max(needed, rec["needed"]), worst=max(e_dev / scale, rec["worst"]), what=what)
     assert e_dev <= bound, (f"{what}: device {e_dev / scale:.2e} from the refined posterior, LAPACK {e_lap / scale:.2e} "
                             f"(bound {bound / scale:.2e}, relative to the maximum; cond2 >= {cond2:.1e})")
+    # the third term may be the binding one only where it exceeds the plain criterion at all (cond2 > 1.8e9)
+    assert needed < 3 or cond2 > 1.8e9, f"{what}: needed the cond2 term at cond2 = {cond2:.1e}"
 
 
 ENTRY_RTOL = 4e-15          # device-evaluated matrices vs NumPy's, relative to the largest entry (measured <= 1e-15)
@@ -132,6 +145,7 @@ ENTRY_RTOL = 4e-15          # device-evaluated matrices vs NumPy's, relative to 
 def test_random_problem_matches_oracle(seed):
     import linpde_gp_amd as lp
     from linpde_gp_amd.linfuncops import diffops
+    _current_seed[0] = seed
     u, okern, oblocks, mean_const, d, rng = _random_problem(lp, seed)
     post = ogp.condition(okern, oblocks, mean_const=mean_const)
     Xt = rng.uniform(-1.0, 1.0, size=(57, d))
@@ -158,3 +172,18 @@ def test_random_problem_matches_oracle(seed):
     dm_exact, dv_exact = ogp.refined_posterior(post, Xt, Ltest)
     _assert_as_good_as_lapack("derivative mean", dm, post.mean(Xt, Ltest), dm_exact, cond2)
     _assert_as_good_as_lapack("derivative variance", dv, post.var(Xt, Ltest), dv_exact, cond2)
+
+
+def test_zz_bound_usage():
+    """VERDICT r3 / ADVICE r3: the bar of the test above is the max of three terms; this reports, per seed, which one was
+    NEEDED, and fails the module if more than 10 % of the seeds needed the third (so that an accuracy regression at high
+    condition cannot hide behind it).  The report reaches the driver's log as a pytest warning (shown with -q too)."""
+    import warnings
+    if len(_BOUND_USAGE) < 40:
+        pytest.skip("the randomised problems did not all run in this session")
+    by = {k: sorted(s_ for s_, r in _BOUND_USAGE.items() if r["needed"] == k) for k in (1, 2, 3)}
+    worst = max(_BOUND_USAGE.items(), key=lambda kv: kv[1]["worst"])
+    warnings.warn(f"random problems: {len(by[1])} seeds inside the plain 1e-8 criterion, {len(by[2])} needed 4 x LAPACK's own distance "
+                  f"{by[2]}, {len(by[3])} needed the cond2 term {by[3]}; worst: seed {worst[0]} at {worst[1]['worst']:.2e} "
+                  f"({worst[1]['what']}, cond2 >= {worst[1]['cond2']:.1e})")
+    assert len(by[3]) <= 0.10 * len(_BOUND_USAGE), by[3]

@@ -1,5 +1,5 @@
 """c4 (BASELINE.json config 4: 2-D Poisson-Dirichlet, 256 x 256 collocation + 4 x 256 boundary observations, N_tot = 66 560:
-a 35.4 GB Gram matrix) on one GPU AT FULL SIZE against the CPU oracle, mean and variance on a 64 x 64 prediction grid with
+a 35.4 GB Gram matrix) on one GPU AT FULL SIZE against the CPU oracle, mean and variance on the 128 x 128 prediction grid of SURVEY's c4 (M = 16 384) with
 the one criterion of tests/conftest.py (1e-8 of max |mean| / max |var|).
 
 The oracle (`oracle.workloads.run_in_place`: chunked NumPy assembly into ONE column-major array, LAPACK dpotrf in place,
@@ -26,8 +26,13 @@ def test_c4_poisson2d_256_full_size_vs_oracle():
     from linpde_gp_amd import problems
     cores, avail = os.cpu_count() or 1, psutil.virtual_memory().available
     full = cores >= 128 and avail >= 160e9
-    wl = problems.poisson_2d(256 if full else 192, m_side=64)
-    assert wl.n_total == (66560 if full else 37632) and wl.Xtest.shape[0] == 4096
+    # M = 16 384 prediction points (128 x 128) -- at full size when the host also has the memory
+    # for the oracle's 66 560 x 16 384 right-hand side (8.7 GB more); 64 x 64 otherwise
+    m_side = 128 if (full and avail >= 200e9) else 64
+    wl = problems.poisson_2d(256 if full else 192, m_side=m_side)
+    assert wl.n_total == (66560 if full else 37632) and wl.Xtest.shape[0] == m_side * m_side
+    if cores >= 128 and psutil.virtual_memory().total >= 400e9:
+        assert full, f"a {cores}-core host with {psutil.virtual_memory().total / 1e9:.0f} GB must run c4 at full size ({avail / 1e9:.0f} GB free)"
     workers = max(1, min(16, cores // 8))
     need = owl.host_memory_needed(wl, 512, workers)
     if avail < 1.2 * need:
@@ -40,6 +45,9 @@ def test_c4_poisson2d_256_full_size_vs_oracle():
     del u
     ref = owl.run_in_place(wl, chunk=512, workers=workers)
     rm, rv = assert_posterior_close(mean, var, ref["mean"], ref["var"])
-    print(f"{wl.name}{'' if full else ' (REDUCED: host too small for 256 x 256)'}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} "
-          f"mean err {rm:.2e} x tol, var err {rv:.2e} x tol; oracle {ref['seconds']} ({workers} assembly threads, {cores} cores)")
+    msg = (f"{wl.name}{'' if full else ' (REDUCED: host too small for 256 x 256)'}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} "
+           f"mean err {rm:.2e} x tol, var err {rv:.2e} x tol; oracle {ref['seconds']} ({workers} assembly threads, {cores} cores)")
+    print(msg)
+    import warnings
+    warnings.warn("c4 full-size parity ran as: " + msg)        # (a warning reaches the driver's `pytest -q` log: which size ran)
     assert abs(mean.max() - 0.5894) < 1e-2
