@@ -344,6 +344,8 @@ def main():
 
     import linpde_gp_amd as lp
     from linpde_gp_amd import _dist, _engine, problems
+    if os.environ.get("LPGP_BENCH_EAGER"):          # A/B aid: the status of every factorisation read back inside condition_on_observations (rounds 1-3)
+        lp.config.lazy_factorization = False
 
     def make_workload(n_side, m_side):
         if args.workload == "poisson1d":

@@ -193,6 +193,20 @@ int  lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host);
  *      are kept (block append).  info: 0 ok, k > 0 => leading minor of (padded) order k
  *      is not positive definite.                                                         */
 int  lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info);
+/* The same factorisation ENQUEUED: no host synchronisation, the status stays on the device (one sticky word per
+ * matrix: the first non-positive pivot).  This is the reference's own order of events -- its Cholesky factor is a
+ * `functools.cached_property` evaluated at first use (_conditional.py:92, linops/_block.py:203), so a Gram matrix that
+ * is not positive definite surfaces at the first solve, not inside `condition_on_observations` -- and it lets the host
+ * run ahead of the device over a chain of conditionings (c3: four boundary blocks of ~0.2 ms each, half of it host
+ * time behind a status read-back).  Single GPU only (the multi-GPU factorisation agrees on its status collectively).
+ * lpgp_mat_check waits for the panel stream and returns the status of everything enqueued since the last check:
+ * info = 0 ok; k > 0: the leading minor of (padded) order k is not positive definite, *block = index of the
+ * observation block it lies in -- the factor of blocks 0 .. *block - 1 is intact.  lpgp_mat_truncate drops the blocks
+ * from `nblocks` on (the full view must be current) and clears the status: the matrix is again what it was before they
+ * were declared, exactly as after lpgp_mat_pop_block.                                                                 */
+int  lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat);
+int  lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block);
+int  lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks);
 /* x = G^{-1} b for nrhs right-hand sides, b_host (n x nrhs, column-major, in/out)      */
 int  lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs);
 /* representer weights w = G^{-1} r; keeps w resident for lpgp_predict; w_host may be

@@ -217,7 +217,7 @@ static int64_t local_cols(const lpgp_ctx* ctx, int64_t padded) { return (int64_t
 
 static size_t mat_bytes_a(const lpgp_mat* m) { return (size_t)m->lr_cap * m->lc_cap * sizeof(double); }
 static size_t mat_bytes_l(int64_t cap) { return (size_t)cap * TILE * sizeof(double); }
-static size_t mat_bytes_w(int64_t cap) { return (size_t)2 * cap * sizeof(double); }   // w | r
+static size_t mat_bytes_w(int64_t cap) { return (size_t)(2 * cap + 8) * sizeof(double); }   // w | r | status word of the enqueued factorisations (lpgp_mat::d_status)
 static size_t mat_bytes_d(const lpgp_ctx* ctx, int64_t cap) { return (size_t)round_up(cap, ctx->nb) * ctx->nb * sizeof(double); }
 
 static void mat_release(lpgp_ctx* ctx, lpgp_mat* mat) {
@@ -255,6 +255,7 @@ static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
     LPGP_HIP(hipMemcpyAsync(nl, mat->linv, (size_t)pn_all * TILE * sizeof(double), hipMemcpyDeviceToDevice,
                             ctx->s_main));
     LPGP_HIP(hipMemcpyAsync(nw, mat->w, (size_t)pn_all * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+    LPGP_HIP(hipMemcpyAsync((double*)nw + 2 * cap, mat->d_status, sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));   // (sticky status: kept)
     if (nd) LPGP_HIP(hipMemcpyAsync(nd, mat->dblk, mat_bytes_d(ctx, pn_all), hipMemcpyDeviceToDevice, ctx->s_main));
     // padding columns of the existing blocks must stay zero in the rows added by the growth
     for (const auto& b : mat->blocks) {
@@ -262,11 +263,13 @@ static int mat_alloc(lpgp_ctx* ctx, lpgp_mat* mat, int64_t cap) {
       if (padc > 0) launch_clear_rows(ctx->s_main, (double*)na, lr, pn_all, cap - pn_all, b.poff + b.n, padc, lay);
     }
   }
+  if (!(mat->a && pn_all > 0)) LPGP_HIP(hipMemsetAsync((double*)nw + 2 * cap, 0, sizeof(double), ctx->s_main));       // a new / empty matrix: status clear
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   if (mat->a) mat_release(ctx, mat);
   mat->a = (double*)na;
   mat->linv = (double*)nl;
   mat->w = (double*)nw;
+  mat->d_status = reinterpret_cast<int*>((double*)nw + 2 * cap);
   mat->dblk = (double*)nd;
   mat->cap = cap;
   mat->lr_cap = lr;
@@ -1071,6 +1074,59 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   return 0;
 }
 
+int lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat) {
+  LPGP_CHECK(ctx && mat, "lpgp_potrf_enqueue: null argument");
+  LPGP_DEVICE(ctx);
+  if (mat->pn_fact == mat->pn) return 0;
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf_enqueue: a strict prefix of the blocks is in view");
+  LPGP_CHECK(!ctx->distributed(), "lpgp_potrf_enqueue: single GPU only (the multi-GPU factorisation agrees on its status collectively: lpgp_potrf)");
+  int rc = potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, nullptr);
+  if (rc != 0) return rc;
+  mat->pn_fact = mat->pn;          // provisionally: lpgp_mat_check / lpgp_mat_truncate take it back on failure
+  mat->unchecked = 1;
+  mat->has_w = 0;
+  mat->has_r = 0;
+  return 0;
+}
+
+int lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block) {
+  LPGP_CHECK(ctx && mat && info, "lpgp_mat_check: null argument");
+  LPGP_DEVICE(ctx);
+  *info = 0;
+  if (block) *block = -1;
+  if (!mat->unchecked) return 0;
+  int h = 0;
+  LPGP_HIP(hipMemcpyAsync(&h, mat->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  mat->unchecked = 0;
+  *info = h;
+  if (h > 0 && block) {
+    std::vector<lpgp_block> all = mat->blocks;
+    all.insert(all.end(), mat->hidden.begin(), mat->hidden.end());
+    for (size_t b = 0; b < all.size(); ++b)
+      if ((int64_t)h - 1 >= all[b].poff && (int64_t)h - 1 < all[b].poff + all[b].pn) *block = (int32_t)b;
+  }
+  return 0;
+}
+
+int lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks) {
+  LPGP_CHECK(ctx && mat, "lpgp_mat_truncate: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_mat_truncate: a strict prefix of the blocks is in view");
+  LPGP_CHECK(nblocks >= 0 && nblocks <= (int32_t)mat->blocks.size(), "lpgp_mat_truncate: %d of %d blocks", nblocks, (int)mat->blocks.size());
+  LPGP_CHECK(!ctx->distributed(), "lpgp_mat_truncate: single GPU only");
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));        // nothing of the dropped blocks still in flight
+  mat->blocks.resize((size_t)nblocks);
+  mat->n = nblocks ? mat->blocks.back().off + mat->blocks.back().n : 0;
+  mat->pn = nblocks ? mat->blocks.back().poff + mat->blocks.back().pn : 0;
+  if (mat->pn_fact > mat->pn) mat->pn_fact = mat->pn;
+  LPGP_HIP(hipMemset(mat->d_status, 0, sizeof(int)));
+  mat->unchecked = 0;
+  mat->has_w = 0;
+  mat->has_r = 0;
+  return 0;
+}
+
 int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
   LPGP_CHECK(ctx && mat && b_host && nrhs >= 1, "lpgp_potrs: bad argument");
   LPGP_DEVICE(ctx);
@@ -1143,8 +1199,14 @@ int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_mat_set_residual: matrix is not factored");
   std::vector<double> hp((size_t)mat->pn);
   scatter_padded(mat, r_host, hp.data());
-  LPGP_HIP(hipMemcpyAsync(mat->r(), hp.data(), (size_t)mat->pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  // NOT on the panel stream: the residual's place in HBM is touched by no kernel of the factorisation, so the upload need
+  // not queue behind an enqueued factorisation (lpgp_potrf_enqueue); it is complete when this call returns.  The update
+  // stream of the blocked solves is idle whenever this is called (its work is joined into the panel stream at the end of
+  // every solve) -- and it is an EXISTING stream: HIP multiplexes streams over four hardware queues, and a fifth stream
+  // made two of them share one (measured: c2 predict 2.8 -> 5.6 ms).
+  hipStream_t sc = (ctx->s_upd_all && !ctx->single_stream) ? ctx->s_upd_all : ctx->s_main;
+  LPGP_HIP(hipMemcpyAsync(mat->r(), hp.data(), (size_t)mat->pn * sizeof(double), hipMemcpyHostToDevice, sc));
+  LPGP_HIP(hipStreamSynchronize(sc));
   mat->has_r = 1;
   return 0;
 }

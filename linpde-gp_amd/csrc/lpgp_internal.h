@@ -127,6 +127,7 @@ struct lpgp_ctx {
   DescSlot desc_ring[DESC_RING];
   int desc_next = 0;
   int* d_info = nullptr;           // potrf info word
+  int* d_info_cur = nullptr;       // the word the running factorisation reports to (d_info, or the matrix's own sticky word)
   int* h_info_pinned = nullptr;    // pinned mirror (multi-GPU: a device-to-host copy into pageable memory would BLOCK behind a collective that waits for a dead peer)
   double* d_tmp = nullptr;         // small scratch (vectors)
   int64_t tmp_cap = 0;
@@ -216,6 +217,8 @@ struct lpgp_mat {
   int64_t pn_fact_all = 0;         // the same over view + hidden blocks (meaningful while hidden is non-empty)
   int has_w;
   int has_r;                       // residual resident (lpgp_mat_set_residual)
+  int* d_status = nullptr;         // device word: first non-positive pivot of the factorisations enqueued since the last lpgp_mat_check (sticky)
+  int unchecked = 0;               // a factorisation was enqueued (lpgp_potrf_enqueue) and its status not read yet
   double* r() const { return w + cap; }
 };
 

@@ -314,8 +314,7 @@ int debug_tile_xcc(int32_t* out8, int reset) {
 
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base) {
-  size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
-  if (const char* e = std::getenv("LPGP_EXPERIMENT_POTRF_LDS")) shmem = (size_t)std::atol(e);     // TIMING EXPERIMENT ONLY (wrong results)
+  const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&potrf_tile_kernel), shmem));
   prof_begin(ctx, stream, LPGP_K_POTRF_TILE, (double)TILE * TILE * TILE / 3.0, 0.0);
   hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE_WAVES * 64), shmem, stream, a, lda, linv, d_info, info_base);
@@ -379,7 +378,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     for (int jt = p0; jt < p1; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
       double* linv = mat->linv + (int64_t)jt * tb * tb;
-      LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info, jt * TILE));
+      LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info_cur, jt * TILE));
       if (jt + 1 < T) {
         double* X = dj + tb;     // rows below, same tile column
         LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, T - jt - 1));
@@ -462,7 +461,10 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   const int nbt = (int)(ctx->nb / TILE);
   const int64_t tb = TILE;
   hipStream_t sP = ctx->s_main, sU = ctx->s_upd;
-  LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
+  // info != nullptr: the status is read back at the end (one host synchronisation); nullptr (lpgp_potrf_enqueue): it
+  // accumulates in the matrix's own sticky word and is read by lpgp_mat_check
+  ctx->d_info_cur = info ? ctx->d_info : mat->d_status;
+  if (info) LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
 
   // ---- phase A (append): push the new rows through the already factored columns ----
   if (t_done > 0 && T > t_done) {
@@ -559,11 +561,11 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   }
   if (ev_a1) LPGP_HIP(hipStreamWaitEvent(sP, ev_a1, 0));
   if (ev_b) LPGP_HIP(hipStreamWaitEvent(sP, ev_b, 0));
+  if (!info) return 0;
   int h_info = 0;
   LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
-  if (std::getenv("LPGP_EXPERIMENT_POTRF_LDS")) h_info = 0;
-  if (info) *info = h_info;
+  *info = h_info;
   return 0;
 }
 

@@ -395,6 +395,22 @@ class GramMatrix:
         check(lib.lpgp_potrf(self.ctx._h, self._h, C.byref(info)), "lpgp_potrf")
         return info.value
 
+    def potrf_enqueue(self) -> None:
+        """The factorisation enqueued, no host synchronisation (`lpgp_potrf_enqueue`): its status is read by `check`."""
+        check(lib.lpgp_potrf_enqueue(self.ctx._h, self._h), "lpgp_potrf_enqueue")
+
+    def check(self):
+        """(info, block): status of everything enqueued since the last check (waits for the device); info = 0: fine;
+        k > 0: the k-th leading minor of the padded matrix is not positive definite, in observation block `block`."""
+        info, block = C.c_int32(), C.c_int32()
+        check(lib.lpgp_mat_check(self.ctx._h, self._h, C.byref(info), C.byref(block)), "lpgp_mat_check")
+        return info.value, block.value
+
+    def truncate(self, nblocks: int) -> None:
+        """Drop the blocks from `nblocks` on (rollback of failed conditionings found by `check`)."""
+        check(lib.lpgp_mat_truncate(self.ctx._h, self._h, int(nblocks)), "lpgp_mat_truncate")
+        del self.block_sizes[int(nblocks):]
+
     def potrs(self, B: np.ndarray) -> np.ndarray:
         """Solve G X = B for B of shape (n,) or (n, nrhs)."""
         B = np.asarray(B, dtype=np.double)

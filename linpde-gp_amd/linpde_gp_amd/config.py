@@ -10,3 +10,14 @@ gram_capacity_hint: int = 0
 # `Box.uniform_grid`) are assembled as sums of Kronecker products of 1-D kernel matrices
 # (`lpgp_gram_assemble_grid`); False forces the generic per-entry evaluation.
 use_grid_assembly: bool = True
+
+# When a Gram matrix that is not positive definite is reported.
+# True (default): as in the reference, whose Cholesky factor is a `functools.cached_property` evaluated at first use
+# (`_conditional.py:92`, `linops/_block.py:203`) -- `condition_on_observations` enqueues assembly and factorisation and
+# returns; `np.linalg.LinAlgError` is raised by the first call that needs the factor (`predict`, `mean`, `cov`,
+# `representer_weights`, `gram.cholesky()` ...), on the object whose block failed and on every object conditioned on it;
+# the objects before it stay usable (their part of the factor is untouched, the failed blocks are dropped).  The host
+# runs ahead of the device over a chain of conditionings instead of waiting for a status word after each.
+# False: the status is read back inside `condition_on_observations`, which then raises itself (rounds 1-3).
+# Multi-GPU jobs always check inside `condition_on_observations` (the ranks agree on the status collectively).
+lazy_factorization: bool = True

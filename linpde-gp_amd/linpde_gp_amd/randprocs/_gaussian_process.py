@@ -220,7 +220,7 @@ class _DeviceState:
     view (`lpgp_mat_set_view`), so earlier objects of the chain stay usable; conditioning an object
     that has already been extended (branching) continues on a copy of its part of the factor."""
 
-    def __init__(self, ctx, mat=None):
+    def __init__(self, ctx, mat=None, blocks=()):
         from .. import config
 
         self.ctx = ctx
@@ -228,6 +228,9 @@ class _DeviceState:
         self.view = None             # number of blocks the device-resident weights / residual belong to
         self.weights_key = None
         self.residual_key = None
+        self.blocks = list(blocks)   # the observation blocks in the matrix, in order (identity decides whether an object is alive)
+        self.pending = False         # factorisations enqueued whose status has not been read (config.lazy_factorization)
+        self.failure = None          # message of the last failure found by `verify`
 
     def invalidate(self) -> None:
         """The device dropped the resident representer weights / residual (`lpgp_mat_add_block`, `lpgp_mat_pop_block`
@@ -235,6 +238,27 @@ class _DeviceState:
         self.view = None
         self.weights_key = None
         self.residual_key = None
+
+    def verify(self) -> None:
+        """Read the status of the enqueued factorisations (one host synchronisation, at the first use of the factor).
+        A block that was not positive definite is dropped together with everything appended after it -- the leading
+        part of the factor is untouched by an append -- and the objects that own those blocks raise from now on."""
+        if not self.pending:
+            return
+        self.pending = False
+        info, block = self.mat.check()
+        if info == 0:
+            return
+        self.failure = f"{info}-th leading minor of the (padded) Gram matrix is not positive definite"
+        self.mat.set_view(-1)
+        self.mat.truncate(block)
+        del self.blocks[block:]
+        self.invalidate()
+
+    def owns(self, blocks) -> bool:
+        """Are `blocks` (an object's) still the leading blocks of this matrix?"""
+        n = len(blocks)
+        return n <= len(self.blocks) and (n == 0 or self.blocks[n - 1] is blocks[n - 1])
 
     def use(self, nblocks: int) -> None:
         """Make the leading `nblocks` blocks the matrix every following call sees."""
@@ -258,14 +282,24 @@ class ConditionalGaussianProcess(GaussianProcess):
 
     @classmethod
     def _extend(cls, prior, state, old_blocks, new_block):
+        from .. import config
+
         if new_block.points.n == 0:
             # no observations: nothing to assemble or factor, the factor in HBM stays as it is (and
             # stays valid for the object this one was derived from)
             return cls(prior=prior, blocks=tuple(old_blocks), state=state, representer_weights=None)
-        if state.mat.num_blocks_total != len(old_blocks):
+        lazy = bool(config.lazy_factorization) and state.ctx.world == 1
+        if not state.pending and not state.owns(old_blocks):
+            # the object being conditioned is known to rest on a block that was not positive definite
+            raise np.linalg.LinAlgError(state.failure or "the Gram matrix of this posterior is not positive definite")
+        if len(state.blocks) != len(old_blocks):
             # the object being conditioned has already been extended by another conditioning: this one
             # branches off on its own copy of the leading part of the factor (multi-GPU: not supported)
-            state = _DeviceState(state.ctx, state.mat.clone(len(old_blocks)))
+            state.verify()
+            if not state.owns(old_blocks):
+                raise np.linalg.LinAlgError(state.failure)
+            if len(state.blocks) != len(old_blocks):
+                state = _DeviceState(state.ctx, state.mat.clone(len(old_blocks)), old_blocks)
         state.use(len(old_blocks))
         mat = state.mat
         base = prior.cov
@@ -273,7 +307,7 @@ class ConditionalGaussianProcess(GaussianProcess):
         state.invalidate()           # also on the rollback paths below: the parent's next predict must solve again
         assert bi == len(old_blocks)
         try:
-            info = cls._assemble_and_factor(mat, base, bi, old_blocks, new_block)
+            info = cls._assemble_and_factor(mat, base, bi, old_blocks, new_block, lazy)
         except BaseException:
             # a failed conditioning leaves the object it was called on intact (as in the reference):
             # drop the block again; the leading factor was never touched
@@ -286,13 +320,15 @@ class ConditionalGaussianProcess(GaussianProcess):
             mat.pop_block()
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
+        state.blocks.append(new_block)
+        state.pending = state.pending or lazy
         blocks = tuple(old_blocks) + (new_block,)
         # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
         # in a chain of conditionings only the last object's weights are ever needed
         return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)
 
     @staticmethod
-    def _assemble_and_factor(mat, base, bi, old_blocks, new_block) -> int:
+    def _assemble_and_factor(mat, base, bi, old_blocks, new_block, lazy=False) -> int:
         # lower-left blocks  (L_new k L_j'^*)(X_new, X_j)   (`_conditional.py:270`)
         for bj, ob in enumerate(old_blocks):
             mat.assemble(_lowered(base, new_block.coeffs, ob.coeffs), new_block.points, ob.points, bi, bj)
@@ -308,6 +344,9 @@ class ConditionalGaussianProcess(GaussianProcess):
                     mat.add_dense(bi, cov)
                 else:
                     mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
+        if lazy:
+            mat.potrf_enqueue()          # status: `_DeviceState.verify`, at the first use of the factor
+            return 0
         return mat.potrf()
 
     def __init__(self, *, prior, blocks, state, representer_weights, test_coeffs=None):
@@ -370,7 +409,8 @@ class ConditionalGaussianProcess(GaussianProcess):
         """Mean AND variance need no weights: `K_xX G^{-1} r = V^T (L^{-1} r)` with the solved
         cross-covariance `V = L^{-1} K_Xx` the variance computes anyway; the library only needs
         the residual (its forward substitution hides under the solve for `V`)."""
-        self._check_current()
+        if not (self._state.pending and self._state.owns(self._blocks) and self._state.view == len(self._blocks)):
+            self._check_current()        # (not from a speculative `predict`: see `_use_unverified`)
         if self._state.residual_key != len(self._blocks):
             self._state.mat.set_residual(self._residual())
             self._state.residual_key = len(self._blocks)
@@ -382,8 +422,31 @@ class ConditionalGaussianProcess(GaussianProcess):
     def _check_current(self):
         """Point the shared device matrix at THIS object's blocks.  A later `condition_on_observations`
         appended to the same matrix without touching its leading part, so an earlier posterior keeps
-        working (the reference's posteriors are immutable values)."""
+        working (the reference's posteriors are immutable values).  First use of the factor: the status of the
+        factorisations enqueued so far is read here (`config.lazy_factorization`), and an object whose own block -- or a
+        block it was conditioned on -- was not positive definite raises, as the reference's lazily evaluated Cholesky
+        factor does (`_conditional.py:92`)."""
+        self._state.verify()
+        if not self._state.owns(self._blocks):
+            raise np.linalg.LinAlgError(self._state.failure or "the Gram matrix of this posterior is not positive definite")
         self._state.use(len(self._blocks))
+
+    def _use_unverified(self) -> bool:
+        """`predict` with factorisations still in flight: enqueue the whole prediction behind them FIRST and read their
+        status afterwards (`_verify_after`) -- the device then goes from the last panel of the factorisation straight into
+        the cross-covariance and the forward substitution, with no host round trip in between.  A factor that turns out not
+        to be positive definite costs a prediction computed on garbage, which is discarded.  False: nothing is pending (or
+        this object is already known to be dead): the ordinary order applies."""
+        st = self._state
+        if not st.pending or not st.owns(self._blocks):
+            return False
+        st.use(len(self._blocks))
+        return True
+
+    def _verify_after(self):
+        self._state.verify()
+        if not self._state.owns(self._blocks):
+            raise np.linalg.LinAlgError(self._state.failure or "the Gram matrix of this posterior is not positive definite")
 
     def condition_on_observations(self, Y, X=None, *, L=None, b=None):
         if any(v != 1.0 or any(mi) for mi, v in self._test_coeffs.items()):
@@ -464,10 +527,14 @@ class ConditionalGaussianProcess(GaussianProcess):
         solves for its own columns of the cross-covariance while the sharded factor is streamed past it panel by
         panel (`trsm_lower_dist`), and the results are gathered over the control plane; every rank returns the
         full arrays.  Collective: every rank calls it with the same `x`."""
-        self._check_current()
+        speculative = self._use_unverified()
+        if not speculative:
+            self._check_current()
         X, batch = self._flat(x)
         ctx = self._state.ctx
         if X.shape[0] == 0 or not self._blocks:
+            if speculative:
+                self._verify_after()
             # nothing to predict, or nothing observed yet: the prior (`x1 is None` diagonal)
             mean = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0]).reshape(batch)
             if not return_var:
@@ -482,14 +549,17 @@ class ConditionalGaussianProcess(GaussianProcess):
             if not return_var:
                 return mean
             return mean, np.concatenate([p[1] for p in parts]).reshape(batch)
-        mean, var = self._predict_local(x, X, return_var)
+        mean, var = self._predict_local(x, X, return_var, speculative)
+        if speculative:
+            self._verify_after()
         mean = mean.reshape(batch)
         return (mean, var.reshape(batch)) if return_var else mean
 
-    def _predict_local(self, x_original, X, return_var):
-        # the cross-covariance launches first: the device assembles it while the host stages the residual (a synchronous
-        # 135-KB upload at c3) or the weights are solved for
-        self._check_current()
+    def _predict_local(self, x_original, X, return_var, speculative=False):
+        # the cross-covariance launches first: the device assembles it while the host stages the residual (a 135-KB upload
+        # at c3, on the copy stream) or the weights are solved for
+        if not speculative:
+            self._check_current()
         pts = _engine.as_points(self._state.ctx, x_original, X)
         rhs = self._cross(pts)
         if return_var and self._representer_weights is None:

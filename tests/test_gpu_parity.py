@@ -431,12 +431,73 @@ def test_potrs_multiple_rhs_and_dense_noise(lp):
         g @ np.zeros(7)
 
 
-def test_not_positive_definite_raises(lp):
+@pytest.fixture(params=["lazy", "eager"])
+def factorization_check(lp, request):
+    """`lp.config.lazy_factorization`: True (default, the reference's order of events: the Cholesky factor is evaluated --
+    and a Gram matrix that is not positive definite reported -- at first use, `_conditional.py:92`) / False (the status is
+    read back inside `condition_on_observations`, which raises itself)."""
+    saved = lp.config.lazy_factorization
+    lp.config.lazy_factorization = request.param == "lazy"
+    yield request.param
+    lp.config.lazy_factorization = saved
+
+
+def _condition_expecting_failure(lazy, parent, *args, **kwargs):
+    """A conditioning whose Gram matrix is not positive definite: eager -> `condition_on_observations` raises; lazy -> it
+    returns an object whose first use raises (and keeps raising)."""
+    if not lazy:
+        with pytest.raises(np.linalg.LinAlgError):
+            parent.condition_on_observations(*args, **kwargs)
+        return None
+    child = parent.condition_on_observations(*args, **kwargs)
+    with pytest.raises(np.linalg.LinAlgError):
+        child.predict(np.array([[0.1], [0.2]]))
+    with pytest.raises(np.linalg.LinAlgError):
+        child.representer_weights
+    with pytest.raises(np.linalg.LinAlgError):
+        child.condition_on_observations(np.zeros(1), np.array([[0.77]]))          # known dead: raises at once
+    return child
+
+
+def test_not_positive_definite_raises(lp, factorization_check):
     cf = lp.randprocs.covfuncs
     prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
     X = np.array([[0.0], [0.0], [0.5]])             # duplicated point, no noise => singular Gram
+    _condition_expecting_failure(factorization_check == "lazy", prior, np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+
+
+def test_lazy_failure_in_the_middle_of_a_chain(lp):
+    """Lazy status (default): a block that is not positive definite in the MIDDLE of a chain of conditionings.  Nothing
+    raises while the chain is built (the host runs ahead of the device); the first use of any object from the failed
+    block on raises `LinAlgError`, the objects before it stay exact, and the chain can be continued from them."""
+    assert lp.config.lazy_factorization is True
+    cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 1.0)])]
+    ident = ocf.identity(1)
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    rng = np.random.default_rng(5)
+    X1, Y1 = rng.uniform(-1, 1, (140, 1)), rng.normal(size=140)
+    noise = lp.randvars.Normal(np.zeros(140), 1e-2 * np.eye(140))
+    Xbad = np.array([[0.2], [0.2], [0.5]])
+    X3, Y3 = np.array([[0.31], [-0.62]]), np.array([0.1, 0.2])
+    u1 = prior.condition_on_observations(Y1, X1, b=noise)
+    u2 = u1.condition_on_observations(np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))     # not PD
+    u3 = u2.condition_on_observations(Y3, X3)                                                                      # built on it
+    Xt = np.linspace(-1, 1, 7)[:, None]
     with pytest.raises(np.linalg.LinAlgError):
-        prior.condition_on_observations(np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+        u3.predict(Xt)
+    with pytest.raises(np.linalg.LinAlgError):
+        u2.mean(Xt)
+    post1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
+    m1, v1 = u1.predict(Xt)
+    assert _rel(m1, post1.mean(Xt)) < 1e-8 and np.max(np.abs(v1 - post1.var(Xt))) < 1e-9
+    u4 = u1.condition_on_observations(Y3, X3)
+    post4 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2), ogp.ObsBlock(X3, ident, Y3)])
+    m4, v4 = u4.predict(Xt)
+    assert _rel(m4, post4.mean(Xt)) < 1e-8 and np.max(np.abs(v4 - post4.var(Xt))) < 1e-9
+    with pytest.raises(np.linalg.LinAlgError):
+        u3.predict(Xt)                               # still dead: its blocks are not the ones in the matrix
+    np.testing.assert_allclose(u1.representer_weights, post1.weights, rtol=1e-7, atol=1e-9)
 
 
 def test_earlier_posteriors_stay_usable_and_branching(lp):
@@ -474,7 +535,7 @@ def test_earlier_posteriors_stay_usable_and_branching(lp):
     assert u1.gram.shape == (2, 2) and u2.gram.shape == (4, 4) and u3.gram.shape == (5, 5)
 
 
-def test_failed_conditioning_leaves_the_parent_intact(lp):
+def test_failed_conditioning_leaves_the_parent_intact(lp, factorization_check):
     """a failed `condition_on_observations` (Gram not positive definite) must not corrupt the
     device state it shares with the object it was called on (the new block is rolled back)."""
     cf = lp.randprocs.covfuncs
@@ -493,8 +554,7 @@ def test_failed_conditioning_leaves_the_parent_intact(lp):
     assert _rel(m0, post1.mean(Xt)) < 1e-8
     assert _rel(u1.mean(Xt), post1.mean(Xt)) < 1e-8
     Xbad = np.array([[0.2], [0.2], [0.5]])           # duplicated point and negative noise: not PD
-    with pytest.raises(np.linalg.LinAlgError):
-        u1.condition_on_observations(np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+    _condition_expecting_failure(factorization_check == "lazy", u1, np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
     with pytest.raises(ValueError):                 # host-side validation error: nothing reached the device
         u1.condition_on_observations(np.zeros(4), Xbad)
     m, v = u1.predict(Xt)
