@@ -95,9 +95,10 @@ int  lpgp_dist_grid(lpgp_ctx* ctx, int32_t* pr, int32_t* pc);
 int  lpgp_dist_stats(lpgp_ctx* ctx, double* bytes_sent, double* bytes_received, int32_t reset);
 /* Link probe: what the panel exchanges can expect from the fabric, measured through the calls they use (RCCL
  * ncclSend / ncclRecv groups, or device-to-device copies into IPC-mapped windows) with HIP events on the panel stream.
- * out: world*world + world + 1 doubles in GB/s (0 = not measured on this rank): [s*world + d] the ordered pair s -> d
+ * out: world*world + world + 2 doubles, rates in GB/s (0 = not measured on this rank): [s*world + d] the ordered pair s -> d
  * alone; [world*world + s] one link of s while s sends to every peer at once; [world*world + world] total inbound rate
- * of this rank while every rank sends to every peer at once (the pattern of a Pr x 1 panel gather).  Collective.  The
+ * of this rank while every rank sends to every peer at once (the pattern of a Pr x 1 panel gather); [world*world + world + 1]
+ * the bytes per message actually moved (the receive window of the direct-peer transport may cap `bytes`).  Collective.  The
  * reference has no counterpart (single process, host BLAS); it exists so that ONE run on an 8-GPU node can be held
  * against the communication model of DESIGN.md section 7 (bench.py: config.link_probe).                        */
 int  lpgp_dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out);

@@ -405,6 +405,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_ASM_CT")) ctx->asm_ct = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_DIST_SCOPED_GATHER")) ctx->scoped_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_CHAIN_US_COMM")) ctx->dist_chain_us_comm = std::atof(e);
   if (const char* e = std::getenv("LPGP_GEMM_BAND")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ctx->gemm_band = v; }
   if (const char* e = std::getenv("LPGP_NB_BIG")) {
@@ -495,6 +496,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "gemm3_fact") == 0) *value = ctx->gemm3_fact;
   else if (std::strcmp(key, "dist_bcast") == 0) *value = ctx->dist_bcast;
   else if (std::strcmp(key, "split_gather") == 0) *value = ctx->split_gather;
+  else if (std::strcmp(key, "scoped_gather") == 0) *value = ctx->scoped_gather;
   else if (std::strcmp(key, "lookahead") == 0) *value = ctx->lookahead;
   else if (std::strcmp(key, "fused_solve") == 0) *value = ctx->fused_solve;
   else if (std::strcmp(key, "small_tiles_max") == 0) *value = ctx->small_tiles_max;
@@ -531,6 +533,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->dist_bcast = value != 0;           // (the same on every rank)
   } else if (std::strcmp(key, "split_gather") == 0) {
     ctx->split_gather = value != 0;
+  } else if (std::strcmp(key, "scoped_gather") == 0) {
+    ctx->scoped_gather = value != 0;          // (the same on every rank)
   } else if (std::strcmp(key, "asm_factors") == 0) {
     ctx->asm_factors = value != 0;
   } else if (std::strcmp(key, "asm_fast") == 0) {

@@ -85,10 +85,13 @@ __device__ __forceinline__ void stage_factors(const DevDesc* __restrict__ desc, 
   }
 }
 
-template <int D>
+// FACTORS: the per-point exponential factors (`asm_factors`, off by default) need 2 x LPGP_MAXG * D * 2 * 64 doubles of LDS (32 KB
+// at D = 4); the default instantiation carries the 4-KB exponential table only (the generic kernel is the one that
+// takes everything the specialised kernels reject -- D >= 3, several groups, isotropic -- and ran at 4 / 3 workgroups per CU)
+template <int D, bool FACTORS>
 __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
   __shared__ double sx1[D][AT];
-  __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
+  __shared__ double sfr[FACTORS ? LPGP_MAXG * D * 2 * AT : 1], sfc[FACTORS ? LPGP_MAXG * D * 2 * AT : 1];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];      // table of lpgp_exp_neg (eval_entries.h)
   __shared__ int s_fast;
   const int tr = blockIdx.x % a.tiles_r;   // row tile fastest: consecutive blocks write neighbouring rows
@@ -114,17 +117,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict
 #pragma unroll
     for (int j = 0; j < D; ++j) sx1[j][threadIdx.x] = xc[j];
   }
-  if (threadIdx.x == 0) s_fast = a.flags & 1;
+  if (threadIdx.x == 0) s_fast = FACTORS ? (a.flags & 1) : 0;
   s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];         // (256 threads, 256 entries)
   const ExpTab etab{s_exp};
   __syncthreads();
-  if (a.flags & 1) {
+  if (FACTORS && (a.flags & 1)) {
     // waves 0,1: row factors; waves 2,3: column factors
     if (wu < 2) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 2, &s_fast);
     else stage_factors<D>(desc, xc, x0, col < a.n1, sfc, lane, wu - 2, 2, &s_fast);
     __syncthreads();
   }
-  const bool fast = s_fast != 0;
+  const bool fast = FACTORS && s_fast != 0;
   double sink = 0.0;
 #pragma unroll 1
   for (int pass = 0; pass < 16 / AEK; ++pass) {
@@ -478,7 +481,6 @@ static int stage_desc(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_des
   }
   const size_t bytes = offsetof(DevDesc, coef) + (size_t)ncoef * sizeof(double);
   std::memcpy(slot.h, &host_desc, bytes);
-  slot.h->ncoef = ncoef;
   LPGP_HIP(hipMemcpyAsync(slot.d, slot.h, bytes, hipMemcpyHostToDevice, stream));
   *out = &slot;
   return 0;
@@ -527,10 +529,10 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   const DevDesc* d_desc = slot.d;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
   switch (host_desc.d) {
-    case 1: hipLaunchKernelGGL(assemble_kernel<1>, grid, dim3(256), 0, stream, d_desc, a); break;
-    case 2: hipLaunchKernelGGL(assemble_kernel<2>, grid, dim3(256), 0, stream, d_desc, a); break;
-    case 3: hipLaunchKernelGGL(assemble_kernel<3>, grid, dim3(256), 0, stream, d_desc, a); break;
-    case 4: hipLaunchKernelGGL(assemble_kernel<4>, grid, dim3(256), 0, stream, d_desc, a); break;
+    case 1: if (a.flags & 1) hipLaunchKernelGGL((assemble_kernel<1, true>), grid, dim3(256), 0, stream, d_desc, a); else hipLaunchKernelGGL((assemble_kernel<1, false>), grid, dim3(256), 0, stream, d_desc, a); break;
+    case 2: if (a.flags & 1) hipLaunchKernelGGL((assemble_kernel<2, true>), grid, dim3(256), 0, stream, d_desc, a); else hipLaunchKernelGGL((assemble_kernel<2, false>), grid, dim3(256), 0, stream, d_desc, a); break;
+    case 3: if (a.flags & 1) hipLaunchKernelGGL((assemble_kernel<3, true>), grid, dim3(256), 0, stream, d_desc, a); else hipLaunchKernelGGL((assemble_kernel<3, false>), grid, dim3(256), 0, stream, d_desc, a); break;
+    case 4: if (a.flags & 1) hipLaunchKernelGGL((assemble_kernel<4, true>), grid, dim3(256), 0, stream, d_desc, a); else hipLaunchKernelGGL((assemble_kernel<4, false>), grid, dim3(256), 0, stream, d_desc, a); break;
     default: LPGP_CHECK(false, "assemble: d=%d", host_desc.d);
   }
   prof_end(ctx, stream);
@@ -550,7 +552,7 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
 // slab of each 64-column tile, up to MV_R right-hand sides ride along per evaluation.
 // Partial sums per split go to `part`; mv_reduce_kernel adds them in a fixed order.
 // ---------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool FACTORS>
 __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__ desc, MvArgs a) {
   __shared__ double sx1[D][AT];
   __shared__ double sv[MV_R][AT];
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   // per-point exponential factors (see assemble_kernel): origin = the first row of this workgroup's row tile; the row
   // factors are computed once, the column factors per column tile, and a tile whose points lie more than FACT_TMAX scaled
   // units from the origin falls back to one exp per entry
-  __shared__ double sfr[LPGP_MAXG * D * 2 * AT], sfc[LPGP_MAXG * D * 2 * AT];
+  __shared__ double sfr[FACTORS ? LPGP_MAXG * D * 2 * AT : 1], sfc[FACTORS ? LPGP_MAXG * D * 2 * AT : 1];
   __shared__ int s_fast_r, s_fast_c[2];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
   const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
@@ -576,11 +578,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   for (int r = 0; r < MV_R; ++r) y[r] = 0.0;
   const int per = (a.tiles_c + a.splits - 1) / a.splits;
   const int tc_end = (sp + 1) * per < a.tiles_c ? (sp + 1) * per : a.tiles_c;
-  if (threadIdx.x == 0) { s_fast_r = a.factors; s_fast_c[0] = 1; s_fast_c[1] = 1; }
+  if (threadIdx.x == 0) { s_fast_r = FACTORS ? a.factors : 0; s_fast_c[0] = 1; s_fast_c[1] = 1; }
   s_exp[threadIdx.x] = g_exp_table[threadIdx.x], s_exp[threadIdx.x + 256] = g_exp_table[threadIdx.x + 256];
   const ExpTab etab{s_exp};
   __syncthreads();
-  if (a.factors) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
+  if (FACTORS && a.factors) stage_factors<D>(desc, xr, x0, row < a.n0, sfr, lane, wu, 4, &s_fast_r);
 
   for (int tc = sp * per; tc < tc_end; ++tc) {
     __syncthreads();                                   // previous tile consumed (first tile: flags initialised)
@@ -591,11 +593,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
       double xc[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) xc[j] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-      if (a.factors) stage_factors<D>(desc, xc, x0, c < a.n1, sfc, lane, wu, 4, &s_fast_c[tc & 1]);
+      if (FACTORS && a.factors) stage_factors<D>(desc, xc, x0, c < a.n1, sfc, lane, wu, 4, &s_fast_c[tc & 1]);
       if (threadIdx.x == 0) s_fast_c[(tc + 1) & 1] = 1;       // the next tile's flag (read two barriers from now)
     }
     __syncthreads();
-    const bool fast = s_fast_r != 0 && s_fast_c[tc & 1] != 0;
+    const bool fast = FACTORS && s_fast_r != 0 && s_fast_c[tc & 1] != 0;
 #pragma unroll 1
     for (int pass = 0; pass < 16 / AEK; ++pass) {
       const int cb = w * 16 + pass * AEK;
@@ -671,10 +673,10 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   if (rc != 0) return rc;
   prof_begin(ctx, stream, LPGP_K_MATVEC, 2.0 * (double)n0 * (double)n1 * nr, 0.0);
   switch (host_desc.d) {
-    case 1: hipLaunchKernelGGL(matvec_kernel<1>, grid, dim3(256), 0, stream, slot->d, a); break;
-    case 2: hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, stream, slot->d, a); break;
-    case 3: hipLaunchKernelGGL(matvec_kernel<3>, grid, dim3(256), 0, stream, slot->d, a); break;
-    case 4: hipLaunchKernelGGL(matvec_kernel<4>, grid, dim3(256), 0, stream, slot->d, a); break;
+    case 1: if (a.factors) hipLaunchKernelGGL((matvec_kernel<1, true>), grid, dim3(256), 0, stream, slot->d, a); else hipLaunchKernelGGL((matvec_kernel<1, false>), grid, dim3(256), 0, stream, slot->d, a); break;
+    case 2: if (a.factors) hipLaunchKernelGGL((matvec_kernel<2, true>), grid, dim3(256), 0, stream, slot->d, a); else hipLaunchKernelGGL((matvec_kernel<2, false>), grid, dim3(256), 0, stream, slot->d, a); break;
+    case 3: if (a.factors) hipLaunchKernelGGL((matvec_kernel<3, true>), grid, dim3(256), 0, stream, slot->d, a); else hipLaunchKernelGGL((matvec_kernel<3, false>), grid, dim3(256), 0, stream, slot->d, a); break;
+    case 4: if (a.factors) hipLaunchKernelGGL((matvec_kernel<4, true>), grid, dim3(256), 0, stream, slot->d, a); else hipLaunchKernelGGL((matvec_kernel<4, false>), grid, dim3(256), 0, stream, slot->d, a); break;
     default: LPGP_CHECK(false, "matvec: d=%d", host_desc.d);
   }
   prof_end(ctx, stream);

@@ -132,8 +132,10 @@ static inline GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t
 // ---- broadcast of a set of device buffers, each from its own root to every rank ---------------------------------
 struct Piece {
   int root;
-  double* buf;           // source on the root, destination everywhere else
+  double* buf;           // source on the root, destination on every rank of `dst`
   size_t count;          // doubles
+  uint64_t dst = ~0ull;  // ranks that receive the piece (bit r = rank r; the root's own bit is ignored).  Default: everyone.
+  bool to(int rank) const { return (dst >> rank) & 1ull; }
 };
 
 static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>& pieces, bool bulk = false) {
@@ -141,8 +143,12 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
   double sent = 0.0, recv = 0.0;
   for (const auto& p : pieces) {
     if (p.count == 0) continue;
-    if (p.root == ctx->rank) sent += 8.0 * (double)p.count * (ctx->world - 1);
-    else recv += 8.0 * (double)p.count;
+    if (p.root == ctx->rank) {
+      for (int peer = 0; peer < ctx->world; ++peer)
+        if (peer != ctx->rank && p.to(peer)) sent += 8.0 * (double)p.count;
+    } else if (p.to(ctx->rank)) {
+      recv += 8.0 * (double)p.count;
+    }
   }
   ctx->comm_bytes_sent += sent;
   ctx->comm_bytes_recv += recv;
@@ -187,12 +193,12 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
           LPGP_TRY(barrier());
           if (p.root == ctx->rank) {
             for (int peer = 0; peer < ctx->world; ++peer)
-              if (peer != ctx->rank)
+              if (peer != ctx->rank && p.to(peer))
                 LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer], p.buf + o, n * sizeof(double), hipMemcpyDeviceToDevice, st));
             LPGP_HIP(hipStreamSynchronize(st));
           }
           LPGP_TRY(barrier());
-          if (p.root != ctx->rank)
+          if (p.root != ctx->rank && p.to(ctx->rank))
             LPGP_HIP(hipMemcpyAsync(p.buf + o, ctx->ipc_window, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         ++i;
@@ -205,7 +211,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
         const Piece& p = pieces[q];
         if (p.count == 0 || p.root != ctx->rank) continue;
         for (int peer = 0; peer < ctx->world; ++peer)
-          if (peer != ctx->rank)
+          if (peer != ctx->rank && p.to(peer))
             LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer] + offs[q - i], p.buf, p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
         pushed = true;
       }
@@ -213,7 +219,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       LPGP_TRY(barrier());
       for (size_t q = i; q < j; ++q) {
         const Piece& p = pieces[q];
-        if (p.count == 0 || p.root == ctx->rank) continue;
+        if (p.count == 0 || p.root == ctx->rank || !p.to(ctx->rank)) continue;
         LPGP_HIP(hipMemcpyAsync(p.buf, ctx->ipc_window + offs[q - i], p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
       }
       i = j;
@@ -228,7 +234,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       LPGP_HIP(hipStreamSynchronize(st));
       LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 0, stage.data(), (int64_t)(p.count * sizeof(double)), p.root) == 0,
                  "host exchange: broadcast from rank %d failed", p.root);
-      if (p.root != ctx->rank) {
+      if (p.root != ctx->rank && p.to(ctx->rank)) {        // (the caller's exchange is a broadcast; a rank outside `dst` drops it)
         LPGP_HIP(hipMemcpyAsync(p.buf, stage.data(), p.count * sizeof(double), hipMemcpyHostToDevice, st));
         LPGP_HIP(hipStreamSynchronize(st));
       }
@@ -247,8 +253,8 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
         LPGP_NCCL(ncclBroadcast(p.buf, p.buf, p.count, ncclDouble, p.root, comm, st));
       } else if (p.root == ctx->rank) {
         for (int peer = 0; peer < ctx->world; ++peer)
-          if (peer != ctx->rank) LPGP_NCCL(ncclSend(p.buf, p.count, ncclDouble, peer, comm, st));
-      } else {
+          if (peer != ctx->rank && p.to(peer)) LPGP_NCCL(ncclSend(p.buf, p.count, ncclDouble, peer, comm, st));
+      } else if (p.to(ctx->rank)) {
         LPGP_NCCL(ncclRecv(p.buf, p.count, ncclDouble, p.root, comm, st));
       }
     }
@@ -331,14 +337,16 @@ int dist_warm_up(lpgp_ctx* ctx) {
 //   out[s*W + d]   s -> d alone                     (RCCL: measured by the receiver d; IPC: by the sender s)
 //   out[W*W + s]   s -> every peer at once: rate of ONE of its links (RCCL: inbound at this rank; IPC: at the sender, per peer)
 //   out[W*W + W]   every rank -> every peer at once: total inbound rate of this rank (the pattern of a P x 1 panel gather)
+//   out[W*W + W + 1]  bytes per message actually transferred
 // Collective; every rank passes the same bytes / reps.  bench.py gathers the rows and prints the matrix (config.link_probe).
 int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
   const int W = ctx->world, me = ctx->rank;
-  for (int i = 0; i < W * W + W + 1; ++i) out[i] = 0.0;
+  for (int i = 0; i < W * W + W + 2; ++i) out[i] = 0.0;
   if (W <= 1 || (ctx->host_xfer && !ctx->ipc())) return 0;       // host-staged bring-up transport: nothing to measure
   hipStream_t st = ctx->s_main;
   size_t count = (size_t)bytes / sizeof(double);
   if (ctx->ipc()) count = std::min(count, ctx->ipc_window_doubles / (size_t)W);
+  out[W * W + W + 1] = (double)(count * sizeof(double));      // bytes per message actually moved (the IPC window may cap the request)
   void *ps = nullptr, *pr = nullptr;
   const size_t sb = count * sizeof(double), rb = sb * (size_t)(W - 1);
   if (pool_alloc(ctx, &ps, sb, nullptr) != 0) return -1;
@@ -362,14 +370,25 @@ int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
     for (int s_ = 0; s_ < W && !involved; ++s_)
       for (int d_ = 0; d_ < W; ++d_)
         if (s_ != d_ && sends(s_, d_) && (s_ == me || d_ == me)) { involved = true; break; }
+    double ipc_ms = 0.0;
     for (int r = 0; r <= reps; ++r) {          // r == 0: untimed (connection set-up, both ends in step)
-      if (r == 1 && involved) LPGP_HIP(hipEventRecord(e0, st));
+      if (r == 1 && involved && !ctx->ipc()) LPGP_HIP(hipEventRecord(e0, st));
       if (ctx->ipc()) {
+        // direct-peer transport: the barrier between repetitions (a control-plane round trip) stays OUTSIDE the timed
+        // interval -- only the copies are timed, repetition by repetition (the rates used to include it)
         LPGP_HIP(hipStreamSynchronize(st));
         LPGP_TRY(barrier());
+        if (involved && r >= 1) LPGP_HIP(hipEventRecord(e0, st));
         for (int d_ = 0; d_ < W; ++d_)
           if (d_ != me && sends(me, d_))
             LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[d_] + (size_t)me * count, dsend, sb, hipMemcpyDeviceToDevice, st));
+        if (involved && r >= 1) {
+          LPGP_HIP(hipEventRecord(e1, st));
+          LPGP_HIP(hipStreamSynchronize(st));
+          float ms = 0.f;
+          LPGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+          ipc_ms += (double)ms;
+        }
       } else {
         ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
         LPGP_CHECK(comm != nullptr, "link probe: no communicator");
@@ -386,7 +405,9 @@ int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
         }
       }
     }
-    if (involved) {
+    if (involved && ctx->ipc()) {
+      *seconds = ipc_ms * 1e-3 / reps;
+    } else if (involved) {
       LPGP_HIP(hipEventRecord(e1, st));
       LPGP_TRY(sync_stream(ctx, st));
       float ms = 0.f;
@@ -431,6 +452,24 @@ __global__ __launch_bounds__(256) void unpack_piece_kernel(double* __restrict__ 
   *reinterpret_cast<double2*>(dst + col * ldd + gr) = *reinterpret_cast<const double2*>(src + col * lds + r);
 }
 
+// the inverse on the source: tile i of the piece (class `cq`, its local tiles l0, l0 + 1, ...) is global tile cyc_l2g(cq, l0 + i),
+// which the source member `cr` keeps as its local tile cyc_before(cr, that)
+__global__ __launch_bounds__(256) void pack_piece_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
+                                                          int64_t lds, Cyc cq, Cyc cr, int l0, int64_t rows) {
+  const int64_t col = blockIdx.y;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (r >= rows) return;
+  const int i = (int)(r / TILE);
+  const int64_t sr = (int64_t)cyc_before(cr, cyc_l2g(cq, l0 + i)) * TILE + (r - (int64_t)i * TILE);
+  *reinterpret_cast<double2*>(dst + col * ldd + r) = *reinterpret_cast<const double2*>(src + col * lds + sr);
+}
+// debug aid (LPGP_DIST_POISON=1, tests): the panel buffer is filled with NaN before a gather, so that an update that read a
+// row this rank did not receive would poison the factor
+__global__ __launch_bounds__(256) void poison_kernel(double* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = __builtin_nan("");
+}
+
 static int ensure_buf(lpgp_ctx* ctx, double** p, size_t* cap, size_t doubles) {
   if (doubles <= *cap) return 0;
   DTRACE(ctx, "ensure_buf: %zu -> %zu doubles", *cap, doubles);
@@ -458,64 +497,99 @@ static Grid grid_of(const lpgp_ctx* ctx) {
   return g;
 }
 
-// Make rows [g_a, g_b) (global tiles) of tile columns [c0, c1) of the (partly) factored matrix available on every rank
-// inside a dense column-major panel `out` whose first row is global tile g_lo (leading dimension (T - g_lo) * 128), global
-// row order.  The columns live on process column pcK = (c0 / nbt) % Pc.  Collective; everything is enqueued on `st`.
+// Make rows [g_a, g_b) (global tiles) of tile columns [c0, c1) of the (partly) factored matrix available inside a dense
+// column-major panel `out` whose first row is global tile g_lo (leading dimension (T - g_lo) * 128), global row order.  The
+// columns live on process column pcK = (c0 / nbt) % Pc.  Collective; everything is enqueued on `st`.
 // with_self = false: this rank's own rows are in `out` already (self_unpack) -- it still sends them.  bulk: the second
 // communicator and its own pack buffer (the exchange runs beside the small exchanges of the panel chain).
+// scoped = false: every rank receives every row (the streamed solves, the collected factor: a rank applies the whole
+// panel to its columns).  scoped = true (round 4; the trailing update of the factorisation on Pr, Pc > 1 grids): a rank
+// receives only the rows its update READS -- its tiles (gr, gc) need panel rows gr (row class my_r) and gc (column class
+// my_c) -- so a block of rows with index B goes to process row B % Pr and to process column B % Pc only: the pieces are
+// the classes q = B mod lcm(Pr, Pc), piece q travels from rank (q % Pr, pcK) to the ranks (r, c) with r == q % Pr or
+// c == q % Pc, and a rank takes in ~ S (1/Pr + 1/Pc) of a panel of S bytes instead of S (2 x 4: 3/4).
 static int gather_rows(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, int g_a, int g_b,
-                       bool with_self, bool bulk, double* out) {
+                       bool with_self, bool bulk, double* out, bool scoped = false) {
   if (g_b <= g_a || T <= g_lo) return 0;
   const int64_t ldo = (int64_t)(T - g_lo) * TILE, cols = (int64_t)(c1 - c0) * TILE;
   const int pcK = (c0 / G.nbt) % G.Pc;
   const int64_t ld = mat->lr_cap;
-  // piece of row member r: its local tiles [l0_r, l0_r + nt_r)
-  std::vector<int> l0(G.Pr), nt(G.Pr);
+  if (!(G.Pr > 1 && G.Pc > 1)) scoped = false;                    // (Pr == 1: every rank holds whole tile rows; Pc == 1: whole columns)
+  int Lc = G.Pr;
+  if (scoped) {
+    int a = G.Pr, b = G.Pc;
+    while (b) { const int t = a % b; a = b; b = t; }
+    Lc = G.Pr / a * G.Pc;
+  }
+  static const bool poison = [] { const char* e = std::getenv("LPGP_DIST_POISON"); return e && std::atoi(e) != 0; }();
+  if (poison && with_self && g_a == g_lo && g_b == T) {
+    const size_t n = (size_t)ldo * (size_t)cols;
+    hipLaunchKernelGGL(poison_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n);
+  }
+  // piece of class q: its tiles [l0_q, l0_q + nt_q) in the class's own enumeration
+  auto class_of = [&](int q) { Cyc c = G.R; c.P = Lc; c.me = q; return c; };
+  std::vector<int> l0(Lc), nt(Lc);
   size_t total = 0;
-  for (int r = 0; r < G.Pr; ++r) {
-    const Cyc cr = G.Rof(r);
-    l0[r] = cyc_before(cr, g_a);
-    nt[r] = cyc_before(cr, g_b) - l0[r];
-    total += (size_t)nt[r] * TILE * cols;
+  for (int q = 0; q < Lc; ++q) {
+    const Cyc cq = class_of(q);
+    l0[q] = cyc_before(cq, g_a);
+    nt[q] = cyc_before(cq, g_b) - l0[q];
+    total += (size_t)nt[q] * TILE * cols;
   }
   double** pack = bulk ? &ctx->d_pack_bulk : &ctx->d_pack;
   LPGP_TRY(ensure_buf(ctx, pack, bulk ? &ctx->pack_bulk_cap : &ctx->pack_cap, total));
   std::vector<Piece> pieces;
-  std::vector<double*> pbuf(G.Pr);
+  std::vector<double*> pbuf(Lc);
+  std::vector<char> mine(Lc, 1);                                  // does this rank hold piece q after the exchange?
   size_t off = 0;
-  for (int r = 0; r < G.Pr; ++r) {
-    pbuf[r] = *pack + off;
-    off += (size_t)nt[r] * TILE * cols;
-    if (nt[r] == 0) continue;
-    const int root = r * G.Pc + pcK;
-    if (root == ctx->rank) {
-      // own rows: straight from the local matrix into the dense panel below; packed for the peers
-      const double* src = mat->a + (int64_t)l0[r] * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
-      if (ctx->world > 1) LPGP_TRY(copy2d(st, pbuf[r], (int64_t)nt[r] * TILE, src, ld, (int64_t)nt[r] * TILE, cols));
+  for (int q = 0; q < Lc; ++q) {
+    pbuf[q] = *pack + off;
+    off += (size_t)nt[q] * TILE * cols;
+    if (nt[q] == 0) continue;
+    const int r = q % G.Pr, root = r * G.Pc + pcK;
+    uint64_t dst = ~0ull;
+    if (scoped) {
+      dst = 0;
+      for (int rr = 0; rr < G.Pr; ++rr)
+        for (int cc = 0; cc < G.Pc; ++cc)
+          if (rr == r || cc == q % G.Pc) dst |= 1ull << (rr * G.Pc + cc);
+      mine[q] = (dst >> ctx->rank) & 1ull;
     }
-    pieces.push_back({root, pbuf[r], (size_t)nt[r] * TILE * cols});
+    if (root == ctx->rank && ctx->world > 1) {
+      // own rows, packed for the peers (and unpacked from there into this rank's own panel below)
+      const double* src = mat->a + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+      const int64_t rows = (int64_t)nt[q] * TILE;
+      hipLaunchKernelGGL(pack_piece_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, pbuf[q], rows, src,
+                         ld, class_of(q), G.Rof(r), l0[q], rows);
+    }
+    Piece pc{root, pbuf[q], (size_t)nt[q] * TILE * cols};
+    pc.dst = dst;
+    pieces.push_back(pc);
   }
+  LPGP_HIP(hipGetLastError());
   LPGP_TRY(bcast_pieces(ctx, st, pieces, bulk));
-  for (int r = 0; r < G.Pr; ++r) {
-    if (nt[r] == 0) continue;
-    const int root = r * G.Pc + pcK;
+  for (int q = 0; q < Lc; ++q) {
+    if (nt[q] == 0) continue;
+    const int r = q % G.Pr, root = r * G.Pc + pcK;
     if (root == ctx->rank && !with_self) continue;
-    const double* src = pbuf[r];
-    int64_t lds = (int64_t)nt[r] * TILE;
+    if (root != ctx->rank && !mine[q]) continue;
+    const double* src = pbuf[q];
+    int64_t lds = (int64_t)nt[q] * TILE;
     if (root == ctx->rank && ctx->world <= 1) {
-      src = mat->a + (int64_t)l0[r] * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;
+      src = mat->a + (int64_t)l0[q] * TILE + (int64_t)cyc_before(G.C, c0) * TILE * ld;      // (one rank: class == member, contiguous)
       lds = ld;
     }
-    const int64_t rows = (int64_t)nt[r] * TILE;
+    const int64_t rows = (int64_t)nt[q] * TILE;
     hipLaunchKernelGGL(unpack_piece_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)cols), dim3(256), 0, st, out, ldo, src,
-                       lds, G.Rof(r), l0[r], g_lo, rows);
+                       lds, class_of(q), l0[q], g_lo, rows);
   }
   LPGP_HIP(hipGetLastError());
   return 0;
 }
 
-static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out) {
-  return gather_rows(ctx, st, mat, G, T, c0, c1, g_lo, g_lo, T, true, false, out);
+static int gather_panel(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, const Grid& G, int T, int c0, int c1, int g_lo, double* out,
+                        bool scoped = false) {
+  return gather_rows(ctx, st, mat, G, T, c0, c1, g_lo, g_lo, T, true, false, out, scoped);
 }
 
 // This rank's OWN rows [g_lo, T) of tile columns [c0, c1) (it is a member of their process column) into the dense panel:
@@ -693,7 +767,7 @@ int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int3
     if (G.my_c == pcK) LPGP_TRY(panel_rows_solve(ctx, sP, mat, G, p.c0, p.c1, cyc_before(G.R, row_lo(p)), LTr));
     LPGP_TRY(ensure_panel(ctx, which, (size_t)(T - p.c1) * TILE * (size_t)(p.c1 - p.c0) * TILE));
     double* out = ctx->d_panel[which];
-    if (!split) return gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, out);
+    if (!split) return gather_panel(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, out, ctx->scoped_gather != 0);   // the updates read rows of this rank's row / column class only
     LPGP_HIP(hipEventRecord(ctx->ev_rows[which], sP));           // the rows below the panel are final
     LPGP_TRY(self_unpack(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, out));
     LPGP_TRY(gather_rows(ctx, sP, mat, G, T, p.c0, p.c1, p.c1, p.c1, head_end, false, false, out));

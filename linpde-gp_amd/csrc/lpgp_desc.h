@@ -49,8 +49,6 @@ struct DevGroup {
 struct DevDesc {
   int32_t d;
   int32_t ngroups;
-  int32_t ncoef;                   // used prefix of coef[] (set when the descriptor is staged for a launch)
-  int32_t pad_;
   DevGroup g[LPGP_MAXG];
   double coef[MAXCOEF];
 };

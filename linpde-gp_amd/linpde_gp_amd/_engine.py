@@ -25,6 +25,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self.rank, self.world, self.comm = 0, 1, None
+        self.distributed = False     # joined a multi-GPU job (`lpgp_dist_init*` succeeded): every call on a matrix is collective
 
     def dist_init(self, comm, transport: str = "rccl", grid: "tuple[int, int] | None" = None) -> None:
         """Join a one-process-per-GPU job.  `comm` is the control plane (`_dist.Comm`).
@@ -82,6 +83,7 @@ class Context:
                 check(lib.lpgp_dist_init_host(self._h, comm.rank, comm.world, self._host_exchange, None),
                       "lpgp_dist_init_host")
             self.rank, self.world, self.comm = comm.rank, comm.world, comm
+            self.distributed = True
             return
         # every rank leaves the bring-up in step, also when it fails: rank 0 broadcasts (ok, id-or-error), and the
         # outcome of ncclCommInitRank is agreed on before anybody raises (a rank that raised alone would leave the
@@ -100,6 +102,7 @@ class Context:
         if not all(o for o, _ in results):
             raise _lib.LpgpError("lpgp_dist_init failed: " + "; ".join(f"rank {r}: {e}" for r, (o, e) in enumerate(results) if not o))
         self.rank, self.world, self.comm = comm.rank, comm.world, comm
+        self.distributed = True
 
     @property
     def grid(self) -> "tuple[int, int]":
@@ -116,13 +119,13 @@ class Context:
         `pair_gbps[s][d]` (s -> d alone), `one_to_all_gbps[s]` (one link of s while it sends to every peer),
         `all_to_all_inbound_gbps[r]` (total inbound of rank r while everybody sends to everybody)."""
         W = self.world
-        out = np.zeros(W * W + W + 1)
+        out = np.zeros(W * W + W + 2)
         check(lib.lpgp_dist_link_probe(self._h, int(nbytes), int(reps), as_pd(out)), "lpgp_dist_link_probe")
         rows = self.comm.allgather(out)
         best = np.max(np.stack(rows), axis=0)
         pair = best[:W * W].reshape(W, W)
         off = ~np.eye(W, dtype=bool)
-        return {"bytes": int(nbytes), "reps": int(reps),
+        return {"bytes": int(nbytes), "bytes_per_message": int(out[W * W + W + 1]), "reps": int(reps),
                 "pair_gbps": [[round(float(v), 2) for v in r_] for r_ in pair],
                 "pair_min_gbps": float(pair[off].min()) if W > 1 else 0.0,
                 "pair_median_gbps": float(np.median(pair[off])) if W > 1 else 0.0,

@@ -288,7 +288,7 @@ class ConditionalGaussianProcess(GaussianProcess):
             # no observations: nothing to assemble or factor, the factor in HBM stays as it is (and
             # stays valid for the object this one was derived from)
             return cls(prior=prior, blocks=tuple(old_blocks), state=state, representer_weights=None)
-        lazy = bool(config.lazy_factorization) and state.ctx.world == 1
+        lazy = bool(config.lazy_factorization) and not state.ctx.distributed      # (a context that joined a job -- even of one rank -- factors collectively)
         if not state.pending and not state.owns(old_blocks):
             # the object being conditioned is known to rest on a block that was not positive definite
             raise np.linalg.LinAlgError(state.failure or "the Gram matrix of this posterior is not positive definite")

@@ -201,20 +201,27 @@ def _model_potrf_dist_2d(tiles, dblk, t_done, T, nbt, tb, pr, pc, rank, bcast):
                 for gj in range(nxt, gi + 1):
                     tiles[(gi, gj)] = tiles[(gi, gj)] - panel[gi] @ panel[gj].T
             continue
-        # gather the rows below the panel: one broadcast per source rank (r', process column of the panel)
+        # gather the rows below the panel.  SCOPED (round 4, dist.hip: gather_rows): with Pr, Pc > 1 a rank receives only
+        # the rows its updates read -- row blocks B with B % Pr == my_r (rows of its tiles) or B % Pc == my_c (columns of its
+        # tiles); the pieces are the classes q = B mod lcm(Pr, Pc), each from rank (q % Pr, process column of the panel).
+        # `panel` holds nothing else, so an update that read any other row raises KeyError.  (The transport here is a
+        # gloo broadcast: a rank outside the destination set takes part in it and drops the piece.)
+        import math
         panel = {}
-        for r in range(pr):
-            rows = [gi for gi in range(c1, T) if own_r(gi) == r]
+        lc = math.lcm(pr, pc) if (pr > 1 and pc > 1) else pr
+        for q in range(lc):
+            rows = [gi for gi in range(c1, T) if (gi // nbt) % lc == q]
             if not rows:
                 continue
-            root = r * pc + own_c(c0)
+            root = (q % pr) * pc + own_c(c0)
             if rank == root:
                 send = np.stack([np.hstack([tiles[(gi, gj)] for gj in range(c0, c1)]) for gi in rows])
             else:
                 send = np.empty((len(rows), tb, kw * tb))
             got = bcast(send, root)
-            for gi, P in zip(rows, got):
-                panel[gi] = P
+            if lc == pr or my_r == q % pr or my_c == q % pc:
+                for gi, P in zip(rows, got):
+                    panel[gi] = P
         for gi in range(row_lo, T):
             if own_r(gi) != my_r:
                 continue
@@ -264,7 +271,7 @@ def _dist_model_worker(rank, world, pr, pc, gloo_port, q):
     q.put((rank, ok))
 
 
-@pytest.mark.parametrize("pr,pc", [(2, 1), (1, 2), (2, 2), (3, 1), (2, 3)])
+@pytest.mark.parametrize("pr,pc", [(2, 1), (1, 2), (2, 2), (3, 1), (2, 3), (2, 4)])
 def test_distributed_cholesky_model_gloo(pr, pc):
     """The algorithm of csrc/dist.hip on gloo ranks: every rank keeps ONLY its tiles of the 2-D block-cyclic
     distribution (a rank that read a tile it does not own would raise KeyError) and must end with exactly its share

@@ -189,6 +189,83 @@ def test_multi_rank_rccl_over_loopback_sockets(grid, workload, nb, port, collect
     _run_ranks(grid[0] * grid[1], grid, workload, nb, port, transport="rccl", rank_env=env)
 
 
+SCOPED = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
+import numpy as np
+import linpde_gp_amd as lp
+from linpde_gp_amd import _dist, _engine, problems
+from oracle import workloads as owl
+comm = _dist.Comm.from_env()
+ctx = _engine.default_context()
+ctx.set_option("nb", 128)
+ctx.dist_init(comm, transport=%(transport)r, grid=%(grid)r)
+wl = problems.poisson_2d(n_side=40, n_bdry=33, m_side=9)        # N_tot = 1732: 14 blocks of 128, five conditionings
+ref = owl.run(wl)
+recv = {}
+for scoped in (1, 0):
+    ctx.set_option("scoped_gather", scoped)
+    ctx.dist_stats(reset=True)
+    prior = problems.build_prior(wl)
+    u = prior
+    for o in wl.observations:
+        X, Y = o.X_as_given()
+        b = None if o.noise_var is None else lp.randvars.Normal(np.zeros(Y.shape), np.full(o.X.shape[0], o.noise_var))
+        u = u.condition_on_observations(Y, X=X, L=problems.operator_of(o.op, wl.d), b=b)
+    ctx.sync()
+    recv[scoped] = ctx.dist_stats()["bytes_received"]            # the factorisations alone (the streamed solves need every row)
+    mean, var = u.predict(wl.Xtest)
+    em = np.max(np.abs(mean - ref["mean"])) / np.max(np.abs(ref["mean"]))
+    ev = np.max(np.abs(var - ref["var"])) / np.max(np.abs(ref["var"]))
+    Lf = u.gram.cholesky(True)
+    assert np.all(np.isfinite(Lf)) and em < 1e-8 and ev < 1e-8, (scoped, em, ev)
+    del u
+print("SCOPED", comm.rank, recv[1], recv[0], flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("grid,port,transport", [((2, 2), 30211, "host"), ((2, 4), 30221, "host"), ((2, 2), 30231, "ipc")])
+def test_scoped_panel_gather_on_2d_grids(grid, port, transport):
+    """Round 4 (missing 3): on a Pr x Pc grid with Pr, Pc > 1 a panel's rows travel only to the process row and
+    the process column whose trailing updates read them, ~ S (1/Pr + 1/Pc) per rank instead of the whole panel S
+    (SURVEY.md section 8e).  Every rank runs the same five conditionings with the scoped and with the unscoped gather:
+    both against the oracle -- with LPGP_DIST_POISON=1 the panel buffer is NaN wherever a rank received nothing, so an
+    update that read such a row would poison the factor -- and the bytes received during the factorisations compared."""
+    world = grid[0] * grid[1]
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPGP_DEVICE="0", LPGP_DIST_POISON="1",
+               OPENBLAS_NUM_THREADS="4", OMP_NUM_THREADS="4", MKL_NUM_THREADS="4", LPGP_IPC_WINDOW_MB="8")
+    env.pop("LOCAL_RANK", None)
+    procs = [subprocess.Popen([sys.executable, "-c", SCOPED % {"root": ROOT, "grid": grid, "transport": transport}], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    got = {}
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: " + so[-1500:] + se[-3000:]
+        line = [ln for ln in so.splitlines() if ln.startswith("SCOPED")][-1].split()
+        got[int(line[1])] = (float(line[2]), float(line[3]))
+    scoped, full = sum(v[0] for v in got.values()), sum(v[1] for v in got.values())
+    assert all(v[0] <= v[1] for v in got.values()), got
+    # expected share of the panel bytes: (1/Pr + 1/Pc - 1/(Pr Pc)) / (1 - 1/(Pr Pc)) on average over the ranks -- 2 x 2: 1.0 of
+    # them for the off-diagonal ranks and 1/3 for the diagonal ones (2/3 overall), 2 x 4: 4/7 -- plus the diagonal blocks and
+    # tile inverses, which every rank receives either way (a quarter of the traffic at this size)
+    pr, pc = grid
+    share = (1.0 / pr + 1.0 / pc - 1.0 / (pr * pc)) / (1.0 - 1.0 / (pr * pc))
+    print(f"\n[scoped gather {pr} x {pc}, {transport}] bytes received in the factorisations, all ranks: {scoped:.3e} scoped vs {full:.3e} to everyone "
+          f"= {scoped / full:.3f} (panel share expected {share:.3f}); per rank {got}")
+    assert scoped <= (share + 0.5 * (1.0 - share)) * full, (scoped, full, share)
+    if grid == (2, 2):
+        assert got[0][0] < 0.75 * got[0][1] and got[3][0] < 0.75 * got[3][1]      # ranks (0,0) and (1,1): half of every panel
+
+
 FAILING = r"""
 import os, sys, time
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "linpde-gp_amd"))
