@@ -316,8 +316,10 @@ def main():
     ap.add_argument("--m-side", type=int, default=64, help="prediction grid side (c3: 64)")
     ap.add_argument("--cpu-side", type=int, default=0,
                     help="0 (default): time the CPU oracle on the bench workload itself; > 0: on a bounded sample of this grid side")
-    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson1d", "heat1d", "scattered2d"],
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson1d", "heat1d", "scattered2d", "poisson1d_c1", "heat_reference"],
                     help="poisson2d = c3/c4 (the metric's workload), poisson1d = c2 (N=8192), heat1d = c5 (N=32768 + IC/BC/noisy interior), "
+                         "poisson1d_c1 = c1 (N=512 + 32 repeated noisy boundary values, N_tot = 544), heat_reference = the reference's own heat "
+                         "problem at its own sizes (tests/linpde_gp/problems/test_heat.py:56-99, N_tot = 2 105, 50 x 50 test grid), "
                          "scattered2d = 16 384 noisy values at scattered points (not a BASELINE config: every block through the "
                          "per-entry assembly kernels, none through the Kronecker path)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -354,6 +356,10 @@ def main():
             return problems.heat_1d()               # c5
         if args.workload == "scattered2d":
             return problems.scattered_2d(n=16384, m=4096)
+        if args.workload == "poisson1d_c1":
+            return problems.poisson_1d(512, n_bdry_repeats=16, noise_var=1e-4, m=256)      # c1 (tests/test_gpu_configs.py)
+        if args.workload == "heat_reference":
+            return problems.heat_reference()
         return problems.poisson_2d(n_side=n_side, m_side=m_side)
 
     # ---- CPU baseline FIRST (N = 1 only): the host cores are idle, and the GPU section afterwards is one busy stretch ----
@@ -584,7 +590,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": wl.name,
-            "n_collocation": int(wl.observations[-1].X.shape[0]) if args.workload == "poisson1d" else
+            "n_collocation": int(wl.observations[-1].X.shape[0]) if args.workload in ("poisson1d", "poisson1d_c1") else
                              int(max(o.X.shape[0] for o in wl.observations)),
             "n_other_observations": int(wl.n_total - max(o.X.shape[0] for o in wl.observations)),
             "n_total": wl.n_total,

@@ -9,6 +9,7 @@ from ._workloads import (
     build_prior,
     condition_and_predict,
     heat_1d,
+    heat_reference,
     operator_of,
     poisson_1d,
     poisson_2d,
@@ -18,6 +19,6 @@ from ._workloads import (
 )
 
 __all__ = [
-    "pde", "Observation", "Workload", "build_prior", "condition_and_predict", "heat_1d",
+    "pde", "Observation", "Workload", "build_prior", "condition_and_predict", "heat_1d", "heat_reference",
     "operator_of", "poisson_1d", "poisson_2d", "scattered_2d", "upload", "row_residual", "analytic_solution",
 ]

@@ -40,6 +40,7 @@ class Workload:
     kernel: list                  # oracle-style [(scale, [factor, ...])]
     observations: list = field(default_factory=list)
     Xtest: np.ndarray | None = None
+    solution: np.ndarray | None = None      # closed-form solution on Xtest, where the builder knows one
 
     @property
     def n_total(self) -> int:
@@ -118,6 +119,35 @@ def heat_1d(nt: int = 512, nx: int = 64, alpha: float = 0.1, m_side: int = 64) -
     return Workload(f"heat1d_{nt}x{nx}", 2, kernel, [ic, *bcs, pde, interior], Xt)
 
 
+def heat_reference(n_ic: int = 5, n_bc: int = 50, n_pde=(100, 20), m_side: int = 50) -> Workload:
+    """The reference's OWN heat problem at its own sizes (`tests/linpde_gp/problems/test_heat.py:56-99`): u_t - 0.1 u_xx = 0 on
+    t in [0, 5], x in [-1, 1], initial values sin(pi (x+1)/2) + 2 sin(pi (x+1)) (`TruncatedSineSeries`, coefficients [1, 2]),
+    5 initial values (inset 1e-6), 2 x 50 Dirichlet boundary values with noise 1e-5, 100 x 20 collocation points (N_tot = 2 105),
+    50 x 50 test grid; prior Matern-3/2(l_t = 2.5) x Matern-5/2(l_x = 2.0).  Built with the package's own problem builders,
+    exactly as the reference's test builds it."""
+    from .. import domains
+    from . import pde
+
+    spatial = domains.asdomain([-1.0, 1.0])
+    ibvp = pde.HeatEquationDirichletProblem(t0=0.0, T=5.0, spatial_domain=spatial, alpha=0.1,
+                                            initial_values=pde.TruncatedSineSeries(spatial, coefficients=[1.0, 2.0]))
+    ident = {(0, 0): 1.0}
+    heat = {(1, 0): 1.0, (0, 2): -0.1}
+    X_ic = np.asarray(ibvp.initial_domain.uniform_grid(n_ic, inset=1e-6))
+    obs = [Observation(X_ic.reshape(-1, 2), np.asarray(ibvp.initial_condition.values(X_ic[..., 1])).reshape(-1), ident, None)]
+    for bc in ibvp.boundary_conditions:
+        X_bc = np.asarray(bc.boundary.uniform_grid(n_bc))
+        obs.append(Observation(X_bc.reshape(-1, 2), np.asarray(bc.values(X_bc)).reshape(-1), ident, 1e-5))
+    tg, xg = np.linspace(0.0, 5.0, n_pde[0]), np.linspace(-1.0, 1.0, n_pde[1])
+    Xp = np.stack(np.meshgrid(tg, xg, indexing="ij"), axis=-1).reshape(-1, 2)
+    assert np.array_equal(Xp, np.asarray(ibvp.domain.uniform_grid(tuple(n_pde))).reshape(-1, 2))
+    obs.append(Observation(Xp, np.zeros(Xp.shape[0]), heat, None, grid=(tg, xg)))
+    Xt = np.asarray(ibvp.domain.uniform_grid((m_side, m_side))).reshape(-1, 2)
+    wl = Workload(f"heat_reference_{n_pde[0]}x{n_pde[1]}", 2, [(1.0, [("matern", 1.5, 2.5), ("matern", 2.5, 2.0)])], obs, Xt)
+    wl.solution = np.asarray(ibvp.solution(Xt)).reshape(-1)
+    return wl
+
+
 def scattered_2d(n: int = 8192, m: int = 4096, noise_var: float = 1e-2, seed: int = 0) -> Workload:
     """Noisy values at `n` scattered points of [-1,1]^2, prediction at `m` scattered points, prior 1.5^2 * M52(l=0.8) x
     M32(l=0.6): no tensor grid anywhere, so every block goes through the per-entry assembly kernels (the BASELINE
@@ -194,6 +224,8 @@ def analytic_solution(wl: Workload):
         return np.exp(-0.1 * (np.pi / 2.0) ** 2 * wl.Xtest[:, 0]) * np.sin(np.pi * (wl.Xtest[:, 1] + 1.0) / 2.0)
     if wl.name.startswith("poisson1d"):
         return np.sin(np.pi * wl.Xtest[:, 0])
+    if getattr(wl, "solution", None) is not None:
+        return wl.solution
     return None
 
 
