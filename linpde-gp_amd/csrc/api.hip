@@ -398,6 +398,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_SMALL_RING2")) ctx->small_ring2 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_FUSED_AHEAD")) ctx->fused_ahead = std::atoi(e);
   if (const char* e = std::getenv("LPGP_GEMM3_MARGIN")) ctx->gemm3_margin = std::atof(e);
   if (const char* e = std::getenv("LPGP_GEMM3_FACT")) ctx->gemm3_fact = std::atoi(e);
   if (const char* e = std::getenv("LPGP_ASM_FACTORS")) ctx->asm_factors = std::atoi(e) != 0;
@@ -503,6 +504,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "live_mats") == 0) *value = ctx->live_mats;
   else if (std::strcmp(key, "asm_ct") == 0) *value = ctx->asm_ct;
   else if (std::strcmp(key, "asm_fast") == 0) *value = ctx->asm_fast;
+  else if (std::strcmp(key, "fused_ahead") == 0) *value = ctx->fused_ahead;
   else if (std::strcmp(key, "nb_outer_solve") == 0) *value = ctx->nb_outer_solve;
   else if (std::strcmp(key, "nb_outer_solve_min_tiles") == 0) *value = ctx->nb_outer_solve_min_tiles;
   else if (std::strcmp(key, "nb_solve") == 0) *value = ctx->nb_solve;
@@ -548,6 +550,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->gemm3 = value < 0 ? lpgp_ctx().gemm3 : (int)value;       // (negative: back to the built-in default)
   } else if (std::strcmp(key, "small_ring2") == 0) {
     ctx->small_ring2 = (int)value;
+  } else if (std::strcmp(key, "fused_ahead") == 0) {
+    ctx->fused_ahead = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
   } else if (std::strcmp(key, "nb_solve") == 0) {
@@ -770,7 +774,7 @@ int lpgp_mat_create(lpgp_ctx* ctx, int64_t capacity_hint, lpgp_mat** out) {
   m->n = m->pn = m->pn_fact = 0;
   m->has_w = 0;
   m->has_r = 0;
-  int64_t cap = round_up(capacity_hint > 0 ? capacity_hint : TILE, TILE);
+  int64_t cap = round_up(capacity_hint > 0 ? capacity_hint : 8 * TILE, TILE);      // (no hint: room for 1 024 rows, 8 MB -- the reference's own problem sizes start here)
   int rc = mat_alloc(ctx, m, cap);
   if (rc != 0) {
     delete m;
@@ -800,7 +804,13 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
   b.poff = mat->pn;
   b.pn = round_up(n, TILE);
   if (b.poff + b.pn > mat->cap) {
-    int rc = mat_alloc(ctx, mat, b.poff + b.pn);
+    // grow geometrically while the matrix is small (a chain of small conditionings without `gram_capacity_hint` used to
+    // re-allocate, copy and synchronise at EVERY block: 48 us of host time per add_block at N_tot = 1 152); a block that
+    // needs more than that gets exactly what it needs (the large PDE block of c3 / c4 is the last growth of its chain)
+    int64_t want = b.poff + b.pn;
+    const int64_t geo = round_up(mat->cap + mat->cap / 2, TILE);
+    if (geo > want && geo <= 16384) want = geo;
+    int rc = mat_alloc(ctx, mat, want);
     if (rc != 0) return rc;
   }
   const int64_t pad = b.pn - b.n;

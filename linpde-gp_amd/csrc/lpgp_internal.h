@@ -97,6 +97,7 @@ struct lpgp_ctx {
   int64_t nb = 512;                // panel width of the blocked Cholesky
   int64_t nb_outer_solve = 4096;   // forward substitution: rows below an outer block of this many rows are updated once per block (two-level scheme, potrf.hip); 0: plain right-looking
   int scoped_gather = 1;           // Pr, Pc > 1 grids: a panel's rows go only to the process row / column whose updates read them (0: to everyone, rounds 1-3)
+  int fused_ahead = 1;             // forward substitution: the look-ahead update rides in front of the next fused panel chain (one launch; 0: a launch of its own, rounds 1-3)
   int small_ring2 = 32;            // rank-128 in-panel updates of at least this many 128-tiles run on the two-stage ring of the 64 x 64 kernel (four workgroups per CU); 0: never
   int nb_outer_solve_min_tiles = 384;  // ... from this many tile rows on (c4; measured no gain at c3 / c5 sizes)
   int64_t nb_solve = 0;            // panel width of the blocked forward substitution (0: by size, see trsm_lower_blocked)
@@ -324,6 +325,9 @@ int launch_trsm_tile(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, 
 int launch_trsv_panel(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, int64_t ldl,
                       int nt_rows, int nt_cols, int prof_kernel);
 // the same chain for rows: X (mt tiles of rows x nt_cols <= 4 tile columns) <- X L_KK^{-T}, L_KK already factored
+// the same with the look-ahead update by the previous panel (4 tiles = 512 solved rows right above V) fused in front (solve4p.hip)
+int launch_trsv_panel_ahead(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_t ldv, const double* linv, const double* L, const double* Lprev,
+                            int64_t ldl, int nt_rows, int nt_cols, int prof_kernel);
 int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
                       int nt_cols, int mt, int prof_kernel);
 

@@ -1,5 +1,6 @@
-// The fused panel step of the forward substitution (kernel template + launcher), instantiated in solve.hip (NT = 1, 2, 3)
-// and solve4.hip (NT = 4): the fully unrolled stage schedule of NT = 4 alone takes over a minute to compile.
+// The fused panel step of the forward substitution (kernel template + launcher), instantiated in solve.hip (NT = 1, 2, 3),
+// solve4.hip (NT = 4) and solve4p.hip (the variants with the fused look-ahead update, NP = 4): the fully unrolled stage
+// schedule of NT = 4 alone takes over a minute to compile.
 #pragma once
 
 #include "lpgp_internal.h"
@@ -44,9 +45,20 @@ __device__ __forceinline__ void vm_wait_n() {
 //                   A_i -= X_j L_ij^T, i > j (kind 3, full tile)
 // with the fragments of all NT tiles of the panel in registers (8 NT doubles per lane).
 // =========================================================================================
-constexpr int psv_nprod(int NT) { return 3 * NT + NT * (NT - 1) / 2; }
+// Round 4, NP > 0: the kernel ALSO applies the PREVIOUS panel (NP tiles = 128 NP solved rows of V right above this panel) to
+// its own rows first -- the look-ahead update (a) of the blocked forward substitution, until round 3 a launch of its own in
+// front of this one -- as NP x NT more products at the head of the chain:
+//     for j < NP:   for i < NT:   A_i -= Vprev_j Lprev_ij^T     (kind 4, full tile; Lprev = the factor's block left of the
+//                                                                 panel's diagonal block)
+// One launch instead of two, and above all ONE wait: the fused kernel becomes runnable at the very moment the previous
+// remainder update ends -- together with the next remainder update -- and takes its slots on the drained chip (measured,
+// kernel trace: a panel solve launched beside a starting update completes in 120 us; launched 60 us later, behind (a), it
+// starves until that update drains and the update stream then idles 57-95 us per panel, 2 ms of the c3 prediction).
+constexpr int psv_nprod(int NT, int NP = 0) { return NP * NT + 3 * NT + NT * (NT - 1) / 2; }
 struct PsvProd { int kind, j, i; };
-constexpr PsvProd psv_prod(int NT, int p) {
+constexpr PsvProd psv_prod(int NT, int p, int NP = 0) {
+  if (p < NP * NT) return {4, p / NT, p % NT};
+  p -= NP * NT;
   int q = 0;
   for (int j = 0; j < NT; ++j) {
     for (int k = 0; k < 3; ++k, ++q)
@@ -56,37 +68,37 @@ constexpr PsvProd psv_prod(int NT, int p) {
   }
   return {-1, 0, 0};
 }
-constexpr int psv_first_prod(int NT, int j) {          // index of product (kind 0, j)
-  int q = 0;
+constexpr int psv_first_prod(int NT, int j, int NP = 0) {          // index of product (kind 0, j)
+  int q = NP * NT;
   for (int jj = 0; jj < j; ++jj) q += 3 + (NT - 1 - jj);
   return q;
 }
-template <int NT> constexpr bool psv_tri(int s) { return psv_prod(NT, s / 8).kind != 3; }
-template <int NT> constexpr int psv_stride(int s) { return psv_tri<NT>(s) ? 136 - 16 * (s % 8) : 136; }
-template <int NT> constexpr int psv_size(int s) { return 16 * psv_stride<NT>(s); }
-template <int NT>
+template <int NT, int NP = 0> constexpr bool psv_tri(int s) { return psv_prod(NT, s / 8, NP).kind < 3; }
+template <int NT, int NP = 0> constexpr int psv_stride(int s) { return psv_tri<NT, NP>(s) ? 136 - 16 * (s % 8) : 136; }
+template <int NT, int NP = 0> constexpr int psv_size(int s) { return 16 * psv_stride<NT, NP>(s); }
+template <int NT, int NP = 0>
 struct PsvSched {
-  static constexpr int NS = 8 * psv_nprod(NT);
+  static constexpr int NS = 8 * psv_nprod(NT, NP);
   int off[NS] = {};
   int iss_lo[NS + 1] = {};
   int iss_hi[NS + 1] = {};
   int wait[NS] = {};
 };
-template <int NT>
-constexpr PsvSched<NT> psv_make_sched(int dma_per_stage) {          // same placement rule as tsv_make_sched
-  PsvSched<NT> S;
-  constexpr int NS = PsvSched<NT>::NS;
+template <int NT, int NP = 0>
+constexpr PsvSched<NT, NP> psv_make_sched(int dma_per_stage) {          // same placement rule as tsv_make_sched
+  PsvSched<NT, NP> S;
+  constexpr int NS = PsvSched<NT, NP>::NS;
   int next = 0, head = 0;
   for (int t = 0; t <= NS; ++t) {
     const int live_lo = t == 0 ? 0 : t - 1;
     S.iss_lo[t] = next;
     while (next < NS) {
-      const int sz = psv_size<NT>(next);
+      const int sz = psv_size<NT, NP>(next);
       int o = head;
       if (o + sz > TSV_RING) o = 0;
       bool ok = true;
       for (int l = live_lo; l < next; ++l)
-        if (o < S.off[l] + psv_size<NT>(l) && S.off[l] < o + sz) ok = false;
+        if (o < S.off[l] + psv_size<NT, NP>(l) && S.off[l] < o + sz) ok = false;
       if (!ok) break;
       S.off[next] = o;
       head = o + sz;
@@ -97,11 +109,11 @@ constexpr PsvSched<NT> psv_make_sched(int dma_per_stage) {          // same plac
   }
   return S;
 }
-template <int NT, int RG>
+template <int NT, int RG, int NP = 0>
 constexpr bool psv_sched_ok() {
-  constexpr PsvSched<NT> S = psv_make_sched<NT>(4 / RG);
-  if (S.iss_hi[PsvSched<NT>::NS] != PsvSched<NT>::NS) return false;
-  for (int s = 0; s < PsvSched<NT>::NS; ++s)
+  constexpr PsvSched<NT, NP> S = psv_make_sched<NT, NP>(4 / RG);
+  if (S.iss_hi[PsvSched<NT, NP>::NS] != PsvSched<NT, NP>::NS) return false;
+  for (int s = 0; s < PsvSched<NT, NP>::NS; ++s)
     if (S.iss_hi[s] < s + 1 || S.wait[s] < 0 || S.wait[s] > 62) return false;
   return true;
 }
@@ -112,6 +124,8 @@ struct PanelSolveArgs {
   const double* linv;        // tile inverses of the panel's NT diagonal tiles, contiguous (128 x 128 each, ld 128)
   const double* L;           // the panel's diagonal block of the factor (NT x NT tiles), leading dimension ldl
   int64_t ldl;
+  const double* Lprev = nullptr;   // NP > 0: the factor's NT x NP tile block left of L (same leading dimension); the previous
+                                   // panel's solved rows are the NP * 128 rows of V right above V
 };
 
 // RG = 16-column groups per workgroup (2: eight waves, 32 columns; 1: four waves, 16 columns -- half the matrix work per
@@ -119,12 +133,13 @@ struct PanelSolveArgs {
 // KFAST = true: the forward substitution (above).  KFAST = false: the same chain for ROWS below an already factored
 // diagonal block, X[rows, panel columns] <- X L_KK^{-T} with X(i, c) at V[i + c ldv] -- the panel solve of the multi-GPU
 // factorisation (the diagonal block arrives first there) and of a block append (old panels, new rows).
-template <int NT, int RG, bool KFAST>
+template <int NT, int RG, bool KFAST, int NP = 0>
 __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs g) {
-  static_assert(psv_sched_ok<NT, RG>(), "panel solve: broken stage schedule");
-  constexpr PsvSched<NT> SCH = psv_make_sched<NT>(4 / RG);
+  static_assert(psv_sched_ok<NT, RG, NP>(), "panel solve: broken stage schedule");
+  static_assert(NP == 0 || KFAST, "panel solve: the fused look-ahead update exists for the forward substitution only");
+  constexpr PsvSched<NT, NP> SCH = psv_make_sched<NT, NP>(4 / RG);
   constexpr int XA = RG * 32 * 64;                       // doubles of the fragment image
-  constexpr int NS = PsvSched<NT>::NS;
+  constexpr int NS = PsvSched<NT, NP>::NS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* xa = smem;
   double* ring = smem + XA;
@@ -138,14 +153,20 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
 
   auto issue = [&](auto S_) {
     constexpr int s = decltype(S_)::value;
-    constexpr PsvProd pd = psv_prod(NT, s / 8);
-    constexpr int kt = s % 8, stride = psv_stride<NT>(s);
-    constexpr bool tri = pd.kind != 3;
+    constexpr PsvProd pd = psv_prod(NT, s / 8, NP);
+    constexpr int kt = s % 8, stride = psv_stride<NT, NP>(s);
+    constexpr bool tri = pd.kind < 3;
     constexpr int len = tri ? 128 - 16 * kt : 128, col0 = tri ? 16 * kt : 0;
-    // element (k, c) of M^T is M[c + k ldm]
-    const double* M = (pd.kind == 0 || pd.kind == 2) ? g.linv + (int64_t)pd.j * TILE * TILE
-                                                      : g.L + (int64_t)pd.i * TILE + (int64_t)pd.j * TILE * g.ldl;
-    const int64_t ldm = (pd.kind == 0 || pd.kind == 2) ? (int64_t)TILE : g.ldl;
+    // element (k, c) of M^T is M[c + k ldm].  The base pointers and the leading dimension pass through an empty asm per
+    // stage: the unrolled chain is straight-line code, and the compiler otherwise keeps the scalar base of EVERY factor tile
+    // (up to 26 pointer pairs) alive from the first stage on -- 37 (NP = 0) to 78 (NP = 4) SGPRs spilled to VGPR lanes;
+    // recomputing a base costs three scalar instructions on an idle scalar unit
+    const double* lbase = (pd.kind == 0 || pd.kind == 2) ? g.linv : (pd.kind == 4 ? g.Lprev : g.L);
+    int64_t ldl = g.ldl;
+    asm volatile("" : "+s"(lbase), "+s"(ldl));
+    const double* M = (pd.kind == 0 || pd.kind == 2) ? lbase + (int64_t)pd.j * TILE * TILE
+                                                      : lbase + (int64_t)pd.i * TILE + (int64_t)pd.j * TILE * ldl;
+    const int64_t ldm = (pd.kind == 0 || pd.kind == 2) ? (int64_t)TILE : ldl;
     double* sb = ring + SCH.off[s];
     if (2 * lane < len) {
 #pragma unroll
@@ -165,11 +186,17 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[t][q] = pbase[(t * TILE + q * 16) * cstep];
+  // (NP > 0) the first operand image is the previous panel's first solved tile, negated: the chain opens with A_i -= Vprev_j Lprev_ij^T
+  double vp[8];
+  if constexpr (NP > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vp[q] = pbase[(-(NP * TILE) + q * 16) * cstep];
+  }
   asm volatile("" ::: "memory");
   issue(std::integral_constant<int, 0>{});
   double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) xown[q * 256] = a[0][q];
+  for (int q = 0; q < 8; ++q) xown[q * 256] = NP > 0 ? -vp[q] : a[0][q];
   asm volatile("" ::: "memory");
   static_for<1, SCH.iss_hi[0]>(issue);
   const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
@@ -179,11 +206,11 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
   // dst[q] += sum over the k-steps of (operand fragment from xa) x (factor fragment), product P of the chain
   auto run_product = [&](auto P_, double(&dst)[8]) {
     constexpr int prod = decltype(P_)::value;
-    constexpr bool tri = psv_prod(NT, prod).kind != 3;
+    constexpr bool tri = psv_prod(NT, prod, NP).kind < 3;
     static_for<0, 8>([&](auto KT_) {
       constexpr int kt = decltype(KT_)::value;
       constexpr int s = prod * 8 + kt;
-      constexpr int stride = psv_stride<NT>(s);
+      constexpr int stride = psv_stride<NT, NP>(s);
       constexpr int q0 = tri ? kt : 0;                       // first fragment this stage feeds
       vm_wait_n<SCH.wait[s]>();
       TSV_BARRIER();
@@ -217,10 +244,28 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
     });
   };
 
+  // ---- (NP > 0) the fused look-ahead update: the previous panel applied to this panel's rows ----
+  static_for<0, NP>([&](auto JP_) {
+    constexpr int jp = decltype(JP_)::value;
+    if constexpr (jp > 0) {
+      TSV_BARRIER();                                           // the products of tile jp - 1 have read the fragment image
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xown[q * 256] = -vp[q];
+    }
+    if constexpr (jp + 1 < NP) {
+      // the next solved tile of the previous panel, in flight while the products of this one run
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vp[q] = pbase[(-(NP * TILE) + (jp + 1) * TILE + q * 16) * cstep];
+    }
+    static_for<0, NT>([&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      run_product(std::integral_constant<int, jp * NT + i>{}, a[i]);          // A_i -= Vprev_jp Lprev_{i,jp}^T
+    });
+  });
   static_for<0, NT>([&](auto J_) {
     constexpr int j = decltype(J_)::value;
-    constexpr int p0 = psv_first_prod(NT, j);
-    if constexpr (j > 0) {
+    constexpr int p0 = psv_first_prod(NT, j, NP);
+    if constexpr (j > 0 || NP > 0) {
       TSV_BARRIER();                                           // the updates by X_{j-1} have read xa
 #pragma unroll
       for (int q = 0; q < 8; ++q) xown[q * 256] = a[j][q];
@@ -256,19 +301,19 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
   (void)NS;
 }
 
-template <int NT, int RG, bool KFAST>
+template <int NT, int RG, bool KFAST, int NP = 0>
 int launch_panel_solve_rg(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
   const size_t shmem = (size_t)(RG * 32 * 64 + TSV_RING) * sizeof(double);
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG, KFAST>), shmem));
-  hipLaunchKernelGGL((panel_solve_kernel<NT, RG, KFAST>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG, KFAST, NP>), shmem));
+  hipLaunchKernelGGL((panel_solve_kernel<NT, RG, KFAST, NP>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
 // 16-column workgroups (RG = 1) throughout: per column the 32-column variant is no faster (measured: 264 workgroups of
 // either kind take 117 us at NT = 4 for 4224 resp. 205 us for 8448 columns) and the chain of a narrow block is half as long
-template <int NT, bool KFAST>
+template <int NT, bool KFAST, int NP = 0>
 int launch_panel_solve_nt(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
-  return launch_panel_solve_rg<NT, 1, KFAST>(ctx, stream, a, cols);
+  return launch_panel_solve_rg<NT, 1, KFAST, NP>(ctx, stream, a, cols);
 }
 
 }  // namespace lpgp

@@ -422,3 +422,31 @@ def test_two_level_forward_substitution_small(ctx, chain_bound):
     assert np.max(np.abs(mean0 - ref["mean"])) <= ma and np.max(np.abs(var0 - ref["var"])) <= va
     np.testing.assert_allclose(mean1, mean0, rtol=0, atol=ma)
     np.testing.assert_allclose(var1, var0, rtol=0, atol=va)
+
+
+@pytest.mark.parametrize("n_side,n_bdry", [(40, 20), (41, 20), (43, 20), (44, 20), (50, 28)])      # 17, 18, 19, 20, 24 tile rows: last panels of 1, 2, 3, 4, 4
+def test_forward_substitution_with_fused_look_ahead(ctx, n_side, n_bdry):
+    """Round 4: the look-ahead update of the blocked forward substitution rides in front of the next panel's fused chain
+    (`panel_solve_kernel<NT, 1, true, 4>`, option `fused_ahead`, default on) instead of being a launch of its own.  Ragged last
+    panels of 1, 2, 3 and 4 tile rows (NT = 1 ... 4), 1 156 right-hand-side columns: predict() with and without it, both
+    against the oracle with the one criterion."""
+    from conftest import posterior_tolerances
+    from linpde_gp_amd import problems
+    from oracle import workloads as owl
+    wl = problems.poisson_2d(n_side=n_side, n_bdry=n_bdry, m_side=34)
+    ref = owl.run(wl)
+    assert ctx.get_option("fused_ahead") == 1
+    try:
+        ctx.profile_reset(); ctx.profile_enable(True)
+        u, mean1, var1 = problems.condition_and_predict(wl)
+        prof = ctx.profile_get(); ctx.profile_enable(False)
+        ctx.set_option("fused_ahead", 0)
+        mean0, var0 = u.predict(wl.Xtest)
+    finally:
+        ctx.set_option("fused_ahead", 1)
+    ma, va = posterior_tolerances(ref["mean"], ref["var"])
+    assert np.max(np.abs(mean1 - ref["mean"])) <= ma and np.max(np.abs(var1 - ref["var"])) <= va
+    assert np.max(np.abs(mean0 - ref["mean"])) <= ma and np.max(np.abs(var0 - ref["var"])) <= va
+    np.testing.assert_allclose(mean1, mean0, rtol=0, atol=ma)
+    np.testing.assert_allclose(var1, var0, rtol=0, atol=va)
+    assert prof["panel_fused"]["launches"] >= (wl.n_total + 511) // 512
