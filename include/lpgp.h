@@ -206,6 +206,27 @@ int  lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info);
  * from `nblocks` on (the full view must be current) and clears the status: the matrix is again what it was before they
  * were declared, exactly as after lpgp_mat_pop_block.                                                                 */
 int  lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat);
+/* ONE CONDITIONING IN ONE CALL (round 4) -- `ConditionalGaussianProcess.from_observations / condition_on_observations`
+ * (_conditional.py:253-294, :392-394): declare the new block of n rows, assemble its block row of the Gram matrix --
+ * row[j] describes (L_new k L_j'^*)(X_new, X_j) for every earlier block j = 0 .. nrow - 2, row[nrow - 1] the diagonal block
+ * (L_new k L_new'^*)(X_new, X_new) (X1 = NULL there; F0 / F1 non-NULL: both point sets are tensor grids, the Kronecker path
+ * of lpgp_gram_assemble_grid) --, add the noise b.cov (a scalar variance, or noise_diag[n], or noise_dense[n x n], at most
+ * one of them), and factor: lazy != 0 enqueues the factorisation (lpgp_potrf_enqueue; status by lpgp_mat_check), lazy == 0
+ * factors and returns the status in *info.  On an error -- and on info != 0 -- the block is dropped again (lpgp_mat_pop_block):
+ * the matrix is what it was before the call.  The same launches as the separate calls, in the same order; what it saves
+ * is host time: nrow + 3 calls through the binding per conditioning (at N_tot ~ 1 000 a conditioning is bound by the
+ * host), and the synchronisation the noise upload of lpgp_mat_add_diag needs for its borrowed host vector (here the
+ * vector is staged into the matrix's own storage on an idle stream).  Single GPU and multi-GPU alike (multi-GPU: lazy
+ * must be 0).                                                                                                      */
+typedef struct lpgp_cond_block {
+  const lpgp_kdesc* kd;
+  int32_t ngroups;
+  const lpgp_pts* X1;               /* points of block j; NULL for the diagonal block (and for the Kronecker path) */
+  const lpgp_pts* const* F0;        /* Kronecker path: kd[0].d factor point sets of the new block ... */
+  const lpgp_pts* const* F1;        /* ... and of block j (NULL for the diagonal block) */
+} lpgp_cond_block;
+int  lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* X_new, const lpgp_cond_block* row, int32_t nrow,
+                        double noise_scalar, const double* noise_diag, const double* noise_dense, int32_t lazy, int32_t* info);
 int  lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block);
 int  lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks);
 /* x = G^{-1} b for nrhs right-hand sides, b_host (n x nrhs, column-major, in/out)      */

@@ -150,7 +150,9 @@ int pool_alloc(lpgp_ctx* ctx, void** out, size_t bytes, bool* fresh) {
   int best = -1;
   for (int i = 0; i < (int)ctx->pool.size(); ++i) {
     const auto& b = ctx->pool[i];
-    if (b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (1 << 20) && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = i;
+    // (slack of half the request + 64 KB: with 1 MB, an 18-KB request took the 1.2-MB buffer of the tile inverses of a small matrix,
+    //  whose own request then went to hipMalloc, and the overflowing pool to hipFree -- 0.18 ms per step at N_tot = 1 152)
+    if (b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (64 << 10) && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = i;
   }
   if (best >= 0) {
     *out = ctx->pool[best].p;
@@ -1105,6 +1107,51 @@ int lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat) {
   mat->has_w = 0;
   mat->has_r = 0;
   return 0;
+}
+
+int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* X_new, const lpgp_cond_block* row, int32_t nrow,
+                       double noise_scalar, const double* noise_diag, const double* noise_dense, int32_t lazy, int32_t* info) {
+  LPGP_CHECK(ctx && mat && row && n > 0, "lpgp_mat_condition: bad argument");
+  LPGP_CHECK(nrow == (int32_t)mat->blocks.size() + 1, "lpgp_mat_condition: %d row entries for %d earlier blocks", nrow, (int)mat->blocks.size());
+  LPGP_CHECK((noise_diag != nullptr) + (noise_dense != nullptr) + (noise_scalar != 0.0) <= 1, "lpgp_mat_condition: more than one form of noise");
+  LPGP_CHECK(lazy == 0 || !ctx->distributed(), "lpgp_mat_condition: lazy status on a single GPU only");
+  if (info) *info = 0;
+  const int bi = lpgp_mat_add_block(ctx, mat, n);
+  if (bi < 0) return bi;
+  int rc = 0;
+  for (int j = 0; j < nrow && rc == 0; ++j) {
+    const lpgp_cond_block& e = row[j];
+    if (e.F0)
+      rc = lpgp_gram_assemble_grid(ctx, e.kd, e.ngroups, e.F0, j == bi ? nullptr : e.F1, mat, bi, j);
+    else
+      rc = lpgp_gram_assemble(ctx, e.kd, e.ngroups, X_new, j == bi ? nullptr : e.X1, mat, bi, j);
+  }
+  if (rc == 0 && noise_scalar != 0.0) rc = lpgp_mat_add_diag(ctx, mat, bi, nullptr, noise_scalar);
+  if (rc == 0 && noise_dense) rc = lpgp_mat_add_dense(ctx, mat, bi, noise_dense);
+  if (rc == 0 && noise_diag) {
+    // the vector is staged into the block's own segment of the weights buffer (unused until the first solve, which is
+    // stream-ordered behind the kernel below) through a stream that is idle during conditionings: nothing waits for the
+    // panel stream, where an enqueued factorisation of the previous block may still be running
+    const lpgp_block& B = mat->blocks[bi];
+    hipStream_t sc = (ctx->s_upd_all && !ctx->single_stream && !ctx->distributed()) ? ctx->s_upd_all : ctx->s_main;
+    hipError_t e = hipMemcpyAsync(mat->w + B.poff, noise_diag, (size_t)B.n * sizeof(double), hipMemcpyHostToDevice, sc);
+    if (e == hipSuccess) e = hipStreamSynchronize(sc);
+    if (e != hipSuccess) {
+      set_error("lpgp_mat_condition: noise upload: %s", hipGetErrorString(e));
+      rc = -1;
+    } else {
+      rc = launch_add_diag(ctx->s_main, mat->a, mat->lr_cap, B.poff, B.n, mat->w + B.poff, 0.0, mat_layout(ctx));
+    }
+  }
+  int32_t h = 0;
+  if (rc == 0) rc = lazy ? lpgp_potrf_enqueue(ctx, mat) : lpgp_potrf(ctx, mat, &h);
+  if (rc != 0 || h != 0) {
+    // keep the error text of the failing step: lpgp_mat_pop_block succeeds and would not touch it, but be explicit
+    const std::string msg = lpgp::last_error();
+    if (lpgp_mat_pop_block(ctx, mat) != 0 || rc != 0) set_error("%s", msg.c_str());
+  }
+  if (info) *info = h;
+  return rc;
 }
 
 int lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block) {

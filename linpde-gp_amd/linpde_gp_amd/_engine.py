@@ -398,6 +398,41 @@ class GramMatrix:
         check(lib.lpgp_potrf(self.ctx._h, self._h, C.byref(info)), "lpgp_potrf")
         return info.value
 
+    def condition(self, n: int, X_new: "Points", row, noise_scalar: float = 0.0, noise_diag=None, noise_dense=None, lazy: bool = True) -> int:
+        """One conditioning in one call (`lpgp_mat_condition`): declare the block of `n` rows, assemble its block row --
+        `row` = [(kdesc, X_j or None)] for every earlier block j and, last, the diagonal block --, add the noise, factor
+        (`lazy`: enqueue).  Returns the factorisation status (0 when lazy).  On failure -- an error, or a status != 0 --
+        the block has been dropped again."""
+        arr = (_lib.CondBlock * len(row))()
+        keep = []
+        for e, (kdesc, X1) in zip(arr, row):
+            kd = _kdesc_array(kdesc)
+            keep.append(kd)
+            e.kd, e.ngroups = C.cast(kd, C.POINTER(_lib.KDesc)), len(kd)
+            if X_new.grid_factors is not None and (X1 is None or X1.grid_factors is not None):
+                F0 = (C.c_void_p * len(X_new.grid_factors))(*[f._h for f in X_new.grid_factors])
+                keep.append(F0)
+                e.F0 = C.cast(F0, C.POINTER(C.c_void_p))
+                if X1 is not None:
+                    F1 = (C.c_void_p * len(X1.grid_factors))(*[f._h for f in X1.grid_factors])
+                    keep.append(F1)
+                    e.F1 = C.cast(F1, C.POINTER(C.c_void_p))
+            elif X1 is not None:
+                e.X1 = X1._h
+        nd = None if noise_diag is None else np.ascontiguousarray(noise_diag, dtype=np.double)
+        nD = None if noise_dense is None else np.ascontiguousarray(noise_dense, dtype=np.double)
+        if nd is not None and nd.shape != (int(n),):
+            raise ValueError("diagonal has the wrong length")
+        if nD is not None and nD.shape != (int(n), int(n)):
+            raise ValueError("dense noise block has the wrong shape")
+        info = C.c_int32()
+        check(lib.lpgp_mat_condition(self.ctx._h, self._h, int(n), X_new._h, arr, len(arr), float(noise_scalar),
+                                     as_pd(nd) if nd is not None else None, as_pd(nD) if nD is not None else None, int(bool(lazy)), C.byref(info)),
+              "lpgp_mat_condition")
+        if info.value == 0:
+            self.block_sizes.append(int(n))
+        return info.value
+
     def potrf_enqueue(self) -> None:
         """The factorisation enqueued, no host synchronisation (`lpgp_potrf_enqueue`): its status is read by `check`."""
         check(lib.lpgp_potrf_enqueue(self.ctx._h, self._h), "lpgp_potrf_enqueue")

@@ -38,6 +38,11 @@ class KDesc(C.Structure):
     ]
 
 
+class CondBlock(C.Structure):
+    """`lpgp_cond_block` (include/lpgp.h): one entry of the block row a conditioning assembles."""
+    _fields_ = [("kd", C.POINTER(KDesc)), ("ngroups", C.c_int32), ("X1", C.c_void_p), ("F0", C.POINTER(C.c_void_p)), ("F1", C.POINTER(C.c_void_p))]
+
+
 # int fn(void* user, int32 op, void* buf, int64 bytes, int32 root)   (lpgp_host_exchange_fn)
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32)
 
@@ -100,6 +105,7 @@ def _load() -> C.CDLL:
     sig("lpgp_potrf", C.c_int, vp, vp, C.POINTER(i32))
     sig("lpgp_potrf_enqueue", C.c_int, vp, vp)
     sig("lpgp_mat_check", C.c_int, vp, vp, C.POINTER(i32), C.POINTER(i32))
+    sig("lpgp_mat_condition", C.c_int, vp, vp, i64, vp, C.POINTER(CondBlock), i32, dbl, pd, pd, i32, C.POINTER(i32))
     sig("lpgp_mat_truncate", C.c_int, vp, vp, i32)
     sig("lpgp_potrs", C.c_int, vp, vp, pd, i64)
     sig("lpgp_solve_weights", C.c_int, vp, vp, pd, pd)
@@ -137,7 +143,7 @@ EXPORTED = [
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_pop_block", "lpgp_mat_set_view", "lpgp_mat_num_blocks",
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
-    "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
+    "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_test_panel_solve", "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64",

@@ -303,21 +303,28 @@ class ConditionalGaussianProcess(GaussianProcess):
         state.use(len(old_blocks))
         mat = state.mat
         base = prior.cov
-        bi = mat.add_block(new_block.points.n)
-        state.invalidate()           # also on the rollback paths below: the parent's next predict must solve again
-        assert bi == len(old_blocks)
-        try:
-            info = cls._assemble_and_factor(mat, base, bi, old_blocks, new_block, lazy)
-        except BaseException:
-            # a failed conditioning leaves the object it was called on intact (as in the reference):
-            # drop the block again; the leading factor was never touched
-            try:
-                mat.pop_block()
-            except Exception:  # noqa: BLE001  (the original error is the one to report)
-                pass
-            raise
+        state.invalidate()           # the device drops the resident weights / residual with the new block (also when it is rolled back)
+        # ONE call through the binding per conditioning (`lpgp_mat_condition`): the block row of the Gram matrix --
+        # lower-left blocks (L_new k L_j'^*)(X_new, X_j) (`_conditional.py:270`), diagonal block --, the measurement noise
+        # gram + b.cov (`_conditional.py:392-394`) and the factorisation.  A failed conditioning leaves the object it was
+        # called on intact, as in the reference: the library drops the new block again, the leading factor is never touched.
+        row = [(_lowered(base, new_block.coeffs, ob.coeffs), ob.points) for ob in old_blocks]
+        row.append((_lowered(base, new_block.coeffs, new_block.coeffs), None))
+        n = new_block.points.n
+        scalar, diag, dense = 0.0, None, None
+        if new_block.b is not None and isinstance(new_block.b, randvars.Normal):
+            if new_block.b.cov_diag is not None:
+                diag = np.ascontiguousarray(new_block.b.cov_diag, dtype=np.double)
+            else:
+                cov = np.asarray(new_block.b.cov).reshape(n, n)
+                if np.any(cov - np.diag(np.diag(cov)) != 0.0):
+                    dense = cov
+                else:
+                    diag = np.ascontiguousarray(np.diag(cov), dtype=np.double)
+            if diag is not None and diag.size and np.all(diag == diag.flat[0]):
+                scalar, diag = float(diag.flat[0]), None          # sigma^2 I: nothing to upload
+        info = mat.condition(n, new_block.points, row, noise_scalar=scalar, noise_diag=diag, noise_dense=dense, lazy=lazy)
         if info != 0:
-            mat.pop_block()
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
         state.blocks.append(new_block)
@@ -326,28 +333,6 @@ class ConditionalGaussianProcess(GaussianProcess):
         # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
         # in a chain of conditionings only the last object's weights are ever needed
         return cls(prior=prior, blocks=blocks, state=state, representer_weights=None)
-
-    @staticmethod
-    def _assemble_and_factor(mat, base, bi, old_blocks, new_block, lazy=False) -> int:
-        # lower-left blocks  (L_new k L_j'^*)(X_new, X_j)   (`_conditional.py:270`)
-        for bj, ob in enumerate(old_blocks):
-            mat.assemble(_lowered(base, new_block.coeffs, ob.coeffs), new_block.points, ob.points, bi, bj)
-        mat.assemble(_lowered(base, new_block.coeffs, new_block.coeffs), new_block.points, None, bi, bi)
-        # measurement noise  gram + b.cov   (`_conditional.py:392-394`)
-        if new_block.b is not None and isinstance(new_block.b, randvars.Normal):
-            n = new_block.points.n
-            if new_block.b.cov_diag is not None:
-                mat.add_diag(bi, np.ascontiguousarray(new_block.b.cov_diag))
-            else:
-                cov = np.asarray(new_block.b.cov).reshape(n, n)
-                if np.any(cov - np.diag(np.diag(cov)) != 0.0):
-                    mat.add_dense(bi, cov)
-                else:
-                    mat.add_diag(bi, np.ascontiguousarray(np.diag(cov)))
-        if lazy:
-            mat.potrf_enqueue()          # status: `_DeviceState.verify`, at the first use of the factor
-            return 0
-        return mat.potrf()
 
     def __init__(self, *, prior, blocks, state, representer_weights, test_coeffs=None):
         self._prior = prior
