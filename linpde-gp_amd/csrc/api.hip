@@ -451,6 +451,8 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   for (size_t r = 0; r < ctx->ipc_peer.size(); ++r)
     if ((int)r != ctx->rank && ctx->ipc_peer[r]) (void)hipIpcCloseMemHandle(ctx->ipc_peer[r]);
   if (ctx->ipc_window) (void)hipFree(ctx->ipc_window);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->ev_ipc[i]) (void)hipEventDestroy(ctx->ev_ipc[i]);
   if (ctx->d_pack) (void)hipFree(ctx->d_pack);
   for (int i = 0; i < 2; ++i)
     if (ctx->d_panel[i]) (void)hipFree(ctx->d_panel[i]);

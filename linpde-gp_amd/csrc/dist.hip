@@ -156,22 +156,33 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
   if (ctx->ipc()) {
     // direct-peer transport.  The pieces of one exchange are laid out back to back in every rank's window (same
     // offsets everywhere); an exchange that does not fit is cut into rounds.  Per round:
-    //   barrier A  every rank has copied the previous round out of its window (its stream is drained first)
-    //   push       each root copies its pieces into the window of every peer, device to device, and drains its stream
+    //   wait       this rank's copy-out of the PREVIOUS round of this window has completed (an event, not a drain)
+    //   barrier A  ... on every rank: the window may be written again
+    //   push       each root copies its pieces into the window of every destination, device to device, and waits for them
     //   barrier B  all pushes have landed
-    //   copy out   window -> destination buffers, asynchronously on `st`
+    //   copy out   window -> destination buffers, asynchronously on `st`; its completion is the window's event
+    // Round 4: every rank's window is used as TWO halves, one per exchange stream -- the exchanges of the panel stream
+    // (diagonal blocks, gathers, the head of a split gather) in the lower half, the bulk exchanges of the exchange stream
+    // (the tail of a split gather) in the upper one -- so that an exchange waits for ITS OWN previous copy-out only.
+    // (Until round 3 the one window was shared by both streams and every exchange drained the panel stream AND the
+    // exchange stream before a peer could push again: the look-ahead could hide none of it.)  The barriers still travel
+    // over the control plane: this transport is the fallback for boxes where RCCL cannot be brought up.
     auto barrier = [&]() -> int {
       int v = 0;
       LPGP_CHECK(ctx->host_xfer(ctx->host_xfer_user, 1, &v, (int64_t)sizeof(int), 0) == 0, "ipc transport: barrier failed");
       return 0;
     };
-    // ONE window per rank, shared by the exchanges of every stream: with the split gather the head exchange (panel stream)
-    // queues its copy-out asynchronously and the tail exchange (exchange stream) follows at once -- before a peer may push
-    // into this window again, EVERY stream that can hold a pending copy-out is drained, not just `st`
-    auto drain = [&]() -> int {
-      LPGP_HIP(hipStreamSynchronize(st));
-      if (ctx->s_main != st) LPGP_HIP(hipStreamSynchronize(ctx->s_main));
-      if (ctx->s_comm && ctx->s_comm != st) LPGP_HIP(hipStreamSynchronize(ctx->s_comm));
+    const int half = (bulk && ctx->s_comm && st == ctx->s_comm) ? 1 : 0;
+    const size_t wdoubles = ctx->ipc_window_doubles / 2, woff = (size_t)half * wdoubles;
+    if (!ctx->ev_ipc[half]) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ipc[half], hipEventDisableTiming));
+    auto window_free = [&]() -> int {
+      if (ctx->ipc_copyout_pending[half]) LPGP_HIP(hipEventSynchronize(ctx->ev_ipc[half]));
+      ctx->ipc_copyout_pending[half] = 0;
+      return 0;
+    };
+    auto copied_out = [&]() -> int {
+      LPGP_HIP(hipEventRecord(ctx->ev_ipc[half], st));
+      ctx->ipc_copyout_pending[half] = 1;
       return 0;
     };
     size_t i = 0;
@@ -179,7 +190,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       // one round: pieces [i, j) (a piece larger than the window travels in slices)
       size_t used = 0, j = i;
       std::vector<size_t> offs;
-      while (j < pieces.size() && used + pieces[j].count <= ctx->ipc_window_doubles) {
+      while (j < pieces.size() && used + pieces[j].count <= wdoubles) {
         offs.push_back(used);
         used += pieces[j].count;
         ++j;
@@ -187,24 +198,25 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       if (j == i) {
         // a single piece exceeds the window: slices of the window's size
         const Piece& p = pieces[i];
-        for (size_t o = 0; o < p.count; o += ctx->ipc_window_doubles) {
-          const size_t n = std::min(ctx->ipc_window_doubles, p.count - o);
-          LPGP_TRY(drain());
+        for (size_t o = 0; o < p.count; o += wdoubles) {
+          const size_t n = std::min(wdoubles, p.count - o);
+          LPGP_TRY(window_free());
           LPGP_TRY(barrier());
           if (p.root == ctx->rank) {
             for (int peer = 0; peer < ctx->world; ++peer)
               if (peer != ctx->rank && p.to(peer))
-                LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer], p.buf + o, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer] + woff, p.buf + o, n * sizeof(double), hipMemcpyDeviceToDevice, st));
             LPGP_HIP(hipStreamSynchronize(st));
           }
           LPGP_TRY(barrier());
           if (p.root != ctx->rank && p.to(ctx->rank))
-            LPGP_HIP(hipMemcpyAsync(p.buf + o, ctx->ipc_window, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            LPGP_HIP(hipMemcpyAsync(p.buf + o, ctx->ipc_window + woff, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+          LPGP_TRY(copied_out());
         }
         ++i;
         continue;
       }
-      LPGP_TRY(drain());
+      LPGP_TRY(window_free());
       LPGP_TRY(barrier());
       bool pushed = false;
       for (size_t q = i; q < j; ++q) {
@@ -212,7 +224,7 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
         if (p.count == 0 || p.root != ctx->rank) continue;
         for (int peer = 0; peer < ctx->world; ++peer)
           if (peer != ctx->rank && p.to(peer))
-            LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer] + offs[q - i], p.buf, p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
+            LPGP_HIP(hipMemcpyAsync(ctx->ipc_peer[peer] + woff + offs[q - i], p.buf, p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
         pushed = true;
       }
       if (pushed) LPGP_HIP(hipStreamSynchronize(st));
@@ -220,8 +232,9 @@ static int bcast_pieces(lpgp_ctx* ctx, hipStream_t st, const std::vector<Piece>&
       for (size_t q = i; q < j; ++q) {
         const Piece& p = pieces[q];
         if (p.count == 0 || p.root == ctx->rank || !p.to(ctx->rank)) continue;
-        LPGP_HIP(hipMemcpyAsync(p.buf, ctx->ipc_window + offs[q - i], p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
+        LPGP_HIP(hipMemcpyAsync(p.buf, ctx->ipc_window + woff + offs[q - i], p.count * sizeof(double), hipMemcpyDeviceToDevice, st));
       }
+      LPGP_TRY(copied_out());
       i = j;
     }
   } else if (ctx->host_xfer) {
@@ -345,7 +358,7 @@ int dist_link_probe(lpgp_ctx* ctx, int64_t bytes, int32_t reps, double* out) {
   if (W <= 1 || (ctx->host_xfer && !ctx->ipc())) return 0;       // host-staged bring-up transport: nothing to measure
   hipStream_t st = ctx->s_main;
   size_t count = (size_t)bytes / sizeof(double);
-  if (ctx->ipc()) count = std::min(count, ctx->ipc_window_doubles / (size_t)W);
+  if (ctx->ipc()) count = std::min(count, ctx->ipc_window_doubles / 2 / (size_t)W);      // (lower half: the exchanges of the panel stream)
   out[W * W + W + 1] = (double)(count * sizeof(double));      // bytes per message actually moved (the IPC window may cap the request)
   void *ps = nullptr, *pr = nullptr;
   const size_t sb = count * sizeof(double), rb = sb * (size_t)(W - 1);

@@ -163,7 +163,9 @@ struct lpgp_ctx {
   // IPC handle; a root pushes its pieces straight into the peers' windows (device-to-device copies over xGMI / inside
   // the GPU), the host exchange above only carries the barriers between the phases of an exchange
   double* ipc_window = nullptr;               // this rank's window
-  size_t ipc_window_doubles = 0;
+  size_t ipc_window_doubles = 0;              // used as two halves: [0]: exchanges of the panel stream, [1]: bulk exchanges of the exchange stream
+  hipEvent_t ev_ipc[2] = {nullptr, nullptr};  // completion of the last copy-out of each half (the half may be pushed into again after it)
+  int ipc_copyout_pending[2] = {0, 0};
   std::vector<double*> ipc_peer;              // window of rank r as mapped here (own window for r == rank)
   bool ipc() const { return !ipc_peer.empty(); }
   bool distributed() const { return nccl_comm != nullptr || host_xfer != nullptr || dist_broken; }
