@@ -190,11 +190,11 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
       // instructions, ~450 cycles per pivot); the arithmetic, its order and its rounding are unchanged.
       static_for<0, 16>([&](auto J_) {
         constexpr int j = decltype(J_)::value;
-        double piv = bcast16<j>(row[j]);
-        if (!(piv > 0.0)) {
-          if (!bad) bad = j0 + j + 1;
-          piv = 1.0;
-        }
+        const double piv = bcast16<j>(row[j]);
+        // (no test here: a pivot that is not positive turns into a NaN on the diagonal of L -- rsq of a negative number,
+        //  0 * inf -- and every later pivot of the tile with it; the first one is found AFTER the loop, once per block.
+        //  Rounds 1-3 tested and replaced the pivot inside the loop: a compare and eight selects per pivot on the wave
+        //  whose instruction count IS the duration of the kernel.)
         // inv = piv^{-1/2}: hardware estimate + one Newton step; l = piv*inv refined once more; inv kept consistent with
         // the refined l.  (Round 3 tried scaling the column with the once-refined inv and refining only the diagonal entry,
         // off the pivot-to-pivot chain: four dependent fp64 operations fewer per pivot, 41 -> 39 us per tile.  The tile's own
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
         l = fma(0.5 * inv, res, l);
         inv = fma(inv, -0.5 * inv * inv * res, inv);       // keep inv consistent with the refined l
         row[j] = (i == j) ? l : row[j] * inv;
-        x[j] = (j >= c) ? x[j] * inv : 0.0;                // (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]
+        x[j] = x[j] * inv;                                  // (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j]; exactly 0 for j < c
         static_for<j + 1, 16>([&](auto K_) {
           constexpr int k = decltype(K_)::value;
           const double lkj = bcast16<k>(row[j]);           // L[k][j]
@@ -223,7 +223,6 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           asm volatile("" : "+v"(x[k]), "+v"(row[k]));
         });
       });
-      if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
       if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -231,6 +230,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
           sD[jb * 256 + c * 16 + k] = x[k];
         }
       }
+      {
+        // first pivot of the block that was not positive: its diagonal entry of L is not a finite positive number
+        const double dg = s[(j0 + i) * TL + j0 + i];
+        const unsigned long long notpd = __builtin_amdgcn_ballot_w64(lane < 16 && !(dg > 0.0 && dg < 1.0e300));
+        if (notpd != 0ull) bad = j0 + __builtin_ctzll(notpd) + 1;
+      }
+      if (bad && lane == 0) atomicCAS(info, 0, info_base + bad);
 #ifdef LPGP_TILE_STAMP
       { unsigned long long tC_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tC_) :: "memory"); ts_[6] += tC_ - tA_; }
 #endif
