@@ -97,6 +97,8 @@ struct lpgp_ctx {
   int64_t nb = 512;                // panel width of the blocked Cholesky
   int64_t nb_outer_solve = 4096;   // forward substitution: rows below an outer block of this many rows are updated once per block (two-level scheme, potrf.hip); 0: plain right-looking
   int scoped_gather = 1;           // Pr, Pc > 1 grids: a panel's rows go only to the process row / column whose updates read them (0: to everyone, rounds 1-3)
+  int panel_lds_extra = 0;         // bytes of LDS a fused panel launch asks for beyond its own 69 632 (set by the two-level forward substitution around its launches)
+  int panel_exclusive = 1;         // two-level forward substitution: its panel chains wait for the tail of the long update instead of slipping into it (0: rounds' 4 first behaviour)
   int fused_ahead_min_us = 800;    // ... while the remainder update is estimated at least this long (the fused launch shares its CUs with the update for most of the update's duration)
   int fused_ahead = 1;             // forward substitution: the look-ahead update rides in front of the next fused panel chain (one launch; 0: a launch of its own, rounds 1-3)
   int small_ring2 = 32;            // rank-128 in-panel updates of at least this many 128-tiles run on the two-stage ring of the 64 x 64 kernel (four workgroups per CU); 0: never

@@ -622,6 +622,8 @@ static int trsm_lower_two_level(lpgp_ctx* ctx, lpgp_mat* mat, int T, double* v, 
   };
   bool have_upd_event = false;
   int it = 0;
+  struct PadGuard { lpgp_ctx* c; ~PadGuard() { c->panel_lds_extra = 0; } } pad_guard{ctx};
+  ctx->panel_lds_extra = ctx->panel_exclusive ? 20480 : 0;       // (solve_panel.h: the inner panel chains do not slip into the long outer updates)
   for (int q0 = 0; q0 < T; q0 += NBt, ++it) {
     const int q1 = (q0 + NBt < T) ? q0 + NBt : T;
     // inner: the block's own rows, right-looking by fused panels
@@ -694,6 +696,9 @@ int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, int
   // of its own the look-ahead update took those slots and the panel chain behind it starved until the remainder update
   // drained: the update stream idled 57-95 us per panel.  Kernel traces: profiles/r04_predict_fused_ahead.txt.)  The fused
   // kernel shares its CUs with the update for most of the update's duration, so it pays only while the update is long.
+  static const int pad_blocked = [] { const char* e = std::getenv("LPGP_PANEL_LDS_EXTRA_BLOCKED"); return e ? std::atoi(e) : 0; }();   // (measurement aid)
+  struct PadGuard { lpgp_ctx* c; ~PadGuard() { c->panel_lds_extra = 0; } } pad_guard{ctx};
+  ctx->panel_lds_extra = pad_blocked;
   const bool ahead_ok = fused && la && nbt == 4 && ctx->fused_ahead != 0;
   bool solved = false;                      // the panel at the top of the loop has been solved by the previous iteration's fused launch
   for (int p0 = 0; p0 < T; p0 += nbt, ++it) {

@@ -303,9 +303,15 @@ __global__ __launch_bounds__(256 * RG, 1) void panel_solve_kernel(PanelSolveArgs
 
 template <int NT, int RG, bool KFAST, int NP = 0>
 int launch_panel_solve_rg(lpgp_ctx* ctx, hipStream_t stream, const PanelSolveArgs& a, int64_t cols) {
+  // ctx->panel_lds_extra: LDS the launch asks for beyond what the kernel uses (69 632 B).  With it (20 480 B: 90 112 B in all) a
+  // workgroup no longer fits into the room ONE retiring gemm3 workgroup leaves on a CU (36.9 KB + the 49 KB free beside three of
+  // them), so beside a long three-resident update the chain waits for that update's tail instead of running inside it -- see
+  // trsm_lower_two_level (round 4: without the 78 spilled SGPRs the kernel takes 152 registers, fits such a hole, and c4's
+  // prediction got 3 % SLOWER: the chain ran beside the update at a fraction of its speed and took the update's slots with it).
   const size_t shmem = (size_t)(RG * 32 * 64 + TSV_RING) * sizeof(double);
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG, KFAST, NP>), shmem));
-  hipLaunchKernelGGL((panel_solve_kernel<NT, RG, KFAST, NP>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem, stream, a);
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_solve_kernel<NT, RG, KFAST, NP>), shmem + 20480));
+  hipLaunchKernelGGL((panel_solve_kernel<NT, RG, KFAST, NP>), dim3((unsigned)(cols / (16 * RG))), dim3(256 * RG), shmem + (size_t)ctx->panel_lds_extra,
+                     stream, a);
   LPGP_HIP(hipGetLastError());
   return 0;
 }
