@@ -254,11 +254,12 @@ def test_scoped_panel_gather_on_2d_grids(grid, port, transport):
         got[int(line[1])] = (float(line[2]), float(line[3]))
     scoped, full = sum(v[0] for v in got.values()), sum(v[1] for v in got.values())
     assert all(v[0] <= v[1] for v in got.values()), got
-    # expected share of the panel bytes: (1/Pr + 1/Pc - 1/(Pr Pc)) / (1 - 1/(Pr Pc)) on average over the ranks -- 2 x 2: 1.0 of
-    # them for the off-diagonal ranks and 1/3 for the diagonal ones (2/3 overall), 2 x 4: 4/7 -- plus the diagonal blocks and
-    # tile inverses, which every rank receives either way (a quarter of the traffic at this size)
+    # expected share of the panel bytes, averaged over the ranks: a rank READS 1/Pr + 1/Pc - 1/(Pr Pc) of a panel and owns
+    # 1/(Pr Pc) of it, so it receives (1/Pr + 1/Pc - 2/(Pr Pc)) against 1 - 1/(Pr Pc) to everyone -- 2 x 2: 2/3 (nothing saved
+    # on the off-diagonal ranks, 1/3 on the diagonal ones), 2 x 4: 4/7 -- plus the diagonal blocks and tile inverses, which
+    # every rank receives either way (a quarter of the traffic at this size)
     pr, pc = grid
-    share = (1.0 / pr + 1.0 / pc - 1.0 / (pr * pc)) / (1.0 - 1.0 / (pr * pc))
+    share = (1.0 / pr + 1.0 / pc - 2.0 / (pr * pc)) / (1.0 - 1.0 / (pr * pc))
     print(f"\n[scoped gather {pr} x {pc}, {transport}] bytes received in the factorisations, all ranks: {scoped:.3e} scoped vs {full:.3e} to everyone "
           f"= {scoped / full:.3f} (panel share expected {share:.3f}); per rank {got}")
     assert scoped <= (share + 0.5 * (1.0 - share)) * full, (scoped, full, share)
