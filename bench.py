@@ -643,7 +643,9 @@ def main():
         },
         "phase_ms": {"condition": max(r_[0] for r_ in phase_rows), "predict": max(r_[1] for r_ in phase_rows),
                      "note": "host stamps around the conditioning chain (assembly, block appends, factorisation) and the prediction "
-                             "(cross-covariance, streamed solve, read-outs) of two extra steps; best of two, max over ranks"},
+                             "(cross-covariance, streamed solve, read-outs) of two extra steps with a device synchronisation between the phases "
+                             "(an un-instrumented step has none: the factorisation is enqueued and the prediction follows it on the device, so "
+                             "the two phases add up to more than ms_per_step); best of two, max over ranks"},
         "posterior": {"mean_max": float(np.max(mean)), "var_min": float(np.min(var)), "var_max": float(np.max(var))},
     }
     if configs:

@@ -232,8 +232,8 @@ def analytic_solution(wl: Workload):
 def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var: bool = True, stamps: list | None = None):
     """The canonical user sequence (`experiments/0001_poisson_dirichlet_2d.ipynb` cells 6-22):
     condition block by block, then posterior mean and marginal variance on the test grid.
-    `stamps`: receives `time.perf_counter()` at the start, after the last conditioning (every conditioning ends with the
-    read-back of the factorisation status, so the device is idle there) and at the end."""
+    `stamps`: receives `time.perf_counter()` at the start, after the last conditioning (behind a device synchronisation: the
+    factorisation is only enqueued by then, `config.lazy_factorization`) and at the end."""
     import time
 
     from .. import randvars
@@ -254,6 +254,10 @@ def condition_and_predict(wl: Workload, prior=None, device_arrays=None, want_var
         b = None if o.noise_var is None else randvars.Normal(np.zeros(Y.shape), np.full(n, o.noise_var))
         u = u.condition_on_observations(Y, X=X, L=operator_of(o.op, wl.d), b=b)
     if stamps is not None:
+        # instrumented steps only: wait for the device, so that the stamp separates the two phases ON THE DEVICE (with the lazy
+        # status check the host returns from the conditionings while the factorisation is still running)
+        from .._engine import default_context
+        default_context().sync()
         stamps.append(time.perf_counter())
     Xt = wl.Xtest if device_arrays is None else device_arrays["test"]
     if want_var:
