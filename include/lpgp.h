@@ -19,8 +19,9 @@ extern "C" {
 #endif
 
 #define LPGP_MAXD 4      /* input dimension of a tensor-product kernel            */
-#define LPGP_MAXT 64     /* terms of the expansion  sum_t c_t prod_d d^{n0} d'^{n1} k_d */
-#define LPGP_MAXG 4      /* summands of a sum kernel                              */
+#define LPGP_MAXT 256    /* terms of the expansion  sum_t c_t prod_d d^{n0} d'^{n1} k_d: every pair of second-order
+                          * operators in four dimensions (15 x 15 multi-indices) fits                     */
+#define LPGP_MAXG 16     /* summands of a sum kernel                              */
 
 /* LPGP_MATERN_ISO: ISOTROPIC half-integer Matern over all d input dimensions,
  * k(x,x') = kappa_nu(|| sqrt(2 nu) (x - x') / lengthscale ||)  (probnum `Matern` with
@@ -175,6 +176,10 @@ int  lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
 int  lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                              const lpgp_pts* const* F0, const lpgp_pts* const* F1,
                              lpgp_mat* mat, int32_t bi, int32_t bj);
+/* 1 if lpgp_gram_assemble_grid holds this sum (its tables of terms and of distinct 1-D matrices are fixed-size kernel
+ * arguments: 48 terms over all summands, 16 distinct 1-D matrices per dimension; product-form kernels only), 0 if the
+ * caller must assemble the block entry-wise from the flattened grids (lpgp_gram_assemble).                              */
+int  lpgp_kron_fits(const lpgp_kdesc* kd, int32_t ngroups);
 /* diagonal of block bi += v_host[i] (v_host may be NULL) + scalar                       */
 int  lpgp_mat_add_diag(lpgp_ctx* ctx, lpgp_mat* mat, int32_t bi, const double* v_host, double scalar);
 /* diagonal block bi += B_host (n_bi x n_bi, C-order, symmetric)                          */

@@ -943,6 +943,8 @@ int lpgp_gram_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, con
   return rc;       // asynchronous: consumers are ordered behind it on the main stream
 }
 
+int lpgp_kron_fits(const lpgp_kdesc* kd, int32_t ngroups) { return kron_fits(kd, ngroups) ? 1 : 0; }
+
 int lpgp_gram_assemble_grid(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* const* F0,
                             const lpgp_pts* const* F1, lpgp_mat* mat, int32_t bi, int32_t bj) {
   LPGP_CHECK(ctx && kd && F0 && mat, "lpgp_gram_assemble_grid: null argument");

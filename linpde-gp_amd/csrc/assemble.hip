@@ -63,6 +63,8 @@ struct LdsFactors {
   }
 };
 
+constexpr int FACT_MAXG = 4;     // the factor tables hold this many summands; sums with more take the table exponential
+
 // factors of the point this lane stands for (coordinate xp[j], `valid` false: treated as the origin) for every Matern
 // dimension of every product-form group; items (g, j) are dealt to the four waves.  Clears *fast if the range bound fails.
 template <int D>
@@ -85,13 +87,13 @@ __device__ __forceinline__ void stage_factors(const DevDesc* __restrict__ desc, 
   }
 }
 
-// FACTORS: the per-point exponential factors (`asm_factors`, off by default) need 2 x LPGP_MAXG * D * 2 * 64 doubles of LDS (32 KB
+// FACTORS: the per-point exponential factors (`asm_factors`, off by default) need 2 x FACT_MAXG * D * 2 * 64 doubles of LDS (32 KB
 // at D = 4); the default instantiation carries the 4-KB exponential table only (the generic kernel is the one that
 // takes everything the specialised kernels reject -- D >= 3, several groups, isotropic -- and ran at 4 / 3 workgroups per CU)
 template <int D, bool FACTORS>
 __global__ __launch_bounds__(256) void assemble_kernel(const DevDesc* __restrict__ desc, AsmArgs a) {
   __shared__ double sx1[D][AT];
-  __shared__ double sfr[FACTORS ? LPGP_MAXG * D * 2 * AT : 1], sfc[FACTORS ? LPGP_MAXG * D * 2 * AT : 1];
+  __shared__ double sfr[FACTORS ? FACT_MAXG * D * 2 * AT : 1], sfc[FACTORS ? FACT_MAXG * D * 2 * AT : 1];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];      // table of lpgp_exp_neg (eval_entries.h)
   __shared__ int s_fast;
   const int tr = blockIdx.x % a.tiles_r;   // row tile fastest: consecutive blocks write neighbouring rows
@@ -498,7 +500,7 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   if (a.tiles_r == 0 || a.tiles_c == 0) return 0;
   static const int diag = [] { const char* e = std::getenv("LPGP_ASM_DIAG"); return e ? std::atoi(e) : 0; }();
-  a.flags = (ctx->asm_factors ? 1 : 0) | ((diag & 3) << 1);
+  a.flags = ((ctx->asm_factors && host_desc.ngroups <= FACT_MAXG) ? 1 : 0) | ((diag & 3) << 1);
   dim3 grid((unsigned)((int64_t)a.tiles_r * a.tiles_c));
   double entries = lower_only ? 0.5 * (double)n0 * ((double)n0 + 1.0) : (double)n0 * (double)n1;
   {
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   // per-point exponential factors (see assemble_kernel): origin = the first row of this workgroup's row tile; the row
   // factors are computed once, the column factors per column tile, and a tile whose points lie more than FACT_TMAX scaled
   // units from the origin falls back to one exp per entry
-  __shared__ double sfr[FACTORS ? LPGP_MAXG * D * 2 * AT : 1], sfc[FACTORS ? LPGP_MAXG * D * 2 * AT : 1];
+  __shared__ double sfr[FACTORS ? FACT_MAXG * D * 2 * AT : 1], sfc[FACTORS ? FACT_MAXG * D * 2 * AT : 1];
   __shared__ int s_fast_r, s_fast_c[2];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
   const int tr = blockIdx.x % a.tiles_r, sp = blockIdx.x / a.tiles_r;
@@ -648,7 +650,7 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   MvArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
   a.v = v; a.part = part; a.nr = nr;
-  a.factors = ctx->asm_factors ? 1 : 0;
+  a.factors = (ctx->asm_factors && host_desc.ngroups <= FACT_MAXG) ? 1 : 0;
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
   a.splits = splits;
@@ -917,6 +919,34 @@ static void launch_kron_nu(dim3 grid, hipStream_t stream, const KronArgs& a) {
   else hipLaunchKernelGGL((kron_expand_kernel<D, KR_MAXU>), grid, dim3(256), 0, stream, a);
 }
 
+// Does the Kronecker path hold this sum (its term table and its per-dimension tables of distinct 1-D matrices are fixed-size
+// kernel arguments)?  Callers fall back to the entry-wise assembly of the flattened grids otherwise (lpgp_kron_fits).
+bool kron_fits(const lpgp_kdesc* kd, int ngroups) {
+  if (!kd || ngroups < 1 || ngroups > LPGP_MAXG) return false;
+  const int D = kd[0].d;
+  if (D < 1 || D > LPGP_MAXD) return false;
+  struct Key { int g, n0, n1; };
+  std::vector<Key> keys[LPGP_MAXD];
+  int nterms = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const lpgp_kdesc& K = kd[g];
+    if (K.d != D || K.family[0] == LPGP_MATERN_ISO || K.nterms < 0 || K.nterms > LPGP_MAXT) return false;
+    nterms += K.nterms;
+    if (nterms > KR_MAXT) return false;
+    for (int t = 0; t < K.nterms; ++t)
+      for (int d = 0; d < D; ++d) {
+        const int n0 = K.terms[t].n0[d], n1 = K.terms[t].n1[d];
+        bool found = false;
+        for (const Key& q : keys[d]) found = found || (q.g == g && q.n0 == n0 && q.n1 == n1);
+        if (!found) {
+          if ((int)keys[d].size() >= KR_MAXU) return false;
+          keys[d].push_back({g, n0, n1});
+        }
+      }
+  }
+  return true;
+}
+
 // F0[d] / F1[d]: device coordinate arrays of the grid factors (n0d[d] / n1d[d] points); work:
 // device scratch of at least kron_work_doubles(...) doubles.
 int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
@@ -948,7 +978,7 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
     LPGP_CHECK(K.d == D, "kron assembly: group %d has d=%d != %d", g, K.d, D);
     LPGP_CHECK(K.family[0] != LPGP_MATERN_ISO, "kron assembly: an isotropic Matern is not a product over dimensions");
     for (int t = 0; t < K.nterms; ++t) {
-      LPGP_CHECK(a.nterms < KR_MAXT, "kron assembly: more than %d terms", KR_MAXT);
+      LPGP_CHECK(a.nterms < KR_MAXT, "kron assembly: more than %d terms (lpgp_kron_fits tells beforehand)", KR_MAXT);
       const int ti = a.nterms++;
       a.coef[ti] = K.scale * K.terms[t].coef;
       for (int d = 0; d < D; ++d) {

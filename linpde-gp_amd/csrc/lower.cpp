@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <vector>
 
@@ -165,7 +166,7 @@ static void hermite_poly(int n, long double* out /* n+1 */) {
 
 int lower_kdesc(const lpgp_kdesc* kd, int ngroups, DevDesc* out) {
   LPGP_CHECK(kd != nullptr && ngroups >= 1 && ngroups <= LPGP_MAXG, "lower_kdesc: bad ngroups %d", ngroups);
-  std::memset(out, 0, sizeof(*out));
+  std::memset(out, 0, offsetof(DevDesc, coef));      // header and groups; the coefficient table (64 KB) is written where it is used
   const int d = kd[0].d;
   LPGP_CHECK(d >= 1 && d <= LPGP_MAXD, "lower_kdesc: d=%d out of range", d);
   out->d = d;

@@ -27,7 +27,7 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // r_d = |a_d (x_d - x'_d)|, E = r (Matern) or r^2/2 (ExpQuad); Poly_c dense nested-Horner
 // coefficient tensor.  Built on the host by lower_kdesc (lower.cpp).
 constexpr int MAXCLS = 16;         // parity classes (2^d, d <= 4)
-constexpr int MAXCOEF = 2048;      // coefficient doubles over all groups
+constexpr int MAXCOEF = 8192;      // coefficient doubles over all groups (only the used part is staged to the device)
 
 struct DevGroup {
   double scale;

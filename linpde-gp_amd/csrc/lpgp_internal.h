@@ -365,6 +365,7 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
                          int64_t col_off, int lower_only, const Layout2D& lay);
 size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d);
 constexpr int MV_RHS = 4;         // right-hand sides per pass of the matrix-free product (== MV_R in assemble.hip)
+bool kron_fits(const lpgp_kdesc* kd, int ngroups);
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
                   double* part, int splits, double* out);

@@ -356,8 +356,9 @@ class GramMatrix:
 
     def assemble(self, kdesc, X0: Points, X1: Points | None, bi: int, bj: int):
         arr = _kdesc_array(kdesc)
-        if X0.grid_factors is not None and (X1 is None or X1.grid_factors is not None):
-            # both point sets are tensor grids: sum of Kronecker products of 1-D kernel matrices
+        if X0.grid_factors is not None and (X1 is None or X1.grid_factors is not None) and lib.lpgp_kron_fits(arr, len(arr)):
+            # both point sets are tensor grids: sum of Kronecker products of 1-D kernel matrices (sums too long for
+            # its fixed-size tables are assembled entry-wise from the flattened grids like any other block)
             F0 = (C.c_void_p * len(X0.grid_factors))(*[f._h for f in X0.grid_factors])
             F1 = None if X1 is None else (C.c_void_p * len(X1.grid_factors))(*[f._h for f in X1.grid_factors])
             check(lib.lpgp_gram_assemble_grid(self.ctx._h, arr, len(arr), F0, F1, self._h, bi, bj),
@@ -409,7 +410,7 @@ class GramMatrix:
             kd = _kdesc_array(kdesc)
             keep.append(kd)
             e.kd, e.ngroups = C.cast(kd, C.POINTER(_lib.KDesc)), len(kd)
-            if X_new.grid_factors is not None and (X1 is None or X1.grid_factors is not None):
+            if X_new.grid_factors is not None and (X1 is None or X1.grid_factors is not None) and lib.lpgp_kron_fits(kd, len(kd)):
                 F0 = (C.c_void_p * len(X_new.grid_factors))(*[f._h for f in X_new.grid_factors])
                 keep.append(F0)
                 e.F0 = C.cast(F0, C.POINTER(C.c_void_p))

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LPGP_LIB", os.path.join(_HERE, "liblpgp.so"))     # $LPGP_LIB: a diagnostic build of the same library
 
-MAXD, MAXT, MAXG = 4, 64, 4
+MAXD, MAXT, MAXG = 4, 256, 16
 MATERN_HALFINT, EXPQUAD, MATERN_ISO = 1, 2, 3
 K_ASSEMBLE, K_SYRK, K_GEMM, K_POTRF_TILE, K_TRSM, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("assemble", "syrk_trailing", "gemm", "potrf_tile", "trsm_gemm", "syrk_panel", "gemm_small", "matvec", "syrk_lookahead",
@@ -120,6 +120,7 @@ def _load() -> C.CDLL:
     sig("lpgp_kernel_diag", C.c_int, vp, pk, i32, pd)
     sig("lpgp_kernel_matrix", C.c_int, vp, pk, i32, vp, vp, pd)
     sig("lpgp_gram_assemble_grid", C.c_int, vp, pk, i32, C.POINTER(vp), C.POINTER(vp), vp, i32, i32)
+    sig("lpgp_kron_fits", C.c_int, pk, i32)
     sig("lpgp_kernel_matvec", C.c_int, vp, pk, i32, vp, vp, pd, i64, pd)
     sig("lpgp_profile_enable", C.c_int, vp, i32)
     sig("lpgp_profile_reset", C.c_int, vp)
@@ -145,7 +146,7 @@ EXPORTED = [
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
-    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_profile_enable", "lpgp_profile_reset",
+    "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_kron_fits", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_test_panel_solve", "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64",
     "lpgp_probe_hbm_write",
 ]

@@ -205,11 +205,15 @@ def iso_order2(kd):
 expect_reject(iso_order2)
 
 
-def coef_overflow(kd):       # 4-D, degree 6 per dimension: 7^4 coefficients per class > the table
+def coef_overflow(kd):       # 4-D, degree 6 per dimension: 7^4 coefficients per parity class, four classes > the table
     kd.d = 4
     for j in range(4):
         kd.family[j], kd.p[j], kd.lengthscale[j] = _lib.MATERN_HALFINT, 6, 1.0
-    kd.nterms = 1
+    kd.nterms = 4
+    for t in range(4):
+        kd.terms[t].coef = 1.0
+        for j in range(4):
+            kd.terms[t].n0[j], kd.terms[t].n1[j] = int(j == t), 0
 
 
 expect_reject(coef_overflow)

@@ -180,6 +180,84 @@ def test_sum_kernel_and_3d(lp):
     assert _rel(L(L(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, lap, lap, X0, X1)) < 1e-12
 
 
+def _general_operator(d, rng, max_order=2):
+    """A general operator  sum_{|a| <= max_order} c_a d^a  (mixed derivatives included) and its oracle dictionary."""
+    import itertools
+    from linpde_gp_amd.linfuncops import diffops
+    from linpde_gp_amd.linfuncops.diffops._coefficients import MultiIndex, PartialDerivativeCoefficients
+    idx = [a for a in itertools.product(range(max_order + 1), repeat=d) if sum(a) <= max_order]
+    coef = {a: float(c) for a, c in zip(idx, rng.uniform(0.5, 1.5, len(idx)) * rng.choice([-1.0, 1.0], len(idx)))}
+    pdc = PartialDerivativeCoefficients({(): {MultiIndex(a): c for a, c in coef.items()}}, (d,), ())
+    return diffops.LinearDifferentialOperator(pdc, ((d,), ())), coef
+
+
+def test_long_sums_and_many_terms(lp):
+    """The reference's sums and operators are unbounded (`_jax_arithmetic.py:16-66`, `_tensor_product.py:38-67`); the
+    descriptor tables hold 16 summands and 256 terms per summand (round 3: 4 and 64): seven summands under a pair of
+    Laplacians, and a pair of GENERAL second-order operators in three dimensions (10 x 10 = 100 terms)."""
+    cf = lp.randprocs.covfuncs
+    from linpde_gp_amd.linfuncops import diffops
+    rng = np.random.default_rng(77)
+    X0, X1 = rng.uniform(-1, 1, size=(75, 2)), rng.uniform(-1, 1, size=(66, 2))
+    k, okern = None, []
+    for g in range(7):
+        s, l0, l1 = 0.3 + 0.2 * g, 0.6 + 0.15 * g, 1.4 - 0.1 * g
+        if g % 2:
+            kg = s * cf.TensorProduct(cf.ExpQuad((), lengthscales=l0), cf.Matern((), nu=2.5, lengthscales=l1))
+            okern.append((s, [("expquad", l0), ("matern", 2.5, l1)]))
+        else:
+            kg = s * cf.TensorProduct(cf.Matern((), nu=3.5, lengthscales=l0), cf.Matern((), nu=2.5, lengthscales=l1))
+            okern.append((s, [("matern", 3.5, l0), ("matern", 2.5, l1)]))
+        k = kg if k is None else k + kg
+    L = diffops.Laplacian((2,))
+    lap = {(2, 0): 1.0, (0, 2): 1.0}
+    assert _rel(L(L(k, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern, lap, lap, X0, X1)) < 1e-12
+    G = L(L(k, argnum=1), argnum=0).matrix(X0)
+    assert _rel(G, ocf.LkL(okern, lap, lap, X0, X0)) < 1e-12
+    # 100 terms
+    X0, X1 = rng.uniform(-1, 1, size=(70, 3)), rng.uniform(-1, 1, size=(40, 3))
+    k3 = 1.3 * cf.TensorProduct(*(cf.Matern((), nu=2.5, lengthscales=l) for l in (1.0, 1.7, 0.8)))
+    okern3 = [(1.3, [("matern", 2.5, 1.0), ("matern", 2.5, 1.7), ("matern", 2.5, 0.8)])]
+    A, ca = _general_operator(3, rng)
+    B, cb = _general_operator(3, rng)
+    assert len(ca) * len(cb) == 100
+    assert _rel(A(B(k3, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern3, ca, cb, X0, X1)) < 1e-12
+
+
+def test_grid_blocks_beyond_the_kronecker_tables(lp):
+    """A sum on tensor grids that does not fit the fixed-size tables of the Kronecker path (`lpgp_kron_fits`: 48 terms,
+    16 distinct 1-D matrices per dimension) is assembled entry-wise from the flattened grids -- round 3 raised an error --
+    in `matrix`-free conditioning and prediction alike: same Gram matrix as scattered copies of the same points."""
+    from linpde_gp_amd import domains
+    from linpde_gp_amd._lib import lib, make_kdesc_array
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(78)
+    k = (1.1 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.3), cf.Matern((), nu=3.5, lengthscales=0.9))
+         + 0.4 * cf.TensorProduct(cf.ExpQuad((), lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=1.6))
+         + 0.2 * cf.TensorProduct(cf.Matern((), nu=3.5, lengthscales=2.0), cf.ExpQuad((), lengthscales=0.7)))
+    A, ca = _general_operator(2, rng)          # 6 x 6 = 36 terms per summand, 108 in all
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), k)
+    Xg = domains.TensorProductGrid(np.linspace(-1.0, 1.0, 19), np.linspace(-0.5, 0.7, 23))
+    Xv = domains.TensorProductGrid(np.linspace(-0.9, 0.9, 7), np.linspace(-0.4, 0.6, 9))
+    Yg, Yv = rng.standard_normal(Xg.shape[:-1]), rng.standard_normal(Xv.shape[:-1])
+    Xt = rng.uniform(-0.5, 0.5, size=(30, 2))
+
+    def run(Xv_, Yv_, Xg_, Yg_):
+        u = prior.condition_on_observations(Yv_, X=Xv_, b=lp.randvars.Normal(np.zeros(Yv_.shape), np.full(Yv_.size, 1e-4)))
+        u = u.condition_on_observations(Yg_, X=Xg_, L=A, b=lp.randvars.Normal(np.zeros(Yg_.shape), np.full(Yg_.size, 1e-2)))
+        return (u.gram.todense(), *u.predict(Xt))
+    G1, m1, v1 = run(Xv, Yv, Xg, Yg)                                                           # grids
+    G0, m0, v0 = run(np.asarray(Xv).reshape(-1, 2), Yv.reshape(-1), np.asarray(Xg).reshape(-1, 2), Yg.reshape(-1))
+    np.testing.assert_allclose(G1, G0, rtol=0, atol=1e-13 * np.abs(G0).max())
+    assert _rel(m1, m0) < 1e-9 and _rel(v1, v0) < 1e-9
+    okern = [(1.1, [("matern", 2.5, 1.3), ("matern", 3.5, 0.9)]), (0.4, [("expquad", 1.0), ("matern", 2.5, 1.6)]),
+             (0.2, [("matern", 3.5, 2.0), ("expquad", 0.7)])]
+    Xgf = np.asarray(Xg).reshape(-1, 2)
+    n0 = Yv.size
+    Gpde = ocf.LkL(okern, ca, ca, Xgf, Xgf) + 1e-2 * np.eye(Xgf.shape[0])
+    assert _rel(G1[n0:, n0:], Gpde) < 1e-12
+
+
 # ---- (2) factor + solve --------------------------------------------------------------------
 def _poisson_blocks(nb, npde, rhs=2.0, noise=1e-8):
     """Small version of BASELINE config c3."""
