@@ -49,12 +49,13 @@ for j in range(n // T):
         X4[:, cs] = x
         rest = slice(16 * c + 16, T)
         W[:, rest] -= x @ L[rest, cs].T
+    dr = L.diagonal().max() / L.diagonal().min(); nm = np.abs(Linv).sum(1).max() * np.abs(L).sum(1).max()
     kt = np.linalg.cond(L); kb = max(np.linalg.cond(L[16*c:16*c+16, 16*c:16*c+16]) for c in range(8))
-    res.append((j, kt, kb, err(Xex), err(X1), err(X2), err(X3), err(X4)))
+    res.append((j, kt, kb, dr, nm, err(Xex), err(X1), err(X2), err(X3), err(X4)))
     # continue the factorisation with the LAPACK-quality panel
     A[(j + 1) * T:, s] = Xex
     A[(j + 1) * T:, (j + 1) * T:] -= Xex @ Xex.T
-print(" tile  cond(Ljj)  max cond(16-blk)   lapack     inv-prod   refined    blk-subst  blk-subst-refined")
-for r in res: print("%4d  %9.2e  %9.2e      %9.2e  %9.2e  %9.2e  %9.2e  %9.2e" % r)
+print(" tile  cond(Ljj)  max cond(16-blk) diag-ratio  inf-norm-cond  lapack     inv-prod   refined    blk-subst  blk-subst-refined")
+for r in res: print("%4d  %9.2e  %9.2e   %9.2e  %9.2e   %9.2e  %9.2e  %9.2e  %9.2e  %9.2e" % r)
 r = np.array(res)
-print("max   %9.2e  %9.2e      %9.2e  %9.2e  %9.2e  %9.2e  %9.2e" % tuple(r[:, 1:].max(0)))
+print("max   %9.2e  %9.2e   %9.2e  %9.2e   %9.2e  %9.2e  %9.2e  %9.2e  %9.2e" % tuple(r[:, 1:].max(0)))
