@@ -400,6 +400,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_FUSED_SOLVE")) ctx->fused_solve = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_GEMM3")) ctx->gemm3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_SMALL_RING2")) ctx->small_ring2 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_SMALL_TILES_MAX")) ctx->small_tiles_max = std::atoi(e);
   if (const char* e = std::getenv("LPGP_FUSED_AHEAD")) ctx->fused_ahead = std::atoi(e);
   if (const char* e = std::getenv("LPGP_PANEL_EXCLUSIVE")) ctx->panel_exclusive = std::atoi(e);
   if (const char* e = std::getenv("LPGP_FUSED_AHEAD_MIN_US")) ctx->fused_ahead_min_us = std::atoi(e);
