@@ -169,14 +169,25 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(sha, kernel_symbol, profiles_dir=None):
+def profile_tag(workload, n_side=128, m_side=64):
+    """Tag of the committed rocprofv3 collection (`profiles/rNN_bench_<tag>_summary.json`) of a bench workload: the BASELINE
+    configurations only; None for any other workload or size (no PMC passes of that command exist)."""
+    if workload == "poisson2d":
+        return {(128, 64): "c3", (256, 128): "c4"}.get((n_side, m_side))
+    return {"poisson1d": "c2", "heat1d": "c5"}.get(workload)
+
+
+def pmc_traffic(sha, kernel_symbol, profiles_dir=None, tag="c3"):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of the SAME command
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; scratch/collect_profiles.sh collects them and records
-    the command and the source identity it ran on).  A summary collected on OTHER kernel sources is not reported as
+    the command and the source identity it ran on; `tag` names the configuration, see profile_tag).  A summary collected on OTHER kernel sources is not reported as
     `traffic` (it is named under `traffic_stale`)."""
     out = {"traffic": None, "traffic_source": None}
+    if tag is None:            # a workload without a committed PMC collection: nothing to report, nothing stale to name
+        out["traffic_note"] = "no rocprofv3 --pmc collection of this workload is committed (profiles/: c2, c3, c4, c5)"
+        return out
     profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
-    for path in sorted(glob.glob(os.path.join(profiles_dir, "r*_bench_c3_summary.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(profiles_dir, f"r*_bench_{tag}_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 summ = json.load(f)
@@ -628,7 +639,7 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            **pmc_traffic(sha, roof_symbol),
+            **pmc_traffic(sha, roof_symbol, tag=profile_tag(args.workload, args.n_side, args.m_side) if not distributed else None),
             "launches_per_step": syrk["launches"] / max(args.steps, 1),
             "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
         },

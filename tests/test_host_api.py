@@ -342,6 +342,14 @@ def test_bench_reports_pmc_traffic_only_from_the_running_sources(tmp_path):
     write("r05_bench_c3_summary.json", sha, sym, 1.7e9)
     got = bench.pmc_traffic(sha, sym, str(tmp_path))
     assert got["traffic"] == 1.7e9 and got["traffic_collected_at_csrc"] == sha and "r05_" in got["traffic_source"]
+    # the collection must be of the SAME bench command: c2 / c4 / c5 have summaries of their own, any other workload none
+    assert bench.pmc_traffic(sha, sym, str(tmp_path), tag="c2")["traffic"] is None
+    write("r05_bench_c2_summary.json", sha, sym, 4.6e8)
+    assert bench.pmc_traffic(sha, sym, str(tmp_path), tag="c2")["traffic"] == 4.6e8
+    assert bench.pmc_traffic(sha, sym, str(tmp_path), tag=None) == {"traffic": None, "traffic_source": None,
+                                                                     "traffic_note": bench.pmc_traffic(sha, sym, str(tmp_path), tag=None)["traffic_note"]}
+    assert [bench.profile_tag(*a) for a in (("poisson2d", 128, 64), ("poisson2d", 256, 128), ("poisson2d", 64, 32), ("poisson1d",), ("heat1d",),
+                                             ("scattered2d",), ("poisson1d_c1",), ("heat_reference",))] == ["c3", "c4", None, "c2", "c5", None, None, None]
 
 
 def test_bench_gpus_n_without_launcher_fails_once_on_a_box_without_gpus():
