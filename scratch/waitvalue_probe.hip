@@ -19,6 +19,9 @@ __global__ void producer(unsigned* flag, unsigned long long* stamps, unsigned va
 }
 __global__ void consumer(unsigned long long* stamps) { stamps[2] = rt(); }
 
+static int g_wait_first = 0;
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int run(const char* what, unsigned* flag) {
   hipStream_t sa, sb;
   CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
@@ -28,12 +31,15 @@ static int run(const char* what, unsigned* flag) {
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipMemset(stamps, 0, 3 * sizeof(unsigned long long)));
     const unsigned value = (unsigned)rep + 1;
-    hipLaunchKernelGGL(producer, dim3(1), dim3(64), 0, sa, flag, stamps, value, 2000, 3000);
-    std::printf("%s rep %d: producer launched\n", what, rep);
+    const double h0 = now_ms();
+    if (!g_wait_first) hipLaunchKernelGGL(producer, dim3(1), dim3(64), 0, sa, flag, stamps, value, 2000, 3000);
     hipError_t e = hipStreamWaitValue32(sb, flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu);
     if (e != hipSuccess) { std::printf("%s: hipStreamWaitValue32 -> %s\n", what, hipGetErrorString(e)); return 0; }
-    std::printf("%s rep %d: wait enqueued\n", what, rep);
+    const double h1 = now_ms();
+    std::printf("%s rep %d: wait enqueued, the call took %.3f ms of host time\n", what, rep, h1 - h0);
     hipLaunchKernelGGL(consumer, dim3(1), dim3(64), 0, sb, stamps);
+    std::printf("%s rep %d: consumer enqueued (+%.3f ms)\n", what, rep, now_ms() - h1);
+    if (g_wait_first) { hipLaunchKernelGGL(producer, dim3(1), dim3(64), 0, sa, flag, stamps, value, 2000, 3000); std::printf("%s rep %d: producer enqueued behind the wait (+%.3f ms)\n", what, rep, now_ms() - h1); }
     CK(hipDeviceSynchronize());
     unsigned long long h[3];
     CK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
@@ -46,6 +52,7 @@ static int run(const char* what, unsigned* flag) {
 int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
   const int which = argc > 1 ? std::atoi(argv[1]) : 0;
+  g_wait_first = argc > 2 ? std::atoi(argv[2]) : 0;
   unsigned* sig = nullptr;
   hipError_t e = hipExtMallocWithFlags((void**)&sig, 8, hipMallocSignalMemory);
   if (e == hipSuccess) { CK(hipMemset(sig, 0, 8)); if (which == 0 && run("signal memory", sig)) return 1; }
