@@ -15,6 +15,7 @@ exact posterior of its own matrix, the device between 7e-11 and 1.3e-8 from that
 end-to-end distance the test checks its two parts separately: the matrices the device evaluates against NumPy's entry by
 entry, and the device's posterior against the exact posterior of ITS OWN matrices (the solver alone)."""
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -141,7 +142,18 @@ def _assert_as_good_as_lapack(what, dev, lapack, exact, cond2=0.0):
 ENTRY_RTOL = 4e-15          # device-evaluated matrices vs NumPy's, relative to the largest entry (measured <= 1e-15)
 
 
-@pytest.mark.parametrize("seed", range(100, 148))
+def _seed_range():
+    """Seeds 100..147 in the suite; LPGP_RANDOM_SEEDS="lo:hi" runs another range of the same generator (one-off surveys)."""
+    spec = os.environ.get("LPGP_RANDOM_SEEDS")
+    if not spec:
+        # + four seeds of the round-4 survey of 1000..1399 on which the device was 9-37 x LAPACK's distance from the exact
+        # posterior until the panel step INSIDE the tile Cholesky was refined (csrc/potrf.hip, phase B; MEASUREMENTS.md)
+        return list(range(100, 148)) + [1088, 1215, 1226, 1388]
+    lo, hi = (int(v) for v in spec.split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _seed_range())
 def test_random_problem_matches_oracle(seed):
     import linpde_gp_amd as lp
     from linpde_gp_amd.linfuncops import diffops
