@@ -119,6 +119,29 @@ def test_potrf_tile(ctx, seed):
     assert np.all(np.triu(Linv, 1) == 0.0)
 
 
+@pytest.mark.parametrize("case", ["dense 1-D grid", "clustered 2-D"])
+def test_potrf_tile_backward_error_on_ill_conditioned_tiles(ctx, case):
+    """A Cholesky factor reproduces its matrix to rounding WHATEVER the condition (LAPACK: 8e-16 of max |A| on these tiles).  The
+    panel step inside the tile kernel -- the product with the explicit inverse of a 16 x 16 diagonal block -- is refined once
+    against the block for that: without the step these tiles (diagonal blocks of condition 1e5) came out at 5e-14 ... 7e-14
+    (round 4, `scratch/tile_chol_accuracy.py`; found by a 400-seed survey of tests/test_gpu_random.py)."""
+    from linpde_gp_amd import _engine
+    rng = np.random.default_rng(0)
+    pts, noise = ((np.linspace(-1, 1, 128)[:, None], 1e-10) if case == "dense 1-D grid"
+                  else (0.05 * rng.standard_normal((128, 2)), 1e-9))
+    K = np.ones((128, 128))
+    for d in range(pts.shape[1]):
+        r = np.sqrt(5.0) * np.abs(pts[:, None, d] - pts[None, :, d])
+        K *= (1 + r + r * r / 3) * np.exp(-r)
+    A = 4.0 * K + noise * np.eye(128)
+    L, _, info = _engine.test_potrf_tile(ctx, A)
+    assert info == 0
+    L = np.tril(L)
+    back = np.abs(A - L @ L.T).max() / np.abs(A).max()
+    lapack = np.linalg.cholesky(A)
+    assert back <= 4e-15, f"backward error {back:.2e} (LAPACK: {np.abs(A - lapack @ lapack.T).max() / np.abs(A).max():.2e})"
+
+
 def test_potrf_tile_not_pd(ctx):
     from linpde_gp_amd import _engine
     A = np.eye(128)
