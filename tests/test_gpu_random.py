@@ -28,6 +28,10 @@ from oracle import gp as ogp
 pytestmark = pytest.mark.gpu
 
 
+# LPGP_RANDOM_SCALE=k multiplies the block sizes (3..159 points in the suite) for one-off surveys of the multi-panel paths
+_SIZE_SCALE = int(os.environ.get("LPGP_RANDOM_SCALE", "1"))
+
+
 def _random_problem(lp, seed):
     from linpde_gp_amd.linfuncops import diffops
     cf = lp.randprocs.covfuncs
@@ -68,7 +72,7 @@ def _random_problem(lp, seed):
 
     u, oblocks = prior, []
     for _b in range(int(rng.integers(1, 5))):
-        n = int(rng.integers(3, 160))
+        n = int(rng.integers(3, 160)) * _SIZE_SCALE
         X = rng.uniform(-1.0, 1.0, size=(n, d))
         Y = rng.standard_normal(n)
         L = operator()
