@@ -18,7 +18,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 pids=()
-for f in api assemble gemm solve solve4 solve4p potrf dist; do
+for f in api assemble gemm solve solve4 solve4p potrf dist testhooks; do
   "$HIPCC" $FLAGS "$@" -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
@@ -28,3 +28,6 @@ for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp.so" "$OUT/api.o" "$OUT/assemble.o" "$OUT/gemm.o" "$OUT/solve.o" "$OUT/solve4.o" "$OUT/solve4p.o" "$OUT/potrf.o" "$OUT/dist.o" "$OUT/lower.o" \
   -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/liblpgp.so"
+# test hooks (include/lpgp_test.h): a library of their own, loaded by tests/ and scratch/ only
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp_testhooks.so" "$OUT/testhooks.o" -L"$OUT" -llpgp -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+echo "built $OUT/liblpgp_testhooks.so"

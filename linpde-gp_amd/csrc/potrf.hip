@@ -73,11 +73,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void potrf_tile_kernel(double* __r
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-  if (tid == 0) {
+#ifdef LPGP_TILE_DIAG
+  if (tid == 0) {                       // (diagnostic builds: which XCD the tile Cholesky ran on, lpgp_debug_tile_xcc)
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     atomicAdd(&g_tile_xcc_hist[xcc & 7], 1);
   }
+#endif
   // ---- load tile: one 1-KiB LDS-DMA piece per column ----
   for (int c = wu; c < TILE; c += TILE_WAVES)
     __builtin_amdgcn_global_load_lds((gptr_t)(a + (int64_t)c * lda + 2 * lane), (lptr_t)(s + c * TL), 16, 0, 0);

@@ -199,16 +199,6 @@ class Context:
             out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         return out
 
-    def probe_mfma_f64(self) -> float:
-        v = C.c_double()
-        check(lib.lpgp_probe_mfma_f64(self._h, C.byref(v)), "lpgp_probe_mfma_f64")
-        return v.value
-
-    def probe_hbm_write(self, nbytes: int = 1 << 30) -> float:
-        v = C.c_double()
-        check(lib.lpgp_probe_hbm_write(self._h, int(nbytes), C.byref(v)), "lpgp_probe_hbm_write")
-        return v.value
-
 
 _default_ctx = None
 _default_lock = threading.Lock()
@@ -556,62 +546,3 @@ def kernel_matvec(ctx: Context, kdesc, X0: Points, X1: Points, V: np.ndarray) ->
     check(lib.lpgp_kernel_matvec(ctx._h, arr, len(arr), X0._h, X1._h, as_pd(V2), V2.shape[1], as_pd(out)),
           "lpgp_kernel_matvec")
     return out[:, 0] if vec else out
-
-
-def test_gemm(ctx: Context, ta: int, tb: int, lower_only: int, alpha: float, A: np.ndarray, B: np.ndarray,
-              beta: float, Cm: np.ndarray, k: int, reps: int = 0):
-    """Raw GEMM on column-major (Fortran-ordered) arrays; returns (C, ms_per_rep)."""
-    A = np.asfortranarray(A, dtype=np.double)
-    B = np.asfortranarray(B, dtype=np.double)
-    Cm = np.asfortranarray(Cm, dtype=np.double).copy(order="F")
-    m, n = Cm.shape
-    ms = C.c_double(0.0)
-    pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_gemm(ctx._h, ta, tb, lower_only, m, n, k, alpha,
-                             A.ctypes.data_as(pd), A.shape[0], B.ctypes.data_as(pd), B.shape[0], beta,
-                             Cm.ctypes.data_as(pd), Cm.shape[0], reps, C.byref(ms)), "lpgp_test_gemm")
-    return Cm, ms.value
-
-
-def test_tile_step(ctx: Context, which: int, XV: np.ndarray, L: np.ndarray, Linv: np.ndarray):
-    """In-place refined tile solve on host buffers (`lpgp_test_tile_step`): which = 0: X (rows x 128) <- X L^{-T},
-    which = 1: V (128 x cols) <- L^{-1} V.  Returns (result, milliseconds)."""
-    XV = np.asfortranarray(XV, dtype=np.double).copy(order="F")
-    L = np.asfortranarray(np.tril(L), dtype=np.double)
-    Linv = np.asfortranarray(np.tril(Linv), dtype=np.double)
-    n = XV.shape[0] if which == 0 else XV.shape[1]
-    ms = C.c_double(0.0)
-    pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_tile_step(ctx._h, which, XV.ctypes.data_as(pd), n, L.ctypes.data_as(pd), Linv.ctypes.data_as(pd),
-                                  C.byref(ms)), "lpgp_test_tile_step")
-    return XV, ms.value
-
-
-def test_panel_solve(ctx: Context, V: np.ndarray, Lblk: np.ndarray, rows_form: bool = False):
-    """Fused panel chain (`lpgp_test_panel_solve`): V (nt*128 x cols) <- Lblk^{-1} V, or with `rows_form`
-    X (cols x nt*128) <- X Lblk^{-T}.  Returns (result, milliseconds)."""
-    import scipy.linalg
-    if rows_form:
-        cols, rows = V.shape
-    else:
-        rows, cols = V.shape
-    nt = rows // 128
-    V = np.asfortranarray(V, dtype=np.double).copy(order="F")
-    Lb = np.asfortranarray(np.tril(Lblk), dtype=np.double)
-    Linv = np.concatenate([np.asfortranarray(np.tril(scipy.linalg.solve_triangular(
-        Lb[t * 128:(t + 1) * 128, t * 128:(t + 1) * 128], np.eye(128), lower=True))).reshape(-1, order="F") for t in range(nt)])
-    ms = C.c_double(0.0)
-    pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_panel_solve(ctx._h, int(bool(rows_form)), V.ctypes.data_as(pd), nt, cols, Lb.ctypes.data_as(pd),
-                                    np.ascontiguousarray(Linv).ctypes.data_as(pd), C.byref(ms)), "lpgp_test_panel_solve")
-    return V, ms.value
-
-
-def test_potrf_tile(ctx: Context, T: np.ndarray):
-    T = np.asfortranarray(T, dtype=np.double).copy(order="F")
-    Linv = np.zeros((128, 128), order="F")
-    info = C.c_int32()
-    pd = C.POINTER(C.c_double)
-    check(lib.lpgp_test_potrf_tile(ctx._h, T.ctypes.data_as(pd), Linv.ctypes.data_as(pd), C.byref(info)),
-          "lpgp_test_potrf_tile")
-    return T, Linv, info.value

@@ -81,7 +81,6 @@ def _load() -> C.CDLL:
     sig("lpgp_dist_grid", C.c_int, vp, C.POINTER(i32), C.POINTER(i32))
     sig("lpgp_dist_stats", C.c_int, vp, pd, pd, i32)
     sig("lpgp_dist_link_probe", C.c_int, vp, i64, i32, pd)
-    sig("lpgp_test_stair_enumerate", C.c_int, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), i64)
     sig("lpgp_dist_init_host", C.c_int, vp, i32, i32, HOST_EXCHANGE_FN, vp)
     sig("lpgp_dist_ipc_export", C.c_int, vp, i64, C.c_char_p)
     sig("lpgp_dist_init_ipc", C.c_int, vp, i32, i32, C.c_char_p, HOST_EXCHANGE_FN, vp)
@@ -125,13 +124,6 @@ def _load() -> C.CDLL:
     sig("lpgp_profile_enable", C.c_int, vp, i32)
     sig("lpgp_profile_reset", C.c_int, vp)
     sig("lpgp_profile_get", C.c_int, vp, i32, pd, C.POINTER(i64), pd, pd)
-    sig("lpgp_test_gemm", C.c_int, vp, i32, i32, i32, i64, i64, i64, dbl, pd, i64, pd, i64, dbl, pd, i64, i32, pd)
-    sig("lpgp_test_potrf_tile", C.c_int, vp, pd, pd, C.POINTER(i32))
-    sig("lpgp_debug_tile_xcc", C.c_int, vp, C.POINTER(i32), i32)
-    sig("lpgp_test_tile_step", C.c_int, vp, i32, pd, i64, pd, pd, pd)
-    sig("lpgp_test_panel_solve", C.c_int, vp, i32, pd, i32, i64, pd, pd, pd)
-    sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
-    sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
     return lib
 
 
@@ -140,16 +132,15 @@ lib = _load()
 EXPORTED = [
     "lpgp_init", "lpgp_finalize", "lpgp_last_error", "lpgp_device_info", "lpgp_sync",
     "lpgp_set_option", "lpgp_get_option", "lpgp_dist_unique_id", "lpgp_dist_init", "lpgp_dist_info", "lpgp_dist_init_host", "lpgp_dist_ipc_export", "lpgp_dist_init_ipc", "lpgp_dist_set_grid",
-    "lpgp_dist_grid", "lpgp_dist_stats", "lpgp_dist_link_probe", "lpgp_test_stair_enumerate", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
+    "lpgp_dist_grid", "lpgp_dist_stats", "lpgp_dist_link_probe", "lpgp_pts_create", "lpgp_pts_destroy", "lpgp_mat_create",
     "lpgp_mat_destroy", "lpgp_mat_add_block", "lpgp_mat_pop_block", "lpgp_mat_set_view", "lpgp_mat_num_blocks",
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_kron_fits", "lpgp_profile_enable", "lpgp_profile_reset",
-    "lpgp_profile_get", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_test_panel_solve", "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64",
-    "lpgp_probe_hbm_write",
-]
+    "lpgp_profile_get",
+    ]
 
 
 def check(rc: int, what: str = "") -> None:

@@ -24,9 +24,11 @@ from __future__ import annotations
 
 import atexit
 import itertools
+import multiprocessing
 import os
 import secrets
 import shutil
+import select
 import socket
 import subprocess
 import sys
@@ -120,6 +122,15 @@ def _worker_main(rank, world, port, conn, transport, device, grid, extra_env):
         pass
 
 
+def _listener_socket(listener):
+    """The listening socket behind a `multiprocessing.connection.Listener` (for `select`): the class exposes no file
+    descriptor of its own; guarded so that a change of its internals fails loudly at bring-up, not as a hang."""
+    sock = getattr(getattr(listener, "_listener", None), "_socket", None)
+    if sock is None or not hasattr(sock, "fileno"):
+        raise RuntimeError("multi-GPU front: cannot reach the listening socket of multiprocessing.connection.Listener")
+    return sock
+
+
 class WorkerGroup:
     """`n_gpus` worker processes, one per GPU, that replay the collective calls of this process."""
 
@@ -150,19 +161,36 @@ class WorkerGroup:
             for r in range(self.world):
                 self._procs.append(subprocess.Popen([sys.executable, "-m", "linpde_gp_amd._spawn_worker", listener.address, str(r)],
                                                     env=child_env, stdin=subprocess.DEVNULL))
-            listener._listener._socket.settimeout(0.5)
             by_rank, t_end = {}, time.monotonic() + timeout
+            lsock = _listener_socket(listener)
             while len(by_rank) < self.world:
+                dead = [r for r, p in enumerate(self._procs) if p.poll() is not None and r not in by_rank]
+                if dead:
+                    raise RuntimeError(f"multi-GPU front: worker {dead[0]} died during bring-up (before it dialled back)")
+                remaining = t_end - time.monotonic()
+                if remaining <= 0:
+                    raise RuntimeError(f"multi-GPU front: a worker did not dial back within {timeout:.0f} s")
+                # wait for a pending connection on the listening socket itself: `Listener.accept` has no timeout, and its
+                # authentication handshake blocks -- so it is only entered when a peer is known to be waiting
+                if not select.select([lsock], [], [], min(0.5, remaining))[0]:
+                    continue
                 try:
                     c = listener.accept()
-                except (socket.timeout, TimeoutError):
-                    dead = [r for r, p in enumerate(self._procs) if p.poll() is not None and r not in by_rank]
-                    if dead:
-                        raise RuntimeError(f"multi-GPU front: worker {dead[0]} died during bring-up (before it dialled back)") from None
-                    if time.monotonic() > t_end:
-                        raise RuntimeError(f"multi-GPU front: a worker did not dial back within {timeout:.0f} s") from None
+                except (multiprocessing.AuthenticationError, EOFError, OSError):
+                    continue                       # a peer that failed the handshake or hung up: not one of ours
+                # a worker that connected but died or hangs before it sent its rank must not hold the parent past `timeout`
+                if not c.poll(max(0.0, min(30.0, t_end - time.monotonic()))):
+                    c.close()
                     continue
-                by_rank[c.recv()] = c
+                try:
+                    r = c.recv()
+                except (EOFError, OSError):
+                    c.close()
+                    continue
+                if not isinstance(r, int) or not 0 <= r < self.world or r in by_rank:
+                    c.close()
+                    raise RuntimeError(f"multi-GPU front: a worker announced rank {r!r} (world {self.world}, registered {sorted(by_rank)})")
+                by_rank[r] = c
             for r in range(self.world):
                 extra = dict(env or {})
                 if rccl_loopback:

@@ -12,12 +12,17 @@ gram_capacity_hint: int = 0
 use_grid_assembly: bool = True
 
 # When a Gram matrix that is not positive definite is reported.
-# True (default): as in the reference, whose Cholesky factor is a `functools.cached_property` evaluated at first use
-# (`_conditional.py:92`, `linops/_block.py:203`) -- `condition_on_observations` enqueues assembly and factorisation and
-# returns; `np.linalg.LinAlgError` is raised by the first call that needs the factor (`predict`, `mean`, `cov`,
-# `representer_weights`, `gram.cholesky()` ...), on the object whose block failed and on every object conditioned on it;
-# the objects before it stay usable (their part of the factor is untouched, the failed blocks are dropped).  The host
-# runs ahead of the device over a chain of conditionings instead of waiting for a status word after each.
-# False: the status is read back inside `condition_on_observations`, which then raises itself (rounds 1-3).
+# False (default): inside `condition_on_observations`, as in the reference -- its constructor evaluates the representer
+# weights (`_conditional.py:44` first conditioning, `:280-282` `schur_update` on re-conditioning; `:83` passes
+# `self.representer_weights` to `Mean`), i.e. the Cholesky factor is computed and `np.linalg.LinAlgError` raised before
+# `condition_on_observations` returns.  Code that wraps the call in try/except (a jitter retry) works unchanged.  The
+# status word is read back once per conditioning (one host synchronisation).
+# True (opt-in, a throughput knob): `condition_on_observations` ENQUEUES assembly and factorisation and returns; the
+# status is read by the first call that needs the factor (`predict`, `mean`, `cov`, `representer_weights`,
+# `gram.cholesky()` ...), which raises `np.linalg.LinAlgError` on the object whose block failed and on every object
+# conditioned on it; the objects before it stay usable (their part of the factor is untouched, the failed blocks are
+# dropped).  The host runs ahead of the device over a chain of conditionings, and a `predict` that follows rides inside
+# the last factorisation (`lpgp_potrf_predict_enqueue`).  The numbers are the same in both modes; only WHERE a failure
+# surfaces differs from the reference.  `bench.py` opts in and says so in its line.
 # Multi-GPU jobs always check inside `condition_on_observations` (the ranks agree on the status collectively).
-lazy_factorization: bool = True
+lazy_factorization: bool = False

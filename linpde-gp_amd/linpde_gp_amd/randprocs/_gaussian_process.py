@@ -289,8 +289,11 @@ class ConditionalGaussianProcess(GaussianProcess):
             # stays valid for the object this one was derived from)
             return cls(prior=prior, blocks=tuple(old_blocks), state=state, representer_weights=None)
         lazy = bool(config.lazy_factorization) and not state.ctx.distributed      # (a context that joined a job -- even of one rank -- factors collectively)
-        if not state.pending and not state.owns(old_blocks):
-            # the object being conditioned is known to rest on a block that was not positive definite
+        if not state.owns(old_blocks):
+            # the object being conditioned rests on a block that was not positive definite and has been dropped:
+            # `state.blocks` only ever shrinks through `verify`'s truncation, so not owning its blocks means dead whether
+            # or not another factorisation is pending (with the check skipped while pending, a dead child's
+            # rows were lowered against ITS points and appended onto the blocks of a sibling)
             raise np.linalg.LinAlgError(state.failure or "the Gram matrix of this posterior is not positive definite")
         if len(state.blocks) != len(old_blocks):
             # the object being conditioned has already been extended by another conditioning: this one
@@ -408,9 +411,9 @@ class ConditionalGaussianProcess(GaussianProcess):
         """Point the shared device matrix at THIS object's blocks.  A later `condition_on_observations`
         appended to the same matrix without touching its leading part, so an earlier posterior keeps
         working (the reference's posteriors are immutable values).  First use of the factor: the status of the
-        factorisations enqueued so far is read here (`config.lazy_factorization`), and an object whose own block -- or a
-        block it was conditioned on -- was not positive definite raises, as the reference's lazily evaluated Cholesky
-        factor does (`_conditional.py:92`)."""
+        factorisations enqueued so far is read here (`config.lazy_factorization = True`; by default every conditioning has
+        read its own), and an object whose own block -- or a block it was conditioned on -- was not positive definite
+        raises."""
         self._state.verify()
         if not self._state.owns(self._blocks):
             raise np.linalg.LinAlgError(self._state.failure or "the Gram matrix of this posterior is not positive definite")

@@ -1,6 +1,7 @@
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'linpde-gp_amd')
 import numpy as np
 from linpde_gp_amd import _engine
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _hooks      # test hooks: liblpgp_testhooks.so
 ctx = _engine.default_context()
 rng = np.random.default_rng(0)
 def run(m, n, k, tri):
@@ -9,7 +10,7 @@ def run(m, n, k, tri):
     out = []
     for dense in (0, 1):
         ctx.set_option("dense_tiles", dense)
-        _, ms = _engine.test_gemm(ctx, 0, 0, tri, -1.0, A, B, 1.0, C, k, reps=5)
+        _, ms = _hooks.test_gemm(ctx, 0, 0, tri, -1.0, A, B, 1.0, C, k, reps=5)
         fl = (m * (m + 1.0) * k) if tri else 2.0 * m * n * k
         out.append(fl / ms / 1e9)
     print(f"m={m} n={n} k={k} tri={tri}: legacy {out[0]:.1f} TF  dense {out[1]:.1f} TF", flush=True)

@@ -5,6 +5,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'linpde-gp_amd')
 import numpy as np
 import linpde_gp_amd as lp
 from linpde_gp_amd import problems
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _hooks      # test hooks: liblpgp_testhooks.so
 names = sys.argv[1:] or ["poisson2d", "poisson1d", "heat"]
 for name in names:
     wl = {"poisson2d": lambda: problems.poisson_2d(), "poisson1d": lambda: problems.poisson_1d(), "heat": lambda: problems.heat_1d(),
@@ -18,4 +19,4 @@ for name in names:
     import ctypes as C
     from linpde_gp_amd._lib import lib
     out = (C.c_int32 * 8)()
-    lib.lpgp_debug_tile_xcc(ctx._h, out, 0)
+    _hooks.lib.lpgp_debug_tile_xcc(ctx._h, out, 0)

@@ -4,6 +4,7 @@ scratch/clock_trace.hip).  LPGP_TEST_GEMM_STREAM=1: on the CU-masked update stre
 import os, sys; sys.path.insert(0, '.'); sys.path.insert(0, 'linpde-gp_amd')
 import numpy as np
 from linpde_gp_amd import _engine
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _hooks      # test hooks: liblpgp_testhooks.so
 ctx = _engine.default_context()
 rng = np.random.default_rng(0)
 m = 16384
@@ -11,6 +12,6 @@ C = np.zeros((m, m), order="F")
 out = []
 for k in (512, 1024, 2048):
     A = rng.standard_normal((m, k))
-    _, ms = _engine.test_gemm(ctx, 0, 0, 1, -1.0, A, A, 1.0, C, k, reps=max(60, int(300 * 512 / k)))
+    _, ms = _hooks.test_gemm(ctx, 0, 0, 1, -1.0, A, A, 1.0, C, k, reps=max(60, int(300 * 512 / k)))
     out.append(f"K = {k}: {ms:.3f} ms = {m * (m + 1.0) * k / ms / 1e9:.1f} TFLOP/s")
 print(f"stream {os.environ.get('LPGP_TEST_GEMM_STREAM', '0')} reserve {os.environ.get('LPGP_RESERVE_CUS', '8')}: " + ";  ".join(out), flush=True)

@@ -297,7 +297,8 @@ def test_staircase_tile_enumeration_of_the_distributed_update():
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "linpde-gp_amd"))
-    from linpde_gp_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _hooks
     cap = 60000
     out = (C.c_int32 * (2 * cap))()
     n_cases = 0
@@ -309,7 +310,7 @@ def test_staircase_tile_enumeration_of_the_distributed_update():
                         continue
                     for r in range(pr):
                         for c in range(pc):
-                            n = _lib.lib.lpgp_test_stair_enumerate(pr, pc, r, c, nbt, T, rlo, clo, out, cap)
+                            n = _hooks.lib.lpgp_test_stair_enumerate(pr, pc, r, c, nbt, T, rlo, clo, out, cap)
                             assert 0 <= n <= cap
                             got = [tuple(x) for x in np.frombuffer(out, dtype=np.int32, count=2 * n).reshape(n, 2)]
                             want = {(i, j) for i in range(rlo, T) for j in range(clo, T)

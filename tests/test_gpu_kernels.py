@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import scipy.linalg
 
+import _hooks      # tests/_hooks.py: liblpgp_testhooks.so (include/lpgp_test.h)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -35,8 +37,8 @@ def test_options_round_trip(ctx):
 
 
 def test_probes(ctx):
-    tf = ctx.probe_mfma_f64()
-    gb = ctx.probe_hbm_write(1 << 30)
+    tf = _hooks.probe_mfma_f64(ctx)
+    gb = _hooks.probe_hbm_write(ctx, 1 << 30)
     print(f"\n[probe] fp64 MFMA issue loop: {tf:.1f} TFLOP/s ; streaming write: {gb:.0f} GB/s ; {ctx.device_info()}")
     assert tf > 10.0 and gb > 500.0
 
@@ -66,10 +68,10 @@ def test_gemm_variants(ctx, gemm_kernel, ta, tb, k):
     C0 = rng.standard_normal((m, n))
     A_store = Am.T if ta else Am          # ta: k fastest => stored (k x m) column-major
     B_store = Bm if tb else Bm.T          # tb=0: stored (n x k) column-major (n fastest)
-    out, _ = _engine.test_gemm(ctx, ta, tb, 0, -1.5, A_store, B_store, 0.5, C0, k)
+    out, _ = _hooks.test_gemm(ctx, ta, tb, 0, -1.5, A_store, B_store, 0.5, C0, k)
     ref = 0.5 * C0 - 1.5 * Am @ Bm
     np.testing.assert_allclose(out, ref, rtol=1e-13, atol=1e-12)
-    out0, _ = _engine.test_gemm(ctx, ta, tb, 0, 1.0, A_store, B_store, 0.0, np.full_like(C0, np.nan), k)
+    out0, _ = _hooks.test_gemm(ctx, ta, tb, 0, 1.0, A_store, B_store, 0.0, np.full_like(C0, np.nan), k)
     np.testing.assert_allclose(out0, Am @ Bm, rtol=1e-13, atol=1e-12)
 
 
@@ -79,7 +81,7 @@ def test_syrk_lower_only(ctx, gemm_kernel):
     n, k = 640, 512
     P = rng.standard_normal((n, k))
     C0 = rng.standard_normal((n, n))
-    out, _ = _engine.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k)
+    out, _ = _hooks.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k)
     ref = C0 - P @ P.T
     edge = 64 if gemm_kernel == "tile64" else 128
     tile = np.arange(n) // edge
@@ -95,10 +97,10 @@ def test_gemm_throughput(ctx):
     n, k = 8192, 512
     P = rng.standard_normal((n, k))
     C0 = np.zeros((n, n), order="F")
-    _, ms = _engine.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k, reps=5)
+    _, ms = _hooks.test_gemm(ctx, 0, 0, 1, -1.0, P, P, 1.0, C0, k, reps=5)
     flops = n * (n + 1.0) * k
     print(f"\n[syrk] n={n} k={k}: {ms:.3f} ms  -> {flops / ms / 1e9:.1f} TFLOP/s algorithmic")
-    _, ms = _engine.test_gemm(ctx, 0, 1, 0, -1.0, P, np.asfortranarray(rng.standard_normal((k, 4096))), 1.0,
+    _, ms = _hooks.test_gemm(ctx, 0, 1, 0, -1.0, P, np.asfortranarray(rng.standard_normal((k, 4096))), 1.0,
                               np.zeros((n, 4096), order="F"), k, reps=5)
     print(f"[gemm nn] {n}x4096x{k}: {ms:.3f} ms -> {2.0 * n * 4096 * k / ms / 1e9:.1f} TFLOP/s")
 
@@ -109,7 +111,7 @@ def test_potrf_tile(ctx, seed):
     rng = np.random.default_rng(seed)
     M = rng.standard_normal((128, 160))
     A = M @ M.T + 1e-3 * np.eye(128)
-    L, Linv, info = _engine.test_potrf_tile(ctx, A)
+    L, Linv, info = _hooks.test_potrf_tile(ctx, A)
     assert info == 0
     Lref = np.linalg.cholesky(A)
     np.testing.assert_allclose(np.tril(L), Lref, rtol=1e-10, atol=1e-11)
@@ -134,7 +136,7 @@ def test_potrf_tile_backward_error_on_ill_conditioned_tiles(ctx, case):
         r = np.sqrt(5.0) * np.abs(pts[:, None, d] - pts[None, :, d])
         K *= (1 + r + r * r / 3) * np.exp(-r)
     A = 4.0 * K + noise * np.eye(128)
-    L, _, info = _engine.test_potrf_tile(ctx, A)
+    L, _, info = _hooks.test_potrf_tile(ctx, A)
     assert info == 0
     L = np.tril(L)
     back = np.abs(A - L @ L.T).max() / np.abs(A).max()
@@ -146,7 +148,7 @@ def test_potrf_tile_not_pd(ctx):
     from linpde_gp_amd import _engine
     A = np.eye(128)
     A[40, 40] = -1.0
-    _, _, info = _engine.test_potrf_tile(ctx, A)
+    _, _, info = _hooks.test_potrf_tile(ctx, A)
     assert info == 41
 
 
@@ -373,7 +375,7 @@ def test_tile_solve_refined(which, n, cond):
     XV = rng.standard_normal((n, 128) if which == 0 else (128, n))
     exact = scipy.linalg.solve_triangular(L, XV.T if which == 0 else XV, lower=True)
     exact = exact.T if which == 0 else exact
-    got, ms = _engine.test_tile_step(ctx, which, XV, L, Linv)
+    got, ms = _hooks.test_tile_step(ctx, which, XV, L, Linv)
     # backward error of the solve: residual against the right-hand side, relative to |X||L| -- the measure that is
     # eps for a substitution and cond * eps for a bare product with the explicit inverse
     res = (got @ L.T - XV) if which == 0 else (L @ got - XV)
@@ -399,13 +401,13 @@ def test_fused_panel_solve(nt, cols):
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     L = np.linalg.cholesky((Q * np.logspace(0, -5, n) ** 2) @ Q.T)          # cond(L) = 1e5
     V = rng.standard_normal((n, cols))
-    got, ms = _engine.test_panel_solve(ctx, V, L)
+    got, ms = _hooks.test_panel_solve(ctx, V, L)
     exact = scipy.linalg.solve_triangular(L, V, lower=True)
     res = np.abs(L @ got - V) / (np.abs(L) @ np.abs(got))
     assert np.max(res) < 5e-14, np.max(res)
     np.testing.assert_allclose(got, exact, rtol=0, atol=1e-9 * np.abs(exact).max())
     # the rows orientation (panel solve of the multi-GPU factorisation / block append): X <- X L^{-T}
-    got_r, _ = _engine.test_panel_solve(ctx, np.ascontiguousarray(V.T), L, rows_form=True)
+    got_r, _ = _hooks.test_panel_solve(ctx, np.ascontiguousarray(V.T), L, rows_form=True)
     np.testing.assert_allclose(got_r, exact.T, rtol=0, atol=1e-9 * np.abs(exact).max())
     res_r = np.abs(got_r @ L.T - V.T) / (np.abs(got_r) @ np.abs(L.T))
     assert np.max(res_r) < 5e-14, np.max(res_r)

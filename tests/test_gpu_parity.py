@@ -511,9 +511,9 @@ def test_potrs_multiple_rhs_and_dense_noise(lp):
 
 @pytest.fixture(params=["lazy", "eager"])
 def factorization_check(lp, request):
-    """`lp.config.lazy_factorization`: True (default, the reference's order of events: the Cholesky factor is evaluated --
-    and a Gram matrix that is not positive definite reported -- at first use, `_conditional.py:92`) / False (the status is
-    read back inside `condition_on_observations`, which raises itself)."""
+    """`lp.config.lazy_factorization`: False (default, the reference's order of events: its constructor evaluates the
+    representer weights, `_conditional.py:44,83,280-282`, so `condition_on_observations` raises itself) / True (opt-in: the
+    factorisation is enqueued and a Gram matrix that is not positive definite is reported at the first use of the factor)."""
     saved = lp.config.lazy_factorization
     lp.config.lazy_factorization = request.param == "lazy"
     yield request.param
@@ -544,11 +544,37 @@ def test_not_positive_definite_raises(lp, factorization_check):
     _condition_expecting_failure(factorization_check == "lazy", prior, np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
 
 
-def test_lazy_failure_in_the_middle_of_a_chain(lp):
-    """Lazy status (default): a block that is not positive definite in the MIDDLE of a chain of conditionings.  Nothing
+@pytest.fixture
+def lazy_mode(lp):
+    saved = lp.config.lazy_factorization
+    lp.config.lazy_factorization = True
+    yield
+    lp.config.lazy_factorization = saved
+
+
+def test_eager_status_is_the_default(lp):
+    """the reference reports a Gram matrix that is not positive definite INSIDE `condition_on_observations`
+    (`_conditional.py:44,83`); so does the default configuration here (a try/except jitter retry keeps working)."""
+    assert lp.config.lazy_factorization is False
+    cf = lp.randprocs.covfuncs
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    X = np.array([[0.0], [0.0], [0.5]])
+    u = None
+    tried = []
+    for noise in (-1e-3, 1e-3):                     # the retry idiom (first attempt: surely not positive definite)
+        tried.append(noise)
+        try:
+            u = prior.condition_on_observations(np.zeros(3), X, b=lp.randvars.Normal(np.zeros(3), noise * np.eye(3)))
+            break
+        except np.linalg.LinAlgError:
+            continue
+    assert tried == [-1e-3, 1e-3] and u is not None and np.all(np.isfinite(u.predict(np.array([[0.1]]))[0]))
+
+
+def test_lazy_failure_in_the_middle_of_a_chain(lp, lazy_mode):
+    """Lazy status (opt-in): a block that is not positive definite in the MIDDLE of a chain of conditionings.  Nothing
     raises while the chain is built (the host runs ahead of the device); the first use of any object from the failed
     block on raises `LinAlgError`, the objects before it stay exact, and the chain can be continued from them."""
-    assert lp.config.lazy_factorization is True
     cf = lp.randprocs.covfuncs
     okern = [(1.0, [("expquad", 1.0)])]
     ident = ocf.identity(1)
@@ -576,6 +602,34 @@ def test_lazy_failure_in_the_middle_of_a_chain(lp):
     with pytest.raises(np.linalg.LinAlgError):
         u3.predict(Xt)                               # still dead: its blocks are not the ones in the matrix
     np.testing.assert_allclose(u1.representer_weights, post1.weights, rtol=1e-7, atol=1e-9)
+
+
+def test_dead_child_conditioned_while_a_sibling_is_pending(lp, lazy_mode):
+    """u2 = u1.cond(bad); u1.predict() finds the failure and truncates to [A]; u2b = u1.cond(B') leaves a
+    factorisation pending on [A, B']; conditioning the dead u2 now must raise -- not append rows lowered against u2's
+    points onto u2b's blocks (same sizes: it would be silently wrong)."""
+    cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 1.0)])]
+    ident = ocf.identity(1)
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    rng = np.random.default_rng(11)
+    X1, Y1 = rng.uniform(-1, 1, (40, 1)), rng.normal(size=40)
+    noise = lp.randvars.Normal(np.zeros(40), 1e-2 * np.eye(40))
+    Xbad = np.array([[0.2], [0.2], [0.5]])
+    Xgood, Ygood = np.array([[0.21], [-0.33], [0.52]]), np.array([0.3, -0.1, 0.2])      # same size as the bad block
+    Xc, Yc = np.array([[0.77]]), np.array([0.4])
+    Xt = np.linspace(-1, 1, 5)[:, None]
+    u1 = prior.condition_on_observations(Y1, X1, b=noise)
+    u2 = u1.condition_on_observations(np.zeros(3), Xbad, b=lp.randvars.Normal(np.zeros(3), -1e-3 * np.eye(3)))
+    u1.predict(Xt)                                   # verifies: the bad block is dropped, u2 is dead
+    u2b = u1.condition_on_observations(Ygood, Xgood)                 # pending on [A, B']
+    assert u2b._state.pending
+    with pytest.raises(np.linalg.LinAlgError):
+        u2.condition_on_observations(Yc, Xc)
+    u3 = u2b.condition_on_observations(Yc, Xc)
+    post = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2), ogp.ObsBlock(Xgood, ident, Ygood), ogp.ObsBlock(Xc, ident, Yc)])
+    m, v = u3.predict(Xt)
+    assert _rel(m, post.mean(Xt)) < 1e-8 and np.max(np.abs(v - post.var(Xt))) < 1e-9
 
 
 def test_earlier_posteriors_stay_usable_and_branching(lp):

@@ -27,6 +27,30 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_lib.EXPORTED) <= declared
 
 
+def test_product_library_exports_no_test_hooks():
+    """the raw-kernel test entry points, probes and diagnostics live in a library of their own
+    (include/lpgp_test.h, liblpgp_testhooks.so: tests/_hooks.py), not in the shipping liblpgp.so."""
+    import subprocess
+    import _hooks
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "lpgp_test.h")).read()
+    declared = set(re.findall(r"\b(lpgp_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hooks.EXPORTED)
+    for name in sorted(declared):
+        assert hasattr(_hooks.lib, name), f"{name} declared in lpgp_test.h but not exported by liblpgp_testhooks.so"
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    leaked = [ln for ln in syms.splitlines() if re.search(r"\blpgp_(test|probe|debug)_", ln)]
+    assert not leaked, leaked
+    # ... and the product package does not import SciPy or the hooks
+    import linpde_gp_amd, pkgutil
+    pkg_dir = os.path.dirname(linpde_gp_amd.__file__)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import scipy" not in text and "testhooks" not in text and "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
 def test_multi_index_and_coefficients_algebra():
     mi = diffops.MultiIndex((1, 2, 0))
     assert mi.order == 3 and mi.is_mixed and mi == diffops.MultiIndex([1, 2, 0]) and hash(mi) == hash(diffops.MultiIndex([1, 2, 0]))
