@@ -200,11 +200,13 @@ int  lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host);
  *      is not positive definite.                                                         */
 int  lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info);
 /* The same factorisation ENQUEUED: no host synchronisation, the status stays on the device (one sticky word per
- * matrix: the first non-positive pivot).  This is the reference's own order of events -- its Cholesky factor is a
- * `functools.cached_property` evaluated at first use (_conditional.py:92, linops/_block.py:203), so a Gram matrix that
- * is not positive definite surfaces at the first solve, not inside `condition_on_observations` -- and it lets the host
- * run ahead of the device over a chain of conditionings (c3: four boundary blocks of ~0.2 ms each, half of it host
- * time behind a status read-back).  Single GPU only (the multi-GPU factorisation agrees on its status collectively).
+ * matrix: the first non-positive pivot).  NOT the reference's order of events -- its constructor evaluates the
+ * representer weights (_conditional.py:44, :83, :280-282), so a Gram matrix that is not positive definite raises inside
+ * `condition_on_observations`; lpgp_potrf reproduces that and is what the host package uses by default.  The enqueued
+ * form is the opt-in throughput mode (`lp.config.lazy_factorization = True`): the host runs ahead of the device over a
+ * chain of conditionings (c3: four boundary blocks of ~0.2 ms each, half of it host time behind a status read-back),
+ * and the failure surfaces at the first use of the factor.  Single GPU only (the multi-GPU factorisation agrees on its
+ * status collectively).
  * lpgp_mat_check waits for the panel stream and returns the status of everything enqueued since the last check:
  * info = 0 ok; k > 0: the leading minor of (padded) order k is not positive definite, *block = index of the
  * observation block it lies in -- the factor of blocks 0 .. *block - 1 is intact.  lpgp_mat_truncate drops the blocks
@@ -216,8 +218,10 @@ int  lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat);
  * row[j] describes (L_new k L_j'^*)(X_new, X_j) for every earlier block j = 0 .. nrow - 2, row[nrow - 1] the diagonal block
  * (L_new k L_new'^*)(X_new, X_new) (X1 = NULL there; F0 / F1 non-NULL: both point sets are tensor grids, the Kronecker path
  * of lpgp_gram_assemble_grid) --, add the noise b.cov (a scalar variance, or noise_diag[n], or noise_dense[n x n], at most
- * one of them), and factor: lazy != 0 enqueues the factorisation (lpgp_potrf_enqueue; status by lpgp_mat_check), lazy == 0
- * factors and returns the status in *info.  On an error -- and on info != 0 -- the block is dropped again (lpgp_mat_pop_block):
+ * one of them), and factor: lazy == 0 factors and returns the status in *info (the reference's order of events); lazy == 1
+ * enqueues the factorisation (lpgp_potrf_enqueue; status by lpgp_mat_check); lazy == 2 assembles only and leaves the
+ * factorisation to whichever call needs the factor first -- the next lpgp_mat_condition (which enqueues it before it
+ * declares its own block), lpgp_potrf / lpgp_potrf_enqueue, or lpgp_potrf_predict, inside which the prediction rides.  On an error -- and on info != 0 -- the block is dropped again (lpgp_mat_pop_block):
  * the matrix is what it was before the call.  The same launches as the separate calls, in the same order; what it saves
  * is host time: nrow + 3 calls through the binding per conditioning (at N_tot ~ 1 000 a conditioning is bound by the
  * host), and the synchronisation the noise upload of lpgp_mat_add_diag needs for its borrowed host vector (here the
@@ -248,6 +252,11 @@ int  lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host);
 /* ---- prediction: replaces `PriorPredictiveCrossCovariance._evaluate`
  *      (_conditional.py:140-153), `Mean._evaluate` (:193-197) and
  *      `CovarianceFunction._evaluate` (:223-231).                                       */
+/* STREAMS (for callers of the C API that keep work asynchronous): everything is ordered on the context's panel stream;
+ * lpgp_mat_condition's noise upload and lpgp_mat_set_residual use an idle side stream ONLY while an enqueued
+ * factorisation is in flight on the panel stream (`lpgp_potrf_enqueue` without `lpgp_mat_check` yet) -- then nothing else
+ * can be reading the weights / residual buffer, because every entry point that reads it (lpgp_predict, lpgp_potrf_predict,
+ * lpgp_solve_weights, lpgp_potrs) returns only after its device work has completed.                                  */
 int  lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out);
 int  lpgp_rhs_destroy(lpgp_rhs* rhs);
 /* rows of block bi of K_Xx <- sum_g (kd[g])(X_obs, X_test)   (n_bi x m)                 */
@@ -262,6 +271,19 @@ int  lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
 int  lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K,
                   const double* prior_mean_host, const double* kxx_host,
                   double* mean_host, double* var_host);
+/* FACTOR WHAT IS NOT FACTORED YET AND PREDICT, IN ONE PIPELINE (round 5).  Same outputs as lpgp_predict with mean and
+ * variance requested and a residual resident (lpgp_mat_set_residual): V = L^{-1} K_Xx, mean = m + V^T (L^{-1} r), var =
+ * k_xx - colsum(V^2) -- but the forward substitution of K_Xx (and of the residual, the spare column) rides INSIDE the
+ * factorisation of the blocks declared since the last factorisation: every panel of the factor hands its columns to the
+ * substitution the moment its chain is complete, and the substitution's panel steps run on a stream of their own,
+ * never on the factorisation's critical path (potrf.hip, `ride_panel`).  The algebra is `BlockMatrix2x2.L_A_inv_B`
+ * (linops/_block.py:203-207) applied to the cross-covariance `PriorPredictiveCrossCovariance._evaluate`
+ * (_conditional.py:140-153) panel by panel; the values are those of lpgp_potrf_enqueue + lpgp_predict, kernel for kernel.
+ * The factorisation's status is NOT read: lpgp_mat_check afterwards (a Gram matrix that is not positive definite yields
+ * a prediction computed on garbage, to be discarded).  If everything is factored already this is lpgp_predict.
+ * Single GPU.                                                                                                       */
+int  lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_mean_host,
+                        const double* kxx_host, double* mean_host, double* var_host);
 /* V <- L^{-1} V  (forward substitution on all m columns)                                */
 int  lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V);
 /* out_host (ma x mb, C-order) = A^T B   (covariance update V0^T V1)                     */

@@ -345,6 +345,9 @@ int lpgp_init(int device, lpgp_ctx** out) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_fact[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_a1[i], hipEventDisableTiming));
   }
+  for (int i = 0; i < 3; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
+  if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
@@ -412,6 +415,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
     (void)hipEventDestroy(p.e1);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
@@ -495,6 +499,8 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "nb_solve") == 0) *value = ctx->nb_solve;
   else if (std::strcmp(key, "solve_chain_us_tile") == 0) *value = (int64_t)ctx->solve_chain_us_tile;
   else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
+  else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
+  else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else LPGP_CHECK(false, "unknown option %s", key);
   return 0;
 }
@@ -562,6 +568,10 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->nb_big_min_tiles = (int)value;
   } else if (std::strcmp(key, "lookahead") == 0) {
     ctx->lookahead = value != 0;
+  } else if (std::strcmp(key, "ride_stream") == 0) {
+    ctx->ride_stream = (int)value;
+  } else if (std::strcmp(key, "ride_occ3") == 0) {
+    ctx->ride_occ3 = value != 0;
   } else {
     LPGP_CHECK(false, "unknown option %s", key);
   }
@@ -1102,6 +1112,8 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
   LPGP_CHECK(lazy == 0 || !ctx->distributed(), "lpgp_mat_condition: lazy status on a single GPU only");
   LPGP_DEVICE(ctx);
   if (info) *info = 0;
+  if (lazy != 0 && mat->pn_fact < mat->pn) LPGP_TRY(lpgp_potrf_enqueue(ctx, mat));     // an earlier block deferred with lazy == 2
+  LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_condition: earlier blocks are not factored (lpgp_potrf first)");
   const int bi = lpgp_mat_add_block(ctx, mat, n);
   if (bi < 0) return bi;
   int rc = 0;
@@ -1132,7 +1144,9 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
     }
   }
   int32_t h = 0;
-  if (rc == 0) rc = lazy ? lpgp_potrf_enqueue(ctx, mat) : lpgp_potrf(ctx, mat, &h);
+  // lazy == 2: the block row is assembled and the factorisation is left to whoever needs the factor first -- the next
+  // lpgp_mat_condition / lpgp_potrf / lpgp_potrf_enqueue, or lpgp_potrf_predict, which lets the prediction ride inside it
+  if (rc == 0 && lazy != 2) rc = lazy ? lpgp_potrf_enqueue(ctx, mat) : lpgp_potrf(ctx, mat, &h);
   if (rc != 0 || h != 0) {
     // keep the error text of the failing step: lpgp_mat_pop_block succeeds and would not touch it, but be explicit
     const std::string msg = lpgp::last_error();
@@ -1249,7 +1263,7 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
 int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
   LPGP_CHECK(ctx && mat && r_host, "lpgp_mat_set_residual: null argument");
   LPGP_DEVICE(ctx);
-  LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_mat_set_residual: matrix is not factored");
+  LPGP_CHECK(mat->pn > 0, "lpgp_mat_set_residual: empty matrix");      // (factored or not: lpgp_potrf_predict takes it along)
   std::vector<double> hp((size_t)mat->pn);
   scatter_padded(mat, r_host, hp.data());
   // NOT on the panel stream: the residual's place in HBM is touched by no kernel of the factorisation, so the upload need
@@ -1403,6 +1417,45 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
       LPGP_TRY(sync_stream(ctx, ctx->s_main));
     }
     for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - h[j];
+  }
+  return 0;
+}
+
+int lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_mean_host, const double* kxx_host,
+                       double* mean_host, double* var_host) {
+  LPGP_CHECK(ctx && mat && K && kxx_host && mean_host && var_host, "lpgp_potrf_predict: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed(), "lpgp_potrf_predict: single GPU only (a multi-GPU job factors collectively: lpgp_potrf, lpgp_predict)");
+  LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf_predict: a strict prefix of the blocks is in view");
+  LPGP_CHECK(K->ld == mat->pn && mat->pn > 0, "lpgp_potrf_predict: right-hand side built for another matrix size");
+  LPGP_CHECK(mat->has_r, "lpgp_potrf_predict: no residual resident (lpgp_mat_set_residual)");
+  const int64_t m = K->m;
+  int rc = ensure_tmp(ctx, 2 * K->m_pad);
+  if (rc != 0) return rc;
+  rc = rhs_clear_unassembled(ctx, mat, K);
+  if (rc != 0) return rc;
+  double* zcol = K->v + (int64_t)m * K->ld;             // the residual rides as the spare column: z = L^{-1} r, mean = V^T z
+  LPGP_HIP(hipMemcpyAsync(zcol, mat->r(), (size_t)mat->pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main));
+  const bool fresh = mat->pn_fact < mat->pn;
+  ctx->d_info_cur = mat->d_status;
+  rc = potrf_predict_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, K->v, K->ld, K->m_pad);
+  if (rc != 0) return rc;
+  if (fresh) {
+    mat->pn_fact = mat->pn;          // provisionally, as lpgp_potrf_enqueue: lpgp_mat_check / lpgp_mat_truncate take it back on failure
+    mat->unchecked = 1;
+    mat->has_w = 0;
+  }
+  hipLaunchKernelGGL(col_reduce2_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn, (const double*)zcol, ctx->d_tmp,
+                     ctx->d_tmp + K->m_pad);
+  LPGP_HIP(hipGetLastError());
+  std::vector<double> h((size_t)m), h2((size_t)m);
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
+  LPGP_HIP(hipMemcpyAsync(h2.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+  LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp + K->m_pad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+  LPGP_TRY(sync_stream(ctx, ctx->s_main));
+  for (int64_t j = 0; j < m; ++j) {
+    mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h2[j];
+    var_host[j] = kxx_host[j] - h[j];
   }
   return 0;
 }

@@ -92,6 +92,9 @@ struct lpgp_ctx {
   int64_t nb_outer = 2048;             // far columns are updated once per nb_outer columns (0 or <= nb: every panel) ...
   int nb_outer_min_tiles = 192;        // ... while more than this many tile columns remain
   int reserve_narrow = 64;
+  hipEvent_t ev_ride[3] = {nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2]
+  int ride_stream = 0;                 // ... runs on: 0 s_outer (masked like s_upd), 1 s_upd_all (unmasked), 2 s_upd_narrow, other: the panel stream
+  int ride_occ3 = 0;                   // ... its updates may use the three-workgroups-per-CU kernel
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};
   int64_t nb = 512;                // panel width of the blocked Cholesky
@@ -341,6 +344,7 @@ int debug_tile_xcc(int32_t* out8, int reset);
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,
                       int* d_info, int info_base);
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
+int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 // dist.hip: Pr x Pc block-cyclic factorisation and panel-streaming solves
 int potrf_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, int32_t* info);
 int trsm_lower_dist(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);

@@ -369,12 +369,69 @@ static inline int panel_trsm(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int j
                           LPGP_K_TRSM);
 }
 
+// ---- ride-along forward substitution (round 5) -------------------------------------------------------------------
+// `lpgp_potrf_predict`: V = L^{-1} K_Xx is computed INSIDE the factorisation instead of after it.  A panel step of the
+// forward substitution -- V[panel rows] <- L_KK^{-1} V[panel rows] (fused panel chain), then V[rows below] -=
+// L[rows below, panel] V[panel rows] -- needs nothing but the panel's own columns of L, which are final as soon as
+// the panel's chain is (its tile solves run down to the last row).  So every panel of the factorisation -- the old
+// panels a block append pushes its new rows through included -- hands its columns over by ONE event, and the
+// substitution's steps follow on a stream of their own (`ride->stream`), as far behind the factorisation as the chip
+// leaves them: they are never on the factorisation's critical path, they fill the phase where the panel chain bounds
+// it (the last third of c3, all of c2), and the second pipeline with its start-up and its own chain-bound tail is gone.
+// The kernels are the forward substitution's (trsm_lower_blocked), launch for launch; only the schedule differs.
+// (Reference: the same algebra as `BlockMatrix2x2.L_A_inv_B`, linops/_block.py:203-207, applied to K_Xx panel by panel.)
+struct Ride {
+  double* v = nullptr;       // K_Xx -> V, padded rows x m_pad, column-major
+  int64_t ldv = 0;
+  int mtl = 0;               // tile columns (m_pad / 128)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int it = 0;
+};
+
+// panel [p0, p1) of the factor is final on the panel stream from here on: enqueue its substitution step(s)
+static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd) {
+  const int64_t ld = mat->cap, tb = TILE;
+  const double* a = mat->a;
+  hipStream_t sV = rd->stream;
+  if (sV != ctx->s_main) {
+    hipEvent_t ev = rd->ev[rd->it++ & 1];
+    LPGP_HIP(hipEventRecord(ev, ctx->s_main));
+    LPGP_HIP(hipStreamWaitEvent(sV, ev, 0));
+  }
+  for (int q0 = p0; q0 < p1; q0 += 4) {
+    const int q1 = (q0 + 4 < p1) ? q0 + 4 : p1;
+    double* Vq = rd->v + (int64_t)q0 * tb;
+    if (ctx->fused_solve) {
+      LPGP_TRY(launch_trsv_panel(ctx, sV, Vq, rd->ldv, mat->linv + (int64_t)q0 * tb * tb, a + (int64_t)q0 * tb * (ld + 1), ld, q1 - q0,
+                                 rd->mtl, LPGP_K_PANEL));
+    } else {
+      for (int jt = q0; jt < q1; ++jt) {
+        double* Vj = rd->v + (int64_t)jt * tb;
+        LPGP_TRY(launch_trsv_tile(ctx, sV, Vj, rd->ldv, mat->linv + (int64_t)jt * tb * tb, a + (int64_t)jt * tb * (ld + 1), ld, rd->mtl, LPGP_K_TRSM));
+        if (jt + 1 < q1)
+          LPGP_TRY(launch_gemm(ctx, sV, 0, 1,
+                               mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, rd->ldv, rd->v + (int64_t)(jt + 1) * tb, rd->ldv,
+                                  q1 - jt - 1, rd->mtl, TILE, -1.0, 1.0, 0),
+                               LPGP_K_GEMM));
+      }
+    }
+    if (q1 < T) {
+      GemmArgs g = mk(a + (int64_t)q1 * tb + (int64_t)q0 * tb * ld, ld, Vq, rd->ldv, rd->v + (int64_t)q1 * tb, rd->ldv, T - q1, rd->mtl,
+                      (q1 - q0) * TILE, -1.0, 1.0, 0);
+      g.occ3 = ctx->ride_occ3;
+      LPGP_TRY(launch_gemm(ctx, sV, 0, 1, g, LPGP_K_GEMM));
+    }
+  }
+  return 0;
+}
+
 // Factor tile columns [c0, cl) (all rows down to T) right-looking by panels of nb columns with a
 // look-ahead of one panel; the rank-nb updates touch only columns < cl (cl == T: the whole trailing
 // matrix).  `dep`: event behind the last write to columns [c0 + nb, cl) by an earlier launch on
 // another stream (null: none); the first panel chain does not wait for it, the first update does.
 // On return the panel stream is behind every update of the call.
-static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, hipStream_t sU, hipEvent_t dep) {
+static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, hipStream_t sU, hipEvent_t dep, Ride* ride) {
   const int64_t ld = mat->cap;
   double* a = mat->a;
   const int nbt = (int)(ctx->nb / TILE);
@@ -416,6 +473,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
                                LPGP_K_SYRK_PANEL));
       }
     }
+    if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride));          // columns [p0, p1) are final: their substitution step follows on the ride stream
     if (p1 >= cl) break;
     const int K = (p1 - p0) * TILE;
     const double* P = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;      // panel rows below
@@ -481,7 +539,41 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
 }
 
 // Factor tile columns [t_done, T) of the padded matrix; columns [0, t_done) already hold L.
+static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride);
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
+  return potrf_blocked_impl(ctx, mat, t_done64, T64, info, nullptr);
+}
+
+// The factorisation of tile columns [t_done, T) with the forward substitution of `v` (T * 128 rows x m_pad columns, leading
+// dimension ldv) riding inside it: on return (everything enqueued, the panel stream behind all of it) v holds L^{-1} v for
+// the WHOLE factor, old panels included.  Status as with info == nullptr: the matrix's sticky word.
+int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, double* v, int64_t ldv, int64_t m_pad) {
+  Ride rd;
+  rd.v = v; rd.ldv = ldv; rd.mtl = (int)(m_pad / TILE);
+  // the ride stream: a masked update stream that is idle during a factorisation of this size (HIP multiplexes a process's
+  // streams over four hardware queues: no new stream)
+  hipStream_t cand[3] = {ctx->s_outer, ctx->s_upd_all, ctx->s_upd_narrow};
+  rd.stream = (ctx->ride_stream >= 0 && ctx->ride_stream < 3 && cand[ctx->ride_stream]) ? cand[ctx->ride_stream] : ctx->s_main;
+  if (ctx->single_stream) rd.stream = ctx->s_main;
+  rd.ev[0] = ctx->ev_ride[0]; rd.ev[1] = ctx->ev_ride[1];
+  // everything enqueued on the panel stream so far (cross-covariance assembly, residual column) precedes the first step
+  if (rd.stream != ctx->s_main) {
+    LPGP_HIP(hipEventRecord(ctx->ev_ride[2], ctx->s_main));
+    LPGP_HIP(hipStreamWaitEvent(rd.stream, ctx->ev_ride[2], 0));
+  }
+  if (t_done >= T) {
+    // nothing left to factor: the plain substitution
+    return trsm_lower_blocked(ctx, mat, T, v, ldv, m_pad);
+  }
+  LPGP_TRY(potrf_blocked_impl(ctx, mat, t_done, T, nullptr, &rd));
+  if (rd.stream != ctx->s_main) {
+    LPGP_HIP(hipEventRecord(ctx->ev_ride[2], rd.stream));
+    LPGP_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ride[2], 0));
+  }
+  return 0;
+}
+
+static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride) {
   const int T = (int)T64, t_done = (int)t_done64;
   const int64_t ld = mat->cap;
   double* a = mat->a;
@@ -513,6 +605,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
                                   rows + (int64_t)(jt + 1) * tb * ld, ld, mnew, p1 - jt - 1, TILE, -1.0, 1.0, 0),
                                LPGP_K_GEMM));
       }
+      if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride));        // the old panel's columns, new rows included, are final
       const int K = (p1 - p0) * TILE;
       double* Xp = rows + (int64_t)p0 * tb * ld;
       if (p1 < t_done)
@@ -551,7 +644,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
   for (int q0 = t_done; q0 < T; ++oit) {
     const bool outer = la && NBt > nbt && (T - q0) > ctx->nb_outer_min_tiles && (T - q0) > NBt;
     const int q1 = outer ? q0 + NBt : T;
-    LPGP_TRY(factor_columns(ctx, mat, T, q0, q1, sU, ev_a1));
+    LPGP_TRY(factor_columns(ctx, mat, T, q0, q1, sU, ev_a1, ride));
     if (q1 >= T) break;
     hipEvent_t ev_fact = ctx->ev_outer_fact[oit & 1];
     LPGP_HIP(hipEventRecord(ev_fact, sP));             // outer panel [q0, q1) is final (factor_columns joins its updates into sP)

@@ -154,7 +154,9 @@ class Context:
         check(lib.lpgp_sync(self._h), "lpgp_sync")
 
     def set_option(self, key: str, value: int):
+        global _option_epoch
         check(lib.lpgp_set_option(self._h, key.encode(), int(value)), "lpgp_set_option")
+        _option_epoch += 1           # cached predictions were computed with other kernels / schedules
 
     def get_option(self, key: str) -> int:
         v = C.c_int64()
@@ -202,6 +204,12 @@ class Context:
 
 _default_ctx = None
 _default_lock = threading.Lock()
+_option_epoch = 0
+
+
+def option_epoch() -> int:
+    """Bumped by every `Context.set_option`: a posterior's cached last prediction is valid for one epoch."""
+    return _option_epoch
 
 
 def default_context() -> Context:
@@ -389,10 +397,11 @@ class GramMatrix:
         check(lib.lpgp_potrf(self.ctx._h, self._h, C.byref(info)), "lpgp_potrf")
         return info.value
 
-    def condition(self, n: int, X_new: "Points", row, noise_scalar: float = 0.0, noise_diag=None, noise_dense=None, lazy: bool = True) -> int:
+    def condition(self, n: int, X_new: "Points", row, noise_scalar: float = 0.0, noise_diag=None, noise_dense=None, lazy: "bool | int" = True) -> int:
         """One conditioning in one call (`lpgp_mat_condition`): declare the block of `n` rows, assemble its block row --
         `row` = [(kdesc, X_j or None)] for every earlier block j and, last, the diagonal block --, add the noise, factor
-        (`lazy`: enqueue).  Returns the factorisation status (0 when lazy).  On failure -- an error, or a status != 0 --
+        (`lazy` = 1: enqueue; 2: assemble only, the factorisation is left to the first call that needs the factor).  Returns
+        the factorisation status (0 when lazy).  On failure -- an error, or a status != 0 --
         the block has been dropped again."""
         arr = (_lib.CondBlock * len(row))()
         keep = []
@@ -418,7 +427,7 @@ class GramMatrix:
             raise ValueError("dense noise block has the wrong shape")
         info = C.c_int32()
         check(lib.lpgp_mat_condition(self.ctx._h, self._h, int(n), X_new._h, arr, len(arr), float(noise_scalar),
-                                     as_pd(nd) if nd is not None else None, as_pd(nD) if nD is not None else None, int(bool(lazy)), C.byref(info)),
+                                     as_pd(nd) if nd is not None else None, as_pd(nD) if nD is not None else None, int(lazy), C.byref(info)),
               "lpgp_mat_condition")
         if info.value == 0:
             self.block_sizes.append(int(n))
@@ -498,6 +507,16 @@ class Rhs:
                                as_pd(kx) if kx is not None else None,
                                as_pd(mean) if mean is not None else None,
                                as_pd(var) if var is not None else None), "lpgp_predict")
+        return mean, var
+
+    def potrf_predict(self, prior_mean: np.ndarray | None, kxx: np.ndarray):
+        """Factor the blocks that are not factored yet and predict mean and variance in ONE pipeline (`lpgp_potrf_predict`):
+        the forward substitution of this right-hand side rides inside the factorisation.  The status is not read here."""
+        mean, var = np.empty(self.m), np.empty(self.m)
+        pm = np.ascontiguousarray(prior_mean, dtype=np.double) if prior_mean is not None else None
+        kx = np.ascontiguousarray(kxx, dtype=np.double)
+        check(lib.lpgp_potrf_predict(self.ctx._h, self.mat._h, self._h, as_pd(pm) if pm is not None else None, as_pd(kx),
+                                     as_pd(mean), as_pd(var)), "lpgp_potrf_predict")
         return mean, var
 
     def inner(self, other: "Rhs") -> np.ndarray:

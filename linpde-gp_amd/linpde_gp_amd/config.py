@@ -26,3 +26,10 @@ use_grid_assembly: bool = True
 # surfaces differs from the reference.  `bench.py` opts in and says so in its line.
 # Multi-GPU jobs always check inside `condition_on_observations` (the ranks agree on the status collectively).
 lazy_factorization: bool = False
+
+# Lazy mode only: a MEAN-only request (`u.mean(x)`) on a posterior whose factorisation is still deferred takes the fused
+# factor-and-predict pipeline and keeps the variance for the `u.std(x)` / `u.var(x)` on the same points that usually
+# follows (notebook 0001 cell 22 calls `u.mean(grid)`, then `u.std(grid)`): the pair then costs one `predict`.  Off by
+# default: a caller who never asks for the variance would pay the forward substitution of the cross-covariance for nothing.
+# (Independently of this flag every posterior keeps its LAST prediction, so `mean(x)` after `predict(x)` is free.)
+variance_with_mean: bool = False

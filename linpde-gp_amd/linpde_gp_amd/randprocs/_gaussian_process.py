@@ -229,8 +229,16 @@ class _DeviceState:
         self.weights_key = None
         self.residual_key = None
         self.blocks = list(blocks)   # the observation blocks in the matrix, in order (identity decides whether an object is alive)
-        self.pending = False         # factorisations enqueued whose status has not been read (config.lazy_factorization)
+        self.pending = False         # factorisations enqueued (or deferred) whose status has not been read (config.lazy_factorization)
+        self.deferred = False        # the newest block is assembled but its factorisation not even enqueued: whoever needs the
+                                     # factor first enqueues it (`flush`) -- or `predict`, which rides inside it (`lpgp_potrf_predict`)
         self.failure = None          # message of the last failure found by `verify`
+
+    def flush(self) -> None:
+        """Enqueue the factorisation of a block that was only assembled so far."""
+        if self.deferred:
+            self.deferred = False
+            self.mat.potrf_enqueue()
 
     def invalidate(self) -> None:
         """The device dropped the resident representer weights / residual (`lpgp_mat_add_block`, `lpgp_mat_pop_block`
@@ -243,6 +251,7 @@ class _DeviceState:
         """Read the status of the enqueued factorisations (one host synchronisation, at the first use of the factor).
         A block that was not positive definite is dropped together with everything appended after it -- the leading
         part of the factor is untouched by an append -- and the objects that own those blocks raise from now on."""
+        self.flush()
         if not self.pending:
             return
         self.pending = False
@@ -265,6 +274,7 @@ class _DeviceState:
         if nblocks == 0:
             return
         if self.mat.num_blocks != nblocks:
+            self.flush()             # (a view is a statement about the FACTOR: nothing stays merely assembled behind it)
             self.mat.set_view(nblocks)
         if self.view != nblocks:
             self.view = nblocks
@@ -304,6 +314,7 @@ class ConditionalGaussianProcess(GaussianProcess):
             if len(state.blocks) != len(old_blocks):
                 state = _DeviceState(state.ctx, state.mat.clone(len(old_blocks)), old_blocks)
         state.use(len(old_blocks))
+        state.flush()                # a block the previous conditioning only assembled is factored before the next one is declared
         mat = state.mat
         base = prior.cov
         state.invalidate()           # the device drops the resident weights / residual with the new block (also when it is rolled back)
@@ -326,12 +337,15 @@ class ConditionalGaussianProcess(GaussianProcess):
                     diag = np.ascontiguousarray(np.diag(cov), dtype=np.double)
             if diag is not None and diag.size and np.all(diag == diag.flat[0]):
                 scalar, diag = float(diag.flat[0]), None          # sigma^2 I: nothing to upload
-        info = mat.condition(n, new_block.points, row, noise_scalar=scalar, noise_diag=diag, noise_dense=dense, lazy=lazy)
+        # lazy: the block is assembled and its factorisation DEFERRED to the first call that needs the factor (the next
+        # conditioning, `mean`, `cov`, `representer_weights`, ... enqueue it; a `predict` rides inside it)
+        info = mat.condition(n, new_block.points, row, noise_scalar=scalar, noise_diag=diag, noise_dense=dense, lazy=2 if lazy else 0)
         if info != 0:
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
         state.blocks.append(new_block)
         state.pending = state.pending or lazy
+        state.deferred = lazy
         blocks = tuple(old_blocks) + (new_block,)
         # the representer weights are solved on first use (`representer_weights`, `mean`, ...):
         # in a chain of conditionings only the last object's weights are ever needed
@@ -350,6 +364,8 @@ class ConditionalGaussianProcess(GaussianProcess):
         # collector happens to run (measured at c4: a fresh 35 GB hipMalloc per step, +1 s)
         self._mean = None
         self._cov = None
+        self._pred_cache = None      # (option epoch, points, mean, var or None) of the last prediction: a posterior is an immutable
+                                     # value, so `u.mean(x)` followed by `u.std(x)` (notebook 0001 cell 22) shares one pass
 
     @property
     def mean(self):
@@ -515,10 +531,13 @@ class ConditionalGaussianProcess(GaussianProcess):
         solves for its own columns of the cross-covariance while the sharded factor is streamed past it panel by
         panel (`trsm_lower_dist`), and the results are gathered over the control plane; every rank returns the
         full arrays.  Collective: every rank calls it with the same `x`."""
+        X, batch = self._flat(x)
+        hit = self._cached_prediction(x, X, return_var)
+        if hit is not None:
+            return (hit[0].reshape(batch).copy(), hit[1].reshape(batch).copy()) if return_var else hit[0].reshape(batch).copy()
         speculative = self._use_unverified()
         if not speculative:
             self._check_current()
-        X, batch = self._flat(x)
         ctx = self._state.ctx
         if X.shape[0] == 0 or not self._blocks:
             if speculative:
@@ -540,21 +559,48 @@ class ConditionalGaussianProcess(GaussianProcess):
         mean, var = self._predict_local(x, X, return_var, speculative)
         if speculative:
             self._verify_after()
+        self._pred_cache = (_engine.option_epoch(), X.copy(), mean.copy(), None if var is None else var.copy())
         mean = mean.reshape(batch)
-        return (mean, var.reshape(batch)) if return_var else mean
+        if not return_var:
+            return mean
+        return mean, var.reshape(batch)
+
+    def _cached_prediction(self, x, X, need_var):
+        c = self._pred_cache
+        if c is None or (need_var and c[3] is None):
+            return None
+        # same points BY VALUE (the caller may have changed its array in place), same tuning options of the library
+        if c[0] != _engine.option_epoch() or c[1].shape != X.shape or not np.array_equal(c[1], X):
+            return None
+        return c[2], c[3]
 
     def _predict_local(self, x_original, X, return_var, speculative=False):
         # the cross-covariance launches first: the device assembles it while the host stages the residual (a 135-KB upload
         # at c3, on the copy stream) or the weights are solved for
         if not speculative:
             self._check_current()
-        pts = _engine.as_points(self._state.ctx, x_original, X)
+        from .. import config
+
+        st = self._state
+        pts = _engine.as_points(st.ctx, x_original, X)
+        # A factorisation that is still deferred (lazy mode, this object's own block): the prediction rides INSIDE it
+        # (`lpgp_potrf_predict`) -- for mean and variance together; a mean-only request takes that pipeline too if
+        # `config.variance_with_mean` is set (the variance is kept for the `std(x)` that usually follows), else it enqueues
+        # the factorisation and solves for the weights
+        fuse = speculative and st.deferred and self._representer_weights is None and (return_var or config.variance_with_mean)
+        if not fuse:
+            st.flush()
         rhs = self._cross(pts)
+        pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])
+        if fuse:
+            self._ensure_residual()
+            kxx = np.full(X.shape[0], self._prior_diag())
+            st.deferred = False
+            return rhs.potrf_predict(pm, kxx)
         if return_var and self._representer_weights is None:
             self._ensure_residual()
         else:
             self._ensure_weights()
-        pm = self._prior_mean_at(X if self.input_ndim else X[:, 0], X.shape[0])
         kxx = np.full(X.shape[0], self._prior_diag()) if return_var else None
         return rhs.predict(pm, kxx, want_mean=True, want_var=return_var)
 

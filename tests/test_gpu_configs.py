@@ -37,12 +37,28 @@ def _run(lp, wl):
         lp.config.gram_capacity_hint = 0
 
 
-def _vs_oracle(lp, wl):
+def _run_fused(lp, wl):
+    """The same sequence in the opt-in throughput mode: factorisations enqueued, the prediction riding inside the last one
+    (`lpgp_potrf_predict`)."""
+    saved = lp.config.lazy_factorization
+    lp.config.lazy_factorization = True
+    try:
+        return _run(lp, wl)
+    finally:
+        lp.config.lazy_factorization = saved
+
+
+def _vs_oracle(lp, wl, ref=None):
+    """BOTH modes of the package against ONE oracle run: the default (status read back inside every conditioning, prediction
+    as a second pipeline) and the fused factor-and-predict pipeline; and against each other."""
     u, mean, var = _run(lp, wl)
-    ref = owl.run(wl)
+    ref = owl.run(wl) if ref is None else ref
     rm, rv = assert_posterior_close(mean, var, ref["mean"], ref["var"])
-    print(f"{wl.name}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} mean err {rm:.2e} x tol, var err {rv:.2e} x tol; "
-          f"oracle {ref['seconds']['total']:.1f} s")
+    uf, mean_f, var_f = _run_fused(lp, wl)
+    fm, fv = assert_posterior_close(mean_f, var_f, ref["mean"], ref["var"])
+    del uf
+    print(f"{wl.name}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} mean err {rm:.2e} x tol, var err {rv:.2e} x tol "
+          f"(fused pipeline: {fm:.2e}, {fv:.2e}); oracle {ref['seconds']['total']:.1f} s")
     return u, mean, var, ref
 
 
@@ -118,8 +134,11 @@ def test_c5_heat_full_size_vs_oracle(lp):
     del u
     ref = owl.run_in_place(wl, chunk=1024, workers=workers)
     rm, rv = assert_posterior_close(mean, var, ref["mean"], ref["var"])
-    print(f"{wl.name}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} mean err {rm:.2e} x tol, var err {rv:.2e} x tol; "
-          f"oracle {ref['seconds']['total']:.1f} s ({workers} assembly threads)")
+    uf, mean_f, var_f = _run_fused(lp, wl)            # the fused factor-and-predict pipeline against the same oracle run
+    del uf
+    fm, fv = assert_posterior_close(mean_f, var_f, ref["mean"], ref["var"])
+    print(f"{wl.name}: N_tot={wl.n_total} M={wl.Xtest.shape[0]} mean err {rm:.2e} x tol, var err {rv:.2e} x tol "
+          f"(fused pipeline: {fm:.2e}, {fv:.2e}); oracle {ref['seconds']['total']:.1f} s ({workers} assembly threads)")
 
 
 def test_c4_poisson2d_256_properties(lp):

@@ -1,0 +1,183 @@
+"""The fused factor-and-predict pipeline (`lpgp_potrf_predict`, round 5): in the opt-in lazy mode a conditioning only
+assembles its block; the first call that needs the factor enqueues the factorisation -- and a `predict` lets the forward
+substitution of the cross-covariance ride INSIDE it (potrf.hip, `ride_panel`).  Same numbers as the two pipelines of the
+default mode (1e-12), same numbers as the oracle (the one criterion of tests/conftest.py), for every shape of chain:
+single block, appended blocks (old panels), ragged sizes, multi-panel factors, wide and narrow right-hand sides.
+Reference sequence mirrored: `u.mean(x)`, `u.std(x)` (experiments/0001_poisson_dirichlet_2d.ipynb cell 22;
+`_conditional.py:193-197,223-231`).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_posterior_close
+from oracle import covfuncs as ocf
+from oracle import gp as ogp
+from oracle import workloads as owl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lp():
+    import linpde_gp_amd
+    return linpde_gp_amd
+
+
+@pytest.fixture
+def lazy(lp):
+    saved = (lp.config.lazy_factorization, lp.config.variance_with_mean)
+    lp.config.lazy_factorization = True
+    yield lp
+    lp.config.lazy_factorization, lp.config.variance_with_mean = saved
+
+
+def _both_modes(lp, wl):
+    from linpde_gp_amd import problems
+    lp.config.lazy_factorization = False
+    u0, m0, v0 = problems.condition_and_predict(wl)
+    lp.config.lazy_factorization = True
+    u1, m1, v1 = problems.condition_and_predict(wl)
+    return (u0, m0, v0), (u1, m1, v1)
+
+
+@pytest.mark.parametrize("name,make", [
+    ("poisson2d_24", lambda P: P.poisson_2d(n_side=24, n_bdry=24, m_side=12)),            # 5 blocks, 6 tiles, one appended panel
+    ("poisson2d_40_ragged", lambda P: P.poisson_2d(n_side=40, n_bdry=37, m_side=17)),      # ragged blocks, 4 old tiles + 13 new
+    ("poisson1d_1500", lambda P: P.poisson_1d(1500, m=300)),                                # 13 tiles: four panels, narrow RHS
+    ("poisson1d_c1", lambda P: P.poisson_1d(512, n_bdry_repeats=16, noise_var=1e-4, m=256)),
+    ("heat_small", lambda P: P.heat_1d(nt=48, nx=24, m_side=20)),                           # mixed blocks, a block AFTER the big one
+    ("scattered_2000", lambda P: P.scattered_2d(n=2000, m=700)),                            # ONE block: no append phase at all
+    ("heat_reference", lambda P: P.heat_reference()),
+])
+def test_fused_pipeline_equals_two_pipelines_and_oracle(lazy, name, make):
+    from linpde_gp_amd import problems
+    lp = lazy
+    wl = make(problems)
+    (u0, m0, v0), (u1, m1, v1) = _both_modes(lp, wl)
+    assert u1._state.deferred is False and u1._state.pending is False
+    sm, sv = np.max(np.abs(m0)), np.max(np.abs(v0))
+    assert np.max(np.abs(m1 - m0)) <= 1e-12 * sm, np.max(np.abs(m1 - m0)) / sm
+    assert np.max(np.abs(v1 - v0)) <= 1e-12 * sv + 1e-13 * 1.0, np.max(np.abs(v1 - v0)) / sv
+    ref = owl.run(wl)
+    assert_posterior_close(m1, v1, ref["mean"], ref["var"])
+    # the factor the fused pipeline left behind IS the factor: weights, a second prediction elsewhere, the covariance
+    np.testing.assert_allclose(u1.representer_weights, u0.representer_weights, rtol=0, atol=1e-9 * np.max(np.abs(u0.representer_weights)))
+    xs = wl.Xtest[:5]
+    np.testing.assert_allclose(u1.cov.matrix(xs), u0.cov.matrix(xs), rtol=0, atol=1e-12 * max(sv, 1e-3))
+    m2, v2 = u1.predict(wl.Xtest[::3])
+    np.testing.assert_allclose(m2, m0[::3], rtol=0, atol=1e-12 * sm)
+    np.testing.assert_allclose(v2, v0[::3], rtol=0, atol=1e-12 * sv + 1e-13)
+
+
+def test_reference_sequence_mean_then_std(lazy):
+    """`u.mean(x)` then `u.std(x)` (notebook 0001 cell 22) == `u.predict(x)` to 1e-12, in the default mode, in the lazy mode,
+    and in the lazy mode with `variance_with_mean` (the mean call takes the fused pipeline and keeps the variance)."""
+    from linpde_gp_amd import problems
+    lp = lazy
+    wl = problems.poisson_2d(n_side=32, n_bdry=32, m_side=16)
+    lp.config.lazy_factorization = False
+    u, mean, var = problems.condition_and_predict(wl)
+    sd = np.sqrt(np.maximum(var, 0.0))
+    for lazy_mode, vwm in ((False, False), (True, False), (True, True)):
+        lp.config.lazy_factorization, lp.config.variance_with_mean = lazy_mode, vwm
+        prior = problems.build_prior(wl)
+        w = prior
+        for o in wl.observations:
+            X, Y = o.X_as_given()
+            b = None if o.noise_var is None else lp.randvars.Normal(np.zeros(Y.shape), np.full(o.X.shape[0], o.noise_var))
+            w = w.condition_on_observations(Y, X=X, L=problems.operator_of(o.op, wl.d), b=b)
+        assert w._state.deferred is lazy_mode
+        m = w.mean(wl.Xtest)
+        assert w._state.deferred is False
+        assert (w._pred_cache[3] is not None) is (lazy_mode and vwm)
+        s = w.std(wl.Xtest)
+        assert np.max(np.abs(m - mean)) <= 1e-12 * np.max(np.abs(mean)), (lazy_mode, vwm)
+        assert np.max(np.abs(s - sd)) <= 1e-12 * np.max(sd) + 1e-14, (lazy_mode, vwm)
+        # the cached prediction is keyed by the VALUES of the points
+        x2 = wl.Xtest.copy()
+        x2[0] += 0.01
+        m2 = w.mean(x2)
+        assert abs(m2[0] - m[0]) > 0 and np.max(np.abs(m2[1:] - m[1:])) <= 1e-12 * np.max(np.abs(mean))
+
+
+def test_deferred_block_is_factored_by_whoever_needs_it_first(lazy):
+    """Lazy mode: every way of touching the factor before a `predict` enqueues the deferred factorisation first."""
+    lp = lazy
+    cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 0.7)])]
+    ident = ocf.identity(1)
+    rng = np.random.default_rng(21)
+    X1, Y1 = rng.uniform(-1, 1, (150, 1)), rng.normal(size=150)
+    X2, Y2 = rng.uniform(-1, 1, (140, 1)), rng.normal(size=140)
+    Xt = np.linspace(-1, 1, 9)[:, None]
+    post = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2), ogp.ObsBlock(X2, ident, Y2, 0.0, 1e-2)])
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=0.7))
+
+    def chain():
+        u1 = prior.condition_on_observations(Y1, X1, b=lp.randvars.Normal(np.zeros(150), 1e-2 * np.eye(150)))
+        u2 = u1.condition_on_observations(Y2, X2, b=lp.randvars.Normal(np.zeros(140), 1e-2 * np.eye(140)))
+        assert u2._state.deferred
+        return u1, u2
+
+    for first_use in ("weights", "mean", "cov", "cholesky", "older_object", "predict"):
+        u1, u2 = chain()
+        if first_use == "weights":
+            np.testing.assert_allclose(u2.representer_weights, post.weights, rtol=1e-7, atol=1e-9)
+        elif first_use == "mean":
+            np.testing.assert_allclose(u2.mean(Xt), post.mean(Xt), rtol=0, atol=1e-8)
+        elif first_use == "cov":
+            np.testing.assert_allclose(u2.cov.matrix(Xt), post.cov(Xt), rtol=0, atol=1e-8)
+        elif first_use == "cholesky":
+            Lf = u2.gram.cholesky()
+            np.testing.assert_allclose(Lf @ Lf.T, post.G, rtol=0, atol=1e-10)
+        elif first_use == "older_object":
+            p1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
+            m1, v1 = u1.predict(Xt)                 # a view on the leading block: the newest block is factored behind it
+            np.testing.assert_allclose(m1, p1.mean(Xt), rtol=0, atol=1e-8)
+        assert (u2._state.deferred is False) or first_use == "predict"
+        m, v = u2.predict(Xt)
+        np.testing.assert_allclose(m, post.mean(Xt), rtol=0, atol=1e-8)
+        np.testing.assert_allclose(v, post.var(Xt), rtol=0, atol=1e-9)
+
+
+def test_fused_pipeline_on_a_matrix_that_is_not_positive_definite(lazy):
+    """The prediction that rode inside a failing factorisation is discarded; the object raises; its parent stays exact."""
+    lp = lazy
+    cf = lp.randprocs.covfuncs
+    okern = [(1.0, [("expquad", 1.0)])]
+    ident = ocf.identity(1)
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.ExpQuad((1,), lengthscales=1.0))
+    rng = np.random.default_rng(3)
+    X1, Y1 = rng.uniform(-1, 1, (300, 1)), rng.normal(size=300)
+    u1 = prior.condition_on_observations(Y1, X1, b=lp.randvars.Normal(np.zeros(300), 1e-2 * np.eye(300)))
+    Xbad = np.concatenate([np.array([[0.2], [0.2]]), rng.uniform(-1, 1, (200, 1))])
+    u2 = u1.condition_on_observations(np.zeros(202), Xbad, b=lp.randvars.Normal(np.zeros(202), -1e-3 * np.eye(202)))
+    Xt = np.linspace(-1, 1, 7)[:, None]
+    with pytest.raises(np.linalg.LinAlgError):
+        u2.predict(Xt)
+    with pytest.raises(np.linalg.LinAlgError):
+        u2.predict(Xt)
+    post1 = ogp.condition(okern, [ogp.ObsBlock(X1, ident, Y1, 0.0, 1e-2)])
+    m1, v1 = u1.predict(Xt)
+    np.testing.assert_allclose(m1, post1.mean(Xt), rtol=0, atol=1e-8 * np.max(np.abs(post1.mean(Xt))))
+    np.testing.assert_allclose(v1, post1.var(Xt), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("stream", [0, 1, 2, 3])
+def test_ride_stream_variants_agree(lazy, stream):
+    """The substitution's steps on each of the candidate streams (masked outer stream, unmasked, narrow, the panel stream
+    itself): same launches, same values."""
+    from linpde_gp_amd import _engine, problems
+    lp = lazy
+    ctx = _engine.default_context()
+    wl = problems.poisson_2d(n_side=40, n_bdry=40, m_side=24)
+    lp.config.lazy_factorization = False
+    _, m0, v0 = problems.condition_and_predict(wl)
+    lp.config.lazy_factorization = True
+    saved = ctx.get_option("ride_stream")
+    try:
+        ctx.set_option("ride_stream", stream)
+        _, m1, v1 = problems.condition_and_predict(wl)
+    finally:
+        ctx.set_option("ride_stream", saved)
+    assert np.max(np.abs(m1 - m0)) <= 1e-12 * np.max(np.abs(m0)) and np.max(np.abs(v1 - v0)) <= 1e-12 * np.max(np.abs(v0)) + 1e-13
