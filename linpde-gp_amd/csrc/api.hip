@@ -345,9 +345,14 @@ int lpgp_init(int device, lpgp_ctx** out) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_fact[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_a1[i], hipEventDisableTiming));
   }
-  for (int i = 0; i < 3; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
+  for (int i = 0; i < 4; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_OUTER_ROWS")) ctx->ride_outer_rows = std::atol(e);
+  if (const char* e = std::getenv("LPGP_RIDE_OUTER_MIN_TILES")) ctx->ride_outer_min_tiles = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_MAX_TILES")) ctx->ride_max_tiles = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_SAME_STREAM_MAX_TILES")) ctx->ride_same_stream_max_tiles = std::atoi(e);
   for (int i = 0; i < 2; ++i) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming));
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_upd[i], hipEventDisableTiming));
@@ -415,7 +420,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
     (void)hipEventDestroy(p.e1);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
@@ -501,6 +506,11 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
   else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
+  else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
+  else if (std::strcmp(key, "ride_outer_rows") == 0) *value = ctx->ride_outer_rows;
+  else if (std::strcmp(key, "ride_outer_min_tiles") == 0) *value = ctx->ride_outer_min_tiles;
+  else if (std::strcmp(key, "ride_max_tiles") == 0) *value = ctx->ride_max_tiles;
+  else if (std::strcmp(key, "ride_same_stream_max_tiles") == 0) *value = ctx->ride_same_stream_max_tiles;
   else LPGP_CHECK(false, "unknown option %s", key);
   return 0;
 }
@@ -572,6 +582,17 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->ride_stream = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {
     ctx->ride_occ3 = value != 0;
+  } else if (std::strcmp(key, "ride_gate_pct") == 0) {
+    ctx->ride_gate_pct = (int)value;
+  } else if (std::strcmp(key, "ride_outer_rows") == 0) {
+    LPGP_CHECK(value >= 0 && value % (4 * TILE) == 0, "ride_outer_rows must be a multiple of %d (0 disables)", 4 * TILE);
+    ctx->ride_outer_rows = value;
+  } else if (std::strcmp(key, "ride_outer_min_tiles") == 0) {
+    ctx->ride_outer_min_tiles = (int)value;
+  } else if (std::strcmp(key, "ride_max_tiles") == 0) {
+    ctx->ride_max_tiles = (int)value;
+  } else if (std::strcmp(key, "ride_same_stream_max_tiles") == 0) {
+    ctx->ride_same_stream_max_tiles = (int)value;
   } else {
     LPGP_CHECK(false, "unknown option %s", key);
   }

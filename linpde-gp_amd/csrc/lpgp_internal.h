@@ -92,9 +92,14 @@ struct lpgp_ctx {
   int64_t nb_outer = 2048;             // far columns are updated once per nb_outer columns (0 or <= nb: every panel) ...
   int nb_outer_min_tiles = 192;        // ... while more than this many tile columns remain
   int reserve_narrow = 64;
-  hipEvent_t ev_ride[3] = {nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2]
-  int ride_stream = 0;                 // ... runs on: 0 s_outer (masked like s_upd), 1 s_upd_all (unmasked), 2 s_upd_narrow, other: the panel stream
-  int ride_occ3 = 0;                   // ... its updates may use the three-workgroups-per-CU kernel
+  hipEvent_t ev_ride[4] = {nullptr, nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2, 3]
+  int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
+  int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
+  int ride_same_stream_max_tiles = 12; // ... on the panel stream itself for factors of at most this many tile rows
+  int64_t ride_outer_rows = 2048;      // ... two-level form: rows below an outer block of this many rows are updated once per block (0: every panel updates all rows below) ...
+  int ride_outer_min_tiles = 64;       // ... from this many tile rows on
+  int ride_max_tiles = 384;            // factors of at least this many tile rows: factorisation and substitution back to back instead (potrf.hip)
+  int ride_gate_pct = -1;              // (-1: by size, potrf.hip)              // ... its steps are held back until at most this percentage of the tile rows is left to factor (>= 100: released at once)
   hipEvent_t ev_panel[2] = {nullptr, nullptr};
   hipEvent_t ev_upd[2] = {nullptr, nullptr};
   int64_t nb = 512;                // panel width of the blocked Cholesky

@@ -15,6 +15,8 @@
 #include <climits>
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "lpgp_internal.h"
 #include "kernel_util.h"
 
@@ -384,43 +386,111 @@ struct Ride {
   double* v = nullptr;       // K_Xx -> V, padded rows x m_pad, column-major
   int64_t ldv = 0;
   int mtl = 0;               // tile columns (m_pad / 128)
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // the substitution's stream ...
+  hipStream_t stream2 = nullptr;    // ... and, optionally, a second one: the right-hand side's columns are independent, so its two halves
+                                    // run as two sequences of [panel chain, update]; while one half is in its latency-bound
+                                    // panel chain the other one's update has the chip (the look-ahead of trsm_lower_blocked
+                                    // without splitting any launch)
   hipEvent_t ev[2] = {nullptr, nullptr};
   int it = 0;
+  // The gate: while the trailing update bounds the factorisation the chip is full anyway, and substitution steps released
+  // then only take from the update what they gain (kernel trace, profiles/r05_fused_*: with every step released at once the
+  // factorisation stretches over the whole step and STILL ends with its chain-bound panels, because the substitution has
+  // kept pace and has no work left to fill them with).  So the steps are held back -- queued here -- until at most
+  // `gate_pct` per cent of the tile rows are left to factor; from then on the substitution's big early updates run beside
+  // the factorisation's chain-bound last part.  gate_pct >= 100: no gate.  Measured (ms per step; none / 58 / 48 / 36 %
+  // at c3: 53.4 / 52.7 / 52.1 / 52.6 against 55.4 for the two pipelines; c2 8.49 / - / 8.11 / - against 9.37).
+  int gate_pct = 100;
+  // Two-level form for large factors (the scheme of trsm_lower_two_level): inside an OUTER block of `outer_t` tile rows the
+  // rank-nb updates touch the block's own rows only; everything below is updated once per block with K = outer_t * 128 (every
+  // C tile of the right-hand side is then read and written once per 4 096 rows of contraction instead of once per 512: at c4,
+  // 66 560 x 16 512 doubles = 8.8 GB per pass).  0: every panel updates all rows below it.
+  int outer_t = 0;
+  int blk_q0 = 0;            // first tile row of the outer block the steps are in
+  bool open = true;
+  std::vector<std::pair<int, int>> held;
 };
+static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first);
 
 // panel [p0, p1) of the factor is final on the panel stream from here on: enqueue its substitution step(s)
 static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd) {
+  if (!rd->open) {
+    if ((int64_t)(T - p1) * 100 > (int64_t)rd->gate_pct * T && p1 < T) {
+      rd->held.emplace_back(p0, p1);
+      return 0;
+    }
+    rd->open = true;
+    bool first = true;
+    for (auto& h : rd->held) {
+      LPGP_TRY(ride_panel_now(ctx, mat, T, h.first, h.second, rd, first));
+      first = false;
+    }
+    rd->held.clear();
+    return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
+  }
+  return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
+}
+
+static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first) {
   const int64_t ld = mat->cap, tb = TILE;
   const double* a = mat->a;
-  hipStream_t sV = rd->stream;
-  if (sV != ctx->s_main) {
+  const bool two = rd->stream2 != nullptr && rd->stream2 != rd->stream && rd->mtl >= 8;
+  if (sync_first && (rd->stream != ctx->s_main || two)) {
     hipEvent_t ev = rd->ev[rd->it++ & 1];
     LPGP_HIP(hipEventRecord(ev, ctx->s_main));
-    LPGP_HIP(hipStreamWaitEvent(sV, ev, 0));
+    if (rd->stream != ctx->s_main) LPGP_HIP(hipStreamWaitEvent(rd->stream, ev, 0));
+    if (two && rd->stream2 != ctx->s_main) LPGP_HIP(hipStreamWaitEvent(rd->stream2, ev, 0));
   }
+  const int halves = two ? 2 : 1;
   for (int q0 = p0; q0 < p1; q0 += 4) {
     const int q1 = (q0 + 4 < p1) ? q0 + 4 : p1;
-    double* Vq = rd->v + (int64_t)q0 * tb;
-    if (ctx->fused_solve) {
-      LPGP_TRY(launch_trsv_panel(ctx, sV, Vq, rd->ldv, mat->linv + (int64_t)q0 * tb * tb, a + (int64_t)q0 * tb * (ld + 1), ld, q1 - q0,
-                                 rd->mtl, LPGP_K_PANEL));
-    } else {
-      for (int jt = q0; jt < q1; ++jt) {
-        double* Vj = rd->v + (int64_t)jt * tb;
-        LPGP_TRY(launch_trsv_tile(ctx, sV, Vj, rd->ldv, mat->linv + (int64_t)jt * tb * tb, a + (int64_t)jt * tb * (ld + 1), ld, rd->mtl, LPGP_K_TRSM));
-        if (jt + 1 < q1)
-          LPGP_TRY(launch_gemm(ctx, sV, 0, 1,
-                               mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, rd->ldv, rd->v + (int64_t)(jt + 1) * tb, rd->ldv,
-                                  q1 - jt - 1, rd->mtl, TILE, -1.0, 1.0, 0),
-                               LPGP_K_GEMM));
+    // Rows this step updates.  Two-level: down to the end of the current outer block -- plus a margin of three tile rows,
+    // because the steps (at most four tile rows each, on the panel grid of the factorisation, which an appended block
+    // shifts) need not end on the block grid: a step that starts before the block's end E ends before E + 4, so with the
+    // margin every row below E + 3 has all of the block's updates when the block closes, and the ONE outer update of the
+    // block (K = its height) takes the rows from E + 3 on.
+    int lim = T, outer_from = -1, outer_q0 = 0;
+    if (rd->outer_t > 0) {
+      const int E = rd->blk_q0 + rd->outer_t;
+      lim = std::min(T, E + 3);
+      if (q1 >= E || q1 >= T) {
+        outer_from = lim; outer_q0 = rd->blk_q0;
+        rd->blk_q0 = q1;
       }
     }
-    if (q1 < T) {
-      GemmArgs g = mk(a + (int64_t)q1 * tb + (int64_t)q0 * tb * ld, ld, Vq, rd->ldv, rd->v + (int64_t)q1 * tb, rd->ldv, T - q1, rd->mtl,
-                      (q1 - q0) * TILE, -1.0, 1.0, 0);
-      g.occ3 = ctx->ride_occ3;
-      LPGP_TRY(launch_gemm(ctx, sV, 0, 1, g, LPGP_K_GEMM));
+    for (int h = 0; h < halves; ++h) {
+      hipStream_t sV = h == 0 ? rd->stream : rd->stream2;
+      const int c0 = (h == 0) ? 0 : rd->mtl / 2, c1 = (two && h == 0) ? rd->mtl / 2 : rd->mtl;       // tile columns of this half
+      double* vh = rd->v + (int64_t)c0 * tb * rd->ldv;
+      const int mtl = c1 - c0;
+      double* Vq = vh + (int64_t)q0 * tb;
+      if (ctx->fused_solve) {
+        LPGP_TRY(launch_trsv_panel(ctx, sV, Vq, rd->ldv, mat->linv + (int64_t)q0 * tb * tb, a + (int64_t)q0 * tb * (ld + 1), ld, q1 - q0, mtl,
+                                   LPGP_K_PANEL));
+      } else {
+        for (int jt = q0; jt < q1; ++jt) {
+          double* Vj = vh + (int64_t)jt * tb;
+          LPGP_TRY(launch_trsv_tile(ctx, sV, Vj, rd->ldv, mat->linv + (int64_t)jt * tb * tb, a + (int64_t)jt * tb * (ld + 1), ld, mtl, LPGP_K_TRSM));
+          if (jt + 1 < q1)
+            LPGP_TRY(launch_gemm(ctx, sV, 0, 1,
+                                 mk(a + (int64_t)(jt + 1) * tb + (int64_t)jt * tb * ld, ld, Vj, rd->ldv, vh + (int64_t)(jt + 1) * tb, rd->ldv,
+                                    q1 - jt - 1, mtl, TILE, -1.0, 1.0, 0),
+                                 LPGP_K_GEMM));
+        }
+      }
+      if (q1 < lim) {
+        GemmArgs g = mk(a + (int64_t)q1 * tb + (int64_t)q0 * tb * ld, ld, Vq, rd->ldv, vh + (int64_t)q1 * tb, rd->ldv, lim - q1, mtl,
+                        (q1 - q0) * TILE, -1.0, 1.0, 0);
+        g.occ3 = ctx->ride_occ3;
+        LPGP_TRY(launch_gemm(ctx, sV, 0, 1, g, LPGP_K_GEMM));
+      }
+      if (outer_from >= 0 && outer_from < T) {
+        // the outer block [outer_q0, q1) is solved: everything from its margin on in ONE update with K = its height
+        GemmArgs g = mk(a + (int64_t)outer_from * tb + (int64_t)outer_q0 * tb * ld, ld, vh + (int64_t)outer_q0 * tb, rd->ldv,
+                        vh + (int64_t)outer_from * tb, rd->ldv, T - outer_from, mtl, (q1 - outer_q0) * TILE, -1.0, 1.0, 0);
+        g.occ3 = ctx->ride_occ3;
+        LPGP_TRY(launch_gemm(ctx, sV, 0, 1, g, LPGP_K_GEMM));
+      }
     }
   }
   return 0;
@@ -550,25 +620,48 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
 int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, double* v, int64_t ldv, int64_t m_pad) {
   Ride rd;
   rd.v = v; rd.ldv = ldv; rd.mtl = (int)(m_pad / TILE);
-  // the ride stream: a masked update stream that is idle during a factorisation of this size (HIP multiplexes a process's
-  // streams over four hardware queues: no new stream)
-  hipStream_t cand[3] = {ctx->s_outer, ctx->s_upd_all, ctx->s_upd_narrow};
-  rd.stream = (ctx->ride_stream >= 0 && ctx->ride_stream < 3 && cand[ctx->ride_stream]) ? cand[ctx->ride_stream] : ctx->s_main;
-  if (ctx->single_stream) rd.stream = ctx->s_main;
+  // the ride streams: update streams that are idle during a factorisation of this size (HIP multiplexes a process's
+  // streams over four hardware queues: no new stream).  ride_stream = first + 8 * second (second 7: none):
+  // 0 s_outer (masked like s_upd), 1 s_upd_all (unmasked), 2 s_upd_narrow, 3 the panel stream itself, 4 s_upd
+  hipStream_t cand[5] = {ctx->s_outer, ctx->s_upd_all, ctx->s_upd_narrow, ctx->s_main, ctx->s_upd};
+  const int i1 = ctx->ride_stream & 7, i2 = (ctx->ride_stream >> 3) & 7;
+  rd.stream = (i1 < 5 && cand[i1]) ? cand[i1] : ctx->s_main;
+  rd.stream2 = (i2 < 5 && cand[i2]) ? cand[i2] : nullptr;
+  if (ctx->single_stream) { rd.stream = ctx->s_main; rd.stream2 = nullptr; }
   rd.ev[0] = ctx->ev_ride[0]; rd.ev[1] = ctx->ev_ride[1];
+  // Policy by size (measured, MEASUREMENTS.md round 5): a factor of at most 12 tile rows is latency-bound whatever the schedule,
+  // and the fork / join of a second stream costs more than it hides (c1: 0.54 -> 0.64 ms): its steps go on the panel stream.
+  // Up to 192 tile rows the steps are held back until half of the rows are factored; beyond (the factorisation's own
+  // two-level regime) they are released at once (c5: 300.3 ms against 305.8 with the gate at 50 %, 308.4 for two pipelines).
+  if (T <= ctx->ride_same_stream_max_tiles) { rd.stream = ctx->s_main; rd.stream2 = nullptr; }
+  rd.gate_pct = ctx->ride_gate_pct >= 0 ? ctx->ride_gate_pct : (T <= 192 ? 50 : 100);
+  rd.open = rd.gate_pct >= 100 || rd.stream == ctx->s_main;
+  // two-level form: outer blocks of 2 048 rows from 64 tile rows on (c3 51.9 -> 51.4 ms, c5 301.8 -> 298.1; blocks of 4 096: c5 301.0)
+  rd.outer_t = (ctx->ride_outer_rows >= 8 * TILE && T >= ctx->ride_outer_min_tiles && T >= 2 * (ctx->ride_outer_rows / TILE)) ? (int)(ctx->ride_outer_rows / TILE) : 0;
   // everything enqueued on the panel stream so far (cross-covariance assembly, residual column) precedes the first step
-  if (rd.stream != ctx->s_main) {
-    LPGP_HIP(hipEventRecord(ctx->ev_ride[2], ctx->s_main));
-    LPGP_HIP(hipStreamWaitEvent(rd.stream, ctx->ev_ride[2], 0));
-  }
+  LPGP_HIP(hipEventRecord(ctx->ev_ride[2], ctx->s_main));
+  if (rd.stream != ctx->s_main) LPGP_HIP(hipStreamWaitEvent(rd.stream, ctx->ev_ride[2], 0));
+  if (rd.stream2 && rd.stream2 != ctx->s_main) LPGP_HIP(hipStreamWaitEvent(rd.stream2, ctx->ev_ride[2], 0));
   if (t_done >= T) {
     // nothing left to factor: the plain substitution
+    return trsm_lower_blocked(ctx, mat, T, v, ldv, m_pad);
+  }
+  if (T >= ctx->ride_max_tiles) {
+    // very large factors: the two pipelines back to back (no host synchronisation in between).  At c4 (520 tile rows, 129 tile
+    // columns of right-hand side) the factorisation's outer updates with K = 2 048 and the substitution's with K = 4 096 have
+    // the chip to themselves for seconds and the chain-bound parts are a per-cent effect; riding inside costs 1.8 % there
+    // (2 718 against 2 670 ms) where it gains 6 % at c3, 13 % at c2 and 3 % at c5.
+    LPGP_TRY(potrf_blocked_impl(ctx, mat, t_done, T, nullptr, nullptr));
     return trsm_lower_blocked(ctx, mat, T, v, ldv, m_pad);
   }
   LPGP_TRY(potrf_blocked_impl(ctx, mat, t_done, T, nullptr, &rd));
   if (rd.stream != ctx->s_main) {
     LPGP_HIP(hipEventRecord(ctx->ev_ride[2], rd.stream));
     LPGP_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ride[2], 0));
+  }
+  if (rd.stream2 && rd.stream2 != ctx->s_main && rd.stream2 != rd.stream) {
+    LPGP_HIP(hipEventRecord(ctx->ev_ride[3], rd.stream2));
+    LPGP_HIP(hipStreamWaitEvent(ctx->s_main, ctx->ev_ride[3], 0));
   }
   return 0;
 }

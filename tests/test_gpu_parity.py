@@ -329,8 +329,11 @@ def test_mean_without_weights_matches_weight_path(lp):
         assert u._representer_weights is None
         mean_z, var = u.predict(Xt)                    # residual path
         assert u._representer_weights is None          # ... really did not solve for the weights
+        assert u.predict(Xt, return_var=False) is not None and u._representer_weights is None      # (served from the posterior's last prediction)
+        u._pred_cache = None
         mean_w = u.predict(Xt, return_var=False)       # weights path
         assert u._representer_weights is not None
+        u._pred_cache = None
         mean_w2, var2 = u.predict(Xt)                  # weights now resident: K w, then the solve
         ref = post.mean(Xt)
         assert _rel(mean_z, ref) < 1e-8 and _rel(mean_w, ref) < 1e-8
