@@ -50,6 +50,7 @@ import numpy as np  # noqa: E402
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor datasheet)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 ROOFLINE_SLOT = "syrk_trailing"
+T_START = time.time()
 
 
 def _blas_info():
@@ -336,6 +337,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare with the CPU oracle at full size")
     args = ap.parse_args()
+    global T_START
+    T_START = time.time()
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -465,18 +468,35 @@ def main():
         return dt_, out_
 
     # ---- first contact with a real fabric: measure it, then let the measurement pick the variant ----
+    # Everything before the timed region -- link probe and trials -- shares ONE budget (LPGP_BENCH_BUDGET_S, default 300 s of wall
+    # time, agreed on by all ranks): a trial whose predecessor's cost says it would overrun is skipped, and the line says so.
+    # (The builder never had more than one GPU; over loopback sockets a trial takes 20-46 s, on xGMI it should take well under
+    # one: the budget is there for the fabric nobody has measured.)
     link_probe, trials, chosen = None, None, None
+    budget_s = float(os.environ.get("LPGP_BENCH_BUDGET_S", "300"))
+    t_cal0 = time.time()
+
+    def budget_left():
+        return comm.allreduce_max(-(budget_s - (time.time() - t_cal0))) * -1.0      # the MIN over ranks of what is left
+
     if distributed and transport != "host":
         try:
             link_probe = ctx.link_probe(32 << 20, 3)
         except Exception as exc:                # noqa: BLE001
             link_probe = {"error": f"{type(exc).__name__}: {exc}"}
     pinned = "LPGP_GRID" in os.environ or "LPGP_DIST_COLLECTIVE" in os.environ or bool(int(os.environ.get("LPGP_BENCH_NO_TRIALS", "0")))
+    skipped_trials = []
     if distributed and world >= 4 and world % 2 == 0 and not pinned:
         variants = [("Px1_p2p_split", (world, 1), 0), ("P/2x2_p2p", (world // 2, 2), 0), ("Px1_bcast", (world, 1), 1)]
         trials = {}
         lp.config.gram_capacity_hint = wl.n_total
+        last_cost = 0.0
         for name, grid, bc in variants:
+            left = budget_left()
+            if trials and left < 1.5 * last_cost:          # the first variant always runs (it is the default configuration's warm-up anyway)
+                skipped_trials.append({"variant": name, "reason": f"{left:.0f} s of the {budget_s:.0f}-s calibration budget left, the previous trial took {last_cost:.0f} s"})
+                continue
+            t_tr = time.time()
             ctx.dist_set_grid(*grid)
             ctx.set_option("dist_bcast", bc)
             dev_t = problems.upload(wl)
@@ -486,10 +506,12 @@ def main():
             trials[name] = {"grid": list(grid), "collective": "bcast" if bc else "p2p", "ms_per_step": dt_t / 2 * 1e3}
             del dev_t, prior_t, last_t          # every matrix of this grid must be gone before the next lpgp_dist_set_grid
             gc.collect()
+            last_cost = comm.allreduce_max(time.time() - t_tr)
         chosen = min(trials, key=lambda k_: trials[k_]["ms_per_step"])
         _, grid, bc = next(v for v in variants if v[0] == chosen)
         ctx.dist_set_grid(*grid)
         ctx.set_option("dist_bcast", bc)
+    calibration_s = time.time() - t_cal0
 
     lp.config.gram_capacity_hint = wl.n_total
     dev = problems.upload(wl)                # point sets resident in HBM before timing
@@ -616,38 +638,108 @@ def main():
     comm_rows = comm.gather([float(cs["bytes_sent"]) / prof_steps, float(cs["bytes_received"]) / prof_steps,
                              float(prof["comm"]["ms"]) / args.steps])
 
+    # ---- real parity at N > 1: the oracle of the timed workload on rank 0's host cores, started NOW on a thread
+    #      (LAPACK releases the GIL) so that it runs beside the extras below; joined before the line is printed ----
+    oracle_box = {}
+    oracle_thread = None
+    if distributed and rank == 0 and not os.environ.get("LPGP_BENCH_NO_ORACLE"):
+        def _oracle():
+            try:
+                import psutil
+                from oracle import workloads as owl
+                workers = max(1, min(16, (os.cpu_count() or 1) // 8))
+                need = owl.host_memory_needed(wl, 1024, workers)
+                if psutil.virtual_memory().available < 1.3 * need:
+                    oracle_box["skipped"] = f"the oracle at N_tot = {wl.n_total} needs {need / 1e9:.0f} GB of host memory"
+                    return
+                oracle_box["ref"] = owl.run_in_place(wl, chunk=1024, workers=workers)
+            except Exception as exc:            # noqa: BLE001 (reported in the line)
+                oracle_box["skipped"] = f"{type(exc).__name__}: {exc}"
+        oracle_thread = threading.Thread(target=_oracle, daemon=True)
+        oracle_thread.start()
+
     # ---- the BASELINE configuration named for this GPU count, on the same ranks (collective: every rank runs it) ----
     extra = os.environ.get("LPGP_BENCH_EXTRA")
     if extra is None:
         extra = {8: "c4", 4: "c5", 2: "c5"}.get(world, "none") if (distributed and weak) else "none"
-    configs = {}
+    extra_names = [e for e in extra.split(",") if e and e != "none"]
     del dev, prior
     gc.collect()
-    for name in [e for e in extra.split(",") if e and e != "none"]:
-        w2 = {"c4": lambda: problems.poisson_2d(n_side=256, m_side=128), "c5": problems.heat_1d,
-              "c3": problems.poisson_2d, "c2": problems.poisson_1d}[name]()
-        lp.config.gram_capacity_hint = w2.n_total
-        dev2, prior2 = problems.upload(w2), problems.build_prior(w2)
-        problems.condition_and_predict(w2, prior=prior2, device_arrays=dev2)             # untimed: allocation
-        ctx.dist_stats(reset=True)
-        k2 = 2 if name == "c4" else 3
-        dt2, (u2, mean2, var2) = timed_steps(w2, prior2, dev2, k2)
-        cs2 = ctx.dist_stats()
-        comm2 = comm.gather([float(cs2["bytes_sent"]) / k2, float(cs2["bytes_received"]) / k2])
-        props = parity_by_properties(problems, w2, u2, mean2, var2)
-        per_gpu = (world if replicas else 1)
-        configs[name] = {
-            "workload": w2.name, "n_total": int(w2.n_total), "m_predict": int(w2.Xtest.shape[0]), "steps": k2,
-            "ms_per_step": dt2 / k2 * 1e3, "value": per_gpu * w2.total_flops() / (dt2 / k2) / 1e9, "unit": "GFLOP/s",
-            "frac_of_fp64_mfma_peak_all_gpus": per_gpu * w2.total_flops() / (dt2 / k2) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
-            "algorithmic_flops_per_step": w2.total_flops(),
-            "parity_by_properties": props,
-            "comm_bytes_per_rank_per_step": None if comm2 is None or not distributed else [{"rank": r_, "sent": row[0], "received": row[1]} for r_, row in enumerate(comm2)],
-        }
-        del u2, dev2, prior2
-        gc.collect()
+
+    def run_extras():
+        configs_ = {}
+        for name in extra_names:
+            w2 = {"c4": lambda: problems.poisson_2d(n_side=256, m_side=128), "c5": problems.heat_1d,
+                  "c3": problems.poisson_2d, "c2": problems.poisson_1d}[name]()
+            lp.config.gram_capacity_hint = w2.n_total
+            dev2, prior2 = problems.upload(w2), problems.build_prior(w2)
+            problems.condition_and_predict(w2, prior=prior2, device_arrays=dev2)             # untimed: allocation
+            ctx.dist_stats(reset=True)
+            k2 = 2 if name == "c4" else 3
+            dt2, (u2, mean2, var2) = timed_steps(w2, prior2, dev2, k2)
+            cs2 = ctx.dist_stats()
+            # the configuration's own roofline kernel and communication time: one more step under HIP events (outside its timed steps)
+            ctx.profile_reset()
+            ctx.profile_enable([ROOFLINE_SLOT, "comm"])
+            problems.condition_and_predict(w2, prior=prior2, device_arrays=dev2)
+            ctx.sync()
+            pr2 = ctx.profile_get()
+            ctx.profile_enable(False)
+            comm2 = comm.gather([float(cs2["bytes_sent"]) / k2, float(cs2["bytes_received"]) / k2, float(pr2["comm"]["ms"]) * 1e-3])
+            props = parity_by_properties(problems, w2, u2, mean2, var2)
+            per_gpu = (world if replicas else 1)
+            sy2 = pr2[ROOFLINE_SLOT]
+            ach2 = sy2["flops"] / (sy2["ms"] * 1e-3) / 1e12 if sy2["ms"] > 0 else 0.0
+            entry = {
+                "workload": w2.name, "n_total": int(w2.n_total), "m_predict": int(w2.Xtest.shape[0]), "steps": k2, "n_gpus": world,
+                "ms_per_step": dt2 / k2 * 1e3, "value": per_gpu * w2.total_flops() / (dt2 / k2) / 1e9, "unit": "GFLOP/s",
+                "frac_of_fp64_mfma_peak_all_gpus": per_gpu * w2.total_flops() / (dt2 / k2) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+                "algorithmic_flops_per_step": w2.total_flops(),
+                "roofline": {"kernel": "rank-512 trailing update (this rank's share), HIP events over one extra step", "bound": "mfma",
+                             "achieved": ach2, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach2 / FP64_MFMA_PEAK_TFLOPS,
+                             "launches_per_step": sy2["launches"], "traffic": None},
+                "parity_by_properties": props,
+                "comm_per_rank_per_step": None if comm2 is None or not distributed else [
+                    {"rank": r_, "bytes_sent": row[0], "bytes_received": row[1], "seconds_in_comm": row[2]} for r_, row in enumerate(comm2)],
+            }
+            if rank == 0 and name == "c4":
+                # the committed full-size oracle posterior of c4 (tests/golden/c4_posterior.npz, tests/golden/make_c4_golden.py)
+                try:
+                    gold = np.load(os.path.join(ROOT, "tests", "golden", "c4_posterior.npz"))
+                    if int(gold["n_total"]) == w2.n_total and int(gold["m"]) == w2.Xtest.shape[0]:
+                        entry["parity"] = parity_report(mean2, var2, {"mean": gold["mean"], "var": gold["var"], "seconds": "committed fixture"}, w2)
+                        entry["parity"]["oracle"] = "tests/golden/c4_posterior.npz (" + str(gold["provenance"]) + ")"
+                except Exception as exc:        # noqa: BLE001
+                    entry["parity"] = {"skipped": f"{type(exc).__name__}: {exc}"}
+            elif rank == 0 and name == "c5" and not os.environ.get("LPGP_BENCH_NO_ORACLE"):
+                try:
+                    from oracle import workloads as owl
+                    if oracle_thread is not None:
+                        oracle_thread.join()                 # one LAPACK job at a time on the host
+                    ref2 = owl.run_in_place(w2, chunk=1024, workers=max(1, min(16, (os.cpu_count() or 1) // 8)))
+                    entry["parity"] = parity_report(mean2, var2, ref2, w2)
+                    entry["parity"]["oracle"] = "oracle.workloads.run_in_place on rank 0's host cores, in this run"
+                except Exception as exc:        # noqa: BLE001
+                    entry["parity"] = {"skipped": f"{type(exc).__name__}: {exc}"}
+            configs_[name] = entry
+            del u2, dev2, prior2
+            gc.collect()
+        return configs_
+
+    # Extras BEFORE the line only if the line can still be printed inside LPGP_BENCH_LINE_DEADLINE_S (default 600 s after the
+    # start of this process) by an estimate from the measured step; otherwise the line goes out first and the extras follow
+    # as a second JSON object on stderr -- the headline never waits for a configuration nobody has timed on real links.
+    deadline_s = float(os.environ.get("LPGP_BENCH_LINE_DEADLINE_S", "600"))
+    est_extras_s = 0.0
+    for name in extra_names:
+        f2 = {"c4": 1.73e14, "c5": 1.73e13, "c3": 2.78e12, "c2": 2.5e11}.get(name, 1e13)
+        est_extras_s += (f2 / max(wl.total_flops(), 1.0)) * (dt / args.steps) * 5.0 * 1.5 + 10.0 + (40.0 if name == "c5" else 0.0)
+    extras_first = comm.bcast((time.time() - T_START) + est_extras_s < deadline_s if rank == 0 else None) if extra_names else True
+    configs = run_extras() if (extra_names and extras_first) else {}
 
     if rank != 0:
+        if extra_names and not extras_first:
+            run_extras()
         comm.close()
         return
     ms_per_step = dt / args.steps * 1e3
@@ -700,8 +792,10 @@ def main():
             "transport": None if not distributed else transport,
             "process_grid": None if not distributed else list(ctx.grid),
             "link_probe": link_probe,
-            "trials": None if trials is None else {"variants": trials, "chosen": chosen,
-                                                   "note": "two timed steps of the bench workload per variant, during warm-up; the fastest runs the timed region"},
+            "trials": None if trials is None else {"variants": trials, "chosen": chosen, "skipped": skipped_trials,
+                                                   "calibration_seconds": calibration_s, "budget_seconds": budget_s,
+                                                   "note": "two timed steps of the bench workload per variant, during warm-up; the fastest runs the timed region; "
+                                                           "link probe and trials share LPGP_BENCH_BUDGET_S"},
             "comm_per_rank_per_step": None if not distributed else [
                 {"rank": r, "bytes_sent": row[0], "bytes_received": row[1], "seconds_in_comm": row[2] * 1e-3}
                 for r, row in enumerate(comm_rows)],
@@ -765,10 +859,24 @@ def main():
         out["cpu_baseline"] = cpu_json
     if ref is not None:
         out["parity"] = parity_report(mean, var, ref, wl)
+    if oracle_thread is not None:
+        # the timed workload of this multi-GPU run against the oracle (rank 0's host cores, beside the extras)
+        oracle_thread.join(max(30.0, deadline_s - (time.time() - T_START)) if (extra_names and not extras_first) else None)
+        if "ref" in oracle_box:
+            out["parity"] = parity_report(mean, var, oracle_box["ref"], wl)
+            out["parity"]["oracle"] = "oracle.workloads.run_in_place on rank 0's host cores, in this run"
+        else:
+            out["parity"] = {"skipped": oracle_box.get("skipped", "the oracle had not finished when the line was due")}
+    out["config"]["calibration_seconds"] = calibration_s
     assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
     _libc.fflush(None)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
+    if extra_names and not extras_first:
+        late = run_extras()
+        sys.stderr.write(json.dumps({"configs_after_the_line": late, "note": "the BASELINE configuration for this GPU count, run after the line "
+                                     "was printed (LPGP_BENCH_LINE_DEADLINE_S)"}) + "\n")
+        sys.stderr.flush()
     comm.close()
 
 

@@ -61,7 +61,18 @@ typedef struct {
   lpgp_term terms[LPGP_MAXT];
 } lpgp_kdesc;
 
-/* ---- context ------------------------------------------------------------------------ */
+/* ---- context ------------------------------------------------------------------------
+ * THE CONTRACT IS ONE PROCESS PER GPU.  SURVEY.md section 8(b) sketched `lpgp_init(int ndev, const int* dev_ids, int pr, int pc,
+ * lpgp_ctx**)` with "one process drives all 8 GPUs (single-process multi-device RCCL)".  This library deviates, deliberately:
+ * lpgp_init takes ONE device, a context owns one GPU's streams, pools and communicator rank, and a multi-GPU job is N
+ * processes that each call lpgp_init + lpgp_dist_init (rank, world, the RCCL unique id).  Why: (i) the task's launch contract is
+ * one rank per GPU under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE), and the driver's scaling bench starts the
+ * ranks that way; (ii) a single host thread driving eight devices serialises eight panel chains of ~10 us launches through
+ * one Python interpreter -- the chain is latency-bound, eight interpreters keep eight chains fed;
+ * (iii) RCCL's group semantics and HIP's per-thread current device make single-process multi-device code a second code
+ * path to test, for no data-path difference (the same xGMI copies).  The reference's calling convention -- ONE Python
+ * process calling `condition_on_observations` (_conditional.py:253-294) -- is kept above the C ABI: `lp.spawn(n)`
+ * (linpde_gp_amd/_spawn.py) starts one worker process per GPU and replays the caller's calls SPMD.    */
 int  lpgp_init(int device, lpgp_ctx** ctx);
 int  lpgp_finalize(lpgp_ctx* ctx);
 const char* lpgp_last_error(void);

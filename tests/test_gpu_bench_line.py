@@ -39,6 +39,14 @@ def test_bench_prints_one_contract_line():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert line["parity"]["pass"] is True
     assert len(line["config"]["csrc_sha16"]) == 16
+    # round 5: the mode of the timed region is stated, the default mode and the reference's own call sequence are timed beside it
+    assert line["config"]["lazy_factorization"] is True and line["config"]["fused_factor_and_predict"] is True
+    assert line["modes"]["eager_default"]["ms_per_step"] > 0 and line["modes"]["timed_region"]["lazy_factorization"] is True
+    seq = line["reference_sequence"]
+    assert "u.mean(x)" in seq["calls"] and "u.std(x)" in seq["calls"]
+    assert seq["default_mode_ms"] > 0 and seq["lazy_mode_ms"] > 0
+    assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["std_vs_predict_rel"] <= 1e-12
+    assert line["e2e_with_h2d_ms"] > 0 and line["e2e"]["mean_vs_resident_rel"] <= 1e-12 and line["e2e"]["var_vs_resident_rel"] <= 1e-11
 
 
 def test_plain_call_with_gpus_2_starts_its_own_ranks():
@@ -61,3 +69,6 @@ def test_plain_call_with_gpus_2_starts_its_own_ranks():
     assert line["config"]["process_grid"] == [2, 1]
     assert len(line["config"]["comm_per_rank_per_step"]) == 2
     assert all(r["bytes_received"] > 0 for r in line["config"]["comm_per_rank_per_step"])
+    # round 5: real parity at N > 1 -- the timed workload against the oracle on rank 0's host cores, in the same run
+    assert line["parity"]["pass"] is True and "oracle" in line["parity"], line["parity"]
+    assert line["config"]["calibration_seconds"] >= 0
