@@ -592,6 +592,10 @@ def main():
             "overhead_vs_predict_lazy_mode": seq_lazy_ms / (dt / args.steps * 1e3) - 1.0,
             "steps": k_m,
             "mean_vs_predict_rel": float(max(np.max(np.abs(m_e - mean)), np.max(np.abs(m_l - mean))) / scale_m),
+            # (compared on the VARIANCE scale: where the posterior variance is ~0 -- c2: 1e-7 of the prior's -- a rounding error of
+            #  the variance is amplified by 1 / (2 std) in the standard deviation, for `predict` and the sequence alike)
+            "var_from_std_vs_predict_rel": float(max(np.max(np.abs(s_e**2 - np.maximum(var, 0.0))), np.max(np.abs(s_l**2 - np.maximum(var, 0.0))))
+                                                 / max(float(np.max(np.abs(var))), 1e-300)),
             "std_vs_predict_rel": float(max(np.max(np.abs(s_e - sd)), np.max(np.abs(s_l - sd))) / scale_s),
             "note": "default mode: mean(x) solves for the representer weights (two triangular solves with one right-hand side), std(x) "
                     "assembles the cross-covariance again and runs the blocked forward substitution; lazy mode with "

@@ -33,3 +33,14 @@ lazy_factorization: bool = False
 # default: a caller who never asks for the variance would pay the forward substitution of the cross-covariance for nothing.
 # (Independently of this flag every posterior keeps its LAST prediction, so `mean(x)` after `predict(x)` is free.)
 variance_with_mean: bool = False
+
+# Matrix-free posteriors (`randprocs/_matrix_free.py`): the Gram matrix is never formed, every product re-evaluates its entries
+# on the GPU (`lpgp_kernel_matvec`, the reference's KeOps slot, `diffops/_matern.py:112-135`) and solves are preconditioned
+# conjugate gradients.  `matrix_free = True`: every first conditioning builds one; `matrix_free_above = N`: first conditionings
+# on more than N observations do (190 000 points are a 289-GB dense Gram matrix: beyond one device).  0 / False: never.
+matrix_free: bool = False
+matrix_free_above: int = 0
+matrix_free_preconditioner_rank: int = 200      # pivoted-Cholesky rank (0: plain CG)
+matrix_free_rtol: float = 1e-10                  # relative residual of every CG solve
+matrix_free_maxiter: int = 5000
+matrix_free_rhs_chunk: int = 64                  # prediction points per block of variance solves

@@ -168,6 +168,90 @@ class Monomial(Polynomial):
         super().__init__([0.0] * int(degree) + [1.0])
 
 
+class Piecewise(Function):
+    """Scalar function of the real line given piece by piece on the intervals between the break points `xs`
+    (`functions/_piecewise.py:16-86`: same constructor, `xs`, `pieces`, `num_pieces`, scalar `*`): piece i on
+    (xs[i], xs[i + 1]], the first one closed on the left as well; zero outside [xs[0], xs[-1]], as `np.piecewise` leaves it."""
+
+    def __init__(self, xs, fns):
+        xs = np.atleast_1d(np.asarray(xs, dtype=np.double))
+        if xs.ndim != 1:
+            raise ValueError("the break points must form a vector")
+        fns = tuple(fns)
+        if len(fns) != xs.size - 1:
+            raise ValueError("one piece per interval between consecutive break points is required")
+        if not all(f.input_shape == () and f.output_shape == () for f in fns):
+            raise ValueError("the pieces must be scalar functions of the real line")
+        self._xs, self._fns = xs, fns
+        super().__init__(input_shape=(), output_shape=())
+
+    @property
+    def xs(self):
+        return self._xs
+
+    @property
+    def pieces(self):
+        return self._fns
+
+    @property
+    def num_pieces(self) -> int:
+        return len(self._fns)
+
+    def _evaluate(self, x):
+        out = np.zeros_like(x)
+        # interval index of every point: i with xs[i] < x <= xs[i + 1] (x == xs[0] belongs to the first piece)
+        idx = np.searchsorted(self._xs, x, side="left") - 1
+        idx = np.where(x == self._xs[0], 0, idx)
+        inside = (x >= self._xs[0]) & (x <= self._xs[-1])
+        for i, f in enumerate(self._fns):
+            sel = inside & (idx == i)
+            if np.any(sel):
+                out[sel] = f(x[sel])
+        return out
+
+    def _like(self, fns):
+        return Piecewise(self._xs, fns)
+
+    def __rmul__(self, other):
+        if np.ndim(other) == 0:
+            return self._like([float(other) * f for f in self._fns])
+        return NotImplemented
+
+    def __neg__(self):
+        return -1.0 * self
+
+    def partial_derivative(self, multi_index):
+        return Piecewise(self._xs, [differentiate(f, multi_index) for f in self._fns])
+
+
+class PiecewiseLinear(Piecewise):
+    """Continuous piecewise-linear interpolant (`functions/_piecewise.py:89-142`: `from_points`, `+` with a `Constant` or a
+    `Polynomial` -- of degree <= 1: stays `PiecewiseLinear` --, scalar `*`): the heat-source profiles of the CPU-die
+    experiment (`experiments/cpu.py:83-137`)."""
+
+    @staticmethod
+    def from_points(xs, ys) -> "PiecewiseLinear":
+        xs, ys = np.asarray(xs, dtype=np.double), np.asarray(ys, dtype=np.double)
+        pieces = []
+        for lo, hi, y_lo, y_hi in zip(xs[:-1], xs[1:], ys[:-1], ys[1:]):
+            slope = (y_hi - y_lo) / (hi - lo)
+            pieces.append(Polynomial((y_lo - slope * lo, slope)))
+        return PiecewiseLinear(xs, pieces)
+
+    def _like(self, fns):
+        return PiecewiseLinear(self._xs, fns)
+
+    def __add__(self, other):
+        if isinstance(other, Constant) and other.input_shape == () and other.output_shape == ():
+            other = Polynomial([float(other.value)])
+        if not isinstance(other, Polynomial):
+            return NotImplemented
+        fns = [f + other for f in self._fns]
+        return PiecewiseLinear(self._xs, fns) if other.degree <= 1 else Piecewise(self._xs, fns)
+
+    __radd__ = __add__
+
+
 class Affine(Function):
     """`A x + b` with the shape rules of `functions/_affine.py:9-51` (0-d `A`: scalar map of the real line; 1-d `A`: real line
     -> R^m; 2-d `A`: R^d -> R^m).  Only the scalar form can be a prior mean here (single-output GPs)."""

@@ -85,6 +85,10 @@ class GaussianProcess:
         if _spawn.active() is not None:
             # single-process front of the multi-GPU path: the posterior is built, sharded, by the worker processes
             return _spawn.condition(self, Y, X, L=L, b=b)
+        from .. import config
+        if config.matrix_free or (config.matrix_free_above and np.size(Y) > int(config.matrix_free_above)):
+            from ._matrix_free import MatrixFreeConditionalGaussianProcess
+            return MatrixFreeConditionalGaussianProcess.from_observations(self, Y, X, L=L, b=b)
         return ConditionalGaussianProcess.from_observations(self, Y, X, L=L, b=b)
 
 

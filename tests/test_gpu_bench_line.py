@@ -45,7 +45,7 @@ def test_bench_prints_one_contract_line():
     seq = line["reference_sequence"]
     assert "u.mean(x)" in seq["calls"] and "u.std(x)" in seq["calls"]
     assert seq["default_mode_ms"] > 0 and seq["lazy_mode_ms"] > 0
-    assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["std_vs_predict_rel"] <= 1e-12
+    assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["var_from_std_vs_predict_rel"] <= 1e-10
     assert line["e2e_with_h2d_ms"] > 0 and line["e2e"]["mean_vs_resident_rel"] <= 1e-12 and line["e2e"]["var_vs_resident_rel"] <= 1e-11
 
 

@@ -405,3 +405,26 @@ def test_bench_gpus_n_without_launcher_fails_once_on_a_box_without_gpus():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "{" not in res.stdout
+
+
+def test_pcg_and_preconditioner_on_a_plain_matrix():
+    """The iteration itself (host side), on a dense SPD matrix with a low-rank + noise structure."""
+    from linpde_gp_amd.randprocs import _matrix_free as mf
+    rng = np.random.default_rng(0)
+    x = np.sort(rng.uniform(-1, 1, 300))
+    A = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 0.2**2) + 1e-4 * np.eye(300)        # kernel matrix + noise: cond ~ 1e6
+    B = rng.standard_normal((300, 5))
+
+    class Dense:
+        n = 300
+        def diag(self): return np.diag(A).copy()
+        def row(self, p): return A[p].copy()
+    X0, i0 = mf.pcg(lambda V: A @ V, B, None, rtol=1e-11, maxiter=3000)
+    P = mf.PivotedCholeskyPreconditioner(Dense(), rank=40)
+    X1, i1 = mf.pcg(lambda V: A @ V, B, P, rtol=1e-11, maxiter=3000)
+    ref = np.linalg.solve(A, B)
+    assert i0["converged"] and i1["converged"] and 3 * i1["iterations"] < i0["iterations"], (i0["iterations"], i1["iterations"])
+    np.testing.assert_allclose(X0, ref, rtol=0, atol=1e-7 * np.abs(ref).max())
+    np.testing.assert_allclose(X1, ref, rtol=0, atol=1e-7 * np.abs(ref).max())
+    x, info = mf.pcg(lambda V: A @ V, B[:, 0], P, rtol=1e-11)
+    assert x.shape == (300,) and info["converged"]
