@@ -347,6 +347,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   }
   for (int i = 0; i < 4; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_ROWS")) ctx->ride_outer_rows = std::atol(e);
@@ -434,6 +435,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
     (void)hipEventDestroy(sl.done);
   }
   (void)hipFree(ctx->d_info);
+  if (ctx->d_chain_flags) (void)hipFree(ctx->d_chain_flags);
   (void)hipHostFree(ctx->h_info_pinned);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   for (size_t r = 0; r < ctx->ipc_peer.size(); ++r)
@@ -505,6 +507,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "solve_chain_us_tile") == 0) *value = (int64_t)ctx->solve_chain_us_tile;
   else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
   else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
+  else if (std::strcmp(key, "chain_resident_max_rows") == 0) *value = ctx->chain_resident_max_rows;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
   else if (std::strcmp(key, "ride_outer_rows") == 0) *value = ctx->ride_outer_rows;
@@ -580,6 +583,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->lookahead = value != 0;
   } else if (std::strcmp(key, "ride_stream") == 0) {
     ctx->ride_stream = (int)value;
+  } else if (std::strcmp(key, "chain_resident_max_rows") == 0) {
+    ctx->chain_resident_max_rows = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {
     ctx->ride_occ3 = value != 0;
   } else if (std::strcmp(key, "ride_gate_pct") == 0) {
@@ -1187,6 +1192,7 @@ int lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block) 
   LPGP_HIP(hipMemcpyAsync(&h, mat->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
   LPGP_HIP(hipStreamSynchronize(ctx->s_main));
   mat->unchecked = 0;
+  LPGP_CHECK(h >= 0, "resident panel chain: a hand-over between workgroups timed out (device status %d); set LPGP_CHAIN_RESIDENT=-1", h);
   *info = h;
   if (h > 0 && block) {
     std::vector<lpgp_block> all = mat->blocks;

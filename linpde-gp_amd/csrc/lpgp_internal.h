@@ -95,7 +95,12 @@ struct lpgp_ctx {
   hipEvent_t ev_ride[4] = {nullptr, nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2, 3]
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
   int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
-  int ride_same_stream_max_tiles = 12; // ... on the panel stream itself for factors of at most this many tile rows
+  // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
+  // ONE launch whose workgroups hand over through device flags (-1: never)
+  int chain_resident_max_rows = 32;
+  int* d_chain_flags = nullptr;        // ring of flag slots (zeroed; a launch zeroes the slot half a ring ahead)
+  int64_t chain_launches = 0;
+  int ride_same_stream_max_tiles = 0;  // ... on the panel stream itself for factors of at most this many tile rows
   int64_t ride_outer_rows = 2048;      // ... two-level form: rows below an outer block of this many rows are updated once per block (0: every panel updates all rows below) ...
   int ride_outer_min_tiles = 64;       // ... from this many tile rows on
   int ride_max_tiles = 384;            // factors of at least this many tile rows: factorisation and substitution back to back instead (potrf.hip)
@@ -344,6 +349,8 @@ int launch_trsv_panel_ahead(lpgp_ctx* ctx, hipStream_t stream, double* V, int64_
 int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx, const double* linv, const double* L, int64_t ldl,
                       int nt_cols, int mt, int prof_kernel);
 
+// chain.hip: the whole chain of panel [p0, p0 + 4) (rows down to tile T) in one launch
+int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info);
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,

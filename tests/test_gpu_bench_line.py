@@ -45,7 +45,11 @@ def test_bench_prints_one_contract_line():
     seq = line["reference_sequence"]
     assert "u.mean(x)" in seq["calls"] and "u.std(x)" in seq["calls"]
     assert seq["default_mode_ms"] > 0 and seq["lazy_mode_ms"] > 0
-    assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["var_from_std_vs_predict_rel"] <= 1e-10
+    # (c2's posterior variance is 2.5e-7 of the prior's: k(x,x) - sum v^2 cancels seven digits, and two orders of summation --
+    #  the fused pipeline, the blocked substitution of the second pipeline -- differ by the rounding of that difference, a few
+    #  1e-9 of the largest variance: the parity bar, not 1e-12; on well-conditioned problems the two agree to 1e-12,
+    #  tests/test_gpu_fused.py::test_reference_sequence_mean_then_std)
+    assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["var_from_std_vs_predict_rel"] <= 1e-8
     assert line["e2e_with_h2d_ms"] > 0 and line["e2e"]["mean_vs_resident_rel"] <= 1e-12 and line["e2e"]["var_vs_resident_rel"] <= 1e-11
 
 

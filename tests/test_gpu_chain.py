@@ -1,0 +1,82 @@
+"""The resident panel chain (csrc/chain.hip, round 5): the whole chain of a four-tile panel in ONE launch whose workgroups hand
+over through device flags -- against the tile-by-tile launches it replaces (same arithmetic: the factors agree to rounding),
+against the oracle, and in its failure path (a pivot that is not positive inside a resident panel)."""
+import numpy as np
+import pytest
+
+from oracle import covfuncs as ocf
+from oracle import gp as ogp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def ctx():
+    from linpde_gp_amd import _engine
+    c = _engine.default_context()
+    saved = c.get_option("chain_resident_max_rows")
+    yield c
+    c.set_option("chain_resident_max_rows", saved)
+
+
+def _posterior(lp, n, seed, noise=1e-3, ls=0.35):
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, 2))
+    Y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + 0.01 * rng.standard_normal(n)
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), 1.3**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=ls), cf.Matern((), nu=1.5, lengthscales=ls)))
+    okern = [(1.69, [("matern", 2.5, ls), ("matern", 1.5, ls)])]
+    return prior, okern, X, Y, lp.randvars.Normal(np.zeros(n), noise * np.eye(n))
+
+
+@pytest.mark.parametrize("n", [512, 520, 1024, 1500, 2048 + 77, 4608])     # 4 tiles exactly (no rows below) ... 36 tiles: nine panels
+def test_resident_chain_equals_the_tile_by_tile_chain(ctx, n):
+    import linpde_gp_amd as lp
+    prior, okern, X, Y, b = _posterior(lp, n, seed=n)
+    Xt = np.random.default_rng(1).uniform(-1, 1, (33, 2))
+    out = {}
+    for mode, rows in (("resident", 64), ("tiles", -1)):
+        ctx.set_option("chain_resident_max_rows", rows)
+        u = prior.condition_on_observations(Y, X, b=b)
+        out[mode] = (u.gram.cholesky(), u.predict(Xt), u.representer_weights)
+        del u
+    Lr, Lt = out["resident"][0], out["tiles"][0]
+    assert np.max(np.abs(Lr - Lt)) <= 1e-12 * np.max(np.abs(Lt))
+    post = ogp.condition(okern, [ogp.ObsBlock(X, ocf.identity(2), Y, 0.0, 1e-3)])
+    m, v = out["resident"][1]
+    assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
+    assert np.max(np.abs(v - post.var(Xt))) <= 1e-8 * np.max(np.abs(post.var(Xt)))
+    np.testing.assert_allclose(Lr @ Lr.T, post.G, rtol=0, atol=1e-12 * np.max(np.abs(post.G)) * 4)
+
+
+def test_resident_chain_reports_the_first_bad_pivot(ctx):
+    """A Gram matrix that is not positive definite INSIDE a resident panel: the status names the leading minor (here in the third
+    tile of the second panel), the conditioning raises, the parent stays usable."""
+    import linpde_gp_amd as lp
+    ctx.set_option("chain_resident_max_rows", 64)
+    prior, okern, X, Y, _ = _posterior(lp, 1100, seed=5)
+    noise = np.full(1100, 1e-3)
+    noise[830] = -5.0                                  # row 830: tile 6 = panel 1, third tile
+    with pytest.raises(np.linalg.LinAlgError) as e:
+        prior.condition_on_observations(Y, X, b=lp.randvars.Normal(np.zeros(1100), noise))
+    assert "831-th" in str(e.value) or "83" in str(e.value), str(e.value)
+    u = prior.condition_on_observations(Y, X, b=lp.randvars.Normal(np.zeros(1100), np.full(1100, 1e-3)))
+    assert np.all(np.isfinite(u.predict(X[:5])[0]))
+
+
+def test_resident_chain_in_an_appended_block(ctx):
+    """Block append: old panels first (phase A), then resident panels whose first tile column is not a multiple of four."""
+    import linpde_gp_amd as lp
+    ctx.set_option("chain_resident_max_rows", 64)
+    prior, okern, X, Y, _ = _posterior(lp, 1300, seed=9)
+    cuts = [0, 130, 390, 1300]                         # blocks of 2, 3 and 8 tiles (130 -> 256, 260 -> 384, 910 -> 1024 padded rows)
+    u = prior
+    blocks = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        u = u.condition_on_observations(Y[lo:hi], X[lo:hi], b=lp.randvars.Normal(np.zeros(hi - lo), 1e-3 * np.eye(hi - lo)))
+        blocks.append(ogp.ObsBlock(X[lo:hi], ocf.identity(2), Y[lo:hi], 0.0, 1e-3))
+    post = ogp.condition(okern, blocks)
+    Xt = np.random.default_rng(2).uniform(-1, 1, (40, 2))
+    m, v = u.predict(Xt)
+    assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
+    assert np.max(np.abs(v - post.var(Xt))) <= 1e-8 * np.max(np.abs(post.var(Xt)))
