@@ -816,6 +816,11 @@ def main():
             **pmc_traffic(sha, roof_symbol, tag=profile_tag(args.workload, args.n_side, args.m_side) if not distributed else None),
             "launches_per_step": syrk["launches"] / max(args.steps, 1),
             "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
+            "note": ("in the fused factor-and-predict pipeline this kernel shares the chip with the riding substitution's updates "
+                     "(gemm3_f64_kernel<true, 0>) for most of its launches: its own in-situ rate is what `achieved` reports; the "
+                     "rate of the whole step -- every algorithmic flop over the step time -- is `step_frac_of_peak`, and "
+                     "`modes.eager_default` is the two-pipeline schedule in which it runs beside the panel chain only"),
+            "step_frac_of_peak": (flops / (dt / args.steps) / 1e12) / (FP64_MFMA_PEAK_TFLOPS * (1 if not replicas else 1)) / (world if distributed else 1),
         },
         "kernels": {
             name: {

@@ -349,6 +349,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_ROWS")) ctx->ride_outer_rows = std::atol(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_MIN_TILES")) ctx->ride_outer_min_tiles = std::atoi(e);

@@ -94,6 +94,7 @@ struct lpgp_ctx {
   int reserve_narrow = 64;
   hipEvent_t ev_ride[4] = {nullptr, nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2, 3]
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
+  int ride_old_ungated = 1;            // ... the steps of old panels (block append) are not held back by the gate
   int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
   // ONE launch whose workgroups hand over through device flags (-1: never)

@@ -113,7 +113,10 @@ struct Ride {
 static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first);
 
 // panel [p0, p1) of the factor is final on the panel stream from here on: enqueue its substitution step(s)
-static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd) {
+static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool old_panel = false) {
+  // (steps of OLD panels -- a block append pushes its rows through them before it factors anything -- may pass the gate: they fill
+  //  the start-up of the append, the first panel chain on an otherwise idle chip; ride_old_ungated)
+  if (!rd->open && old_panel && ctx->ride_old_ungated && rd->held.empty()) return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
   if (!rd->open) {
     if ((int64_t)(T - p1) * 100 > (int64_t)rd->gate_pct * T && p1 < T) {
       rd->held.emplace_back(p0, p1);
@@ -402,7 +405,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
                                   rows + (int64_t)(jt + 1) * tb * ld, ld, mnew, p1 - jt - 1, TILE, -1.0, 1.0, 0),
                                LPGP_K_GEMM));
       }
-      if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride));        // the old panel's columns, new rows included, are final
+      if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride, true));  // the old panel's columns, new rows included, are final
       const int K = (p1 - p0) * TILE;
       double* Xp = rows + (int64_t)p0 * tb * ld;
       if (p1 < t_done)

@@ -5,12 +5,11 @@ rows = []
 for ln in gzip.open(sys.argv[1], 'rt'):
     p = ln.split(None, 4)
     rows.append(dict(s=int(p[0]) / 10.0, d=int(p[1]) / 10.0, q=p[2], b=int(p[3]), n=p[4].strip()))
-NP = 132
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 W = float(sys.argv[3]) if len(sys.argv) > 3 else 4000.0
-pt = [i for i, r in enumerate(rows) if 'potrf_tile' in r['n']]
-t0 = rows[pt[NP * k]]['s'] - 300.0
-t1 = rows[pt[NP * (k + 1)]]['s'] - 300.0 if NP * (k + 1) < len(pt) else rows[-1]['s'] + rows[-1]['d']
+ends = [i for i, r in enumerate(rows) if r['n'].startswith('col_reduce')]
+t0 = rows[ends[k - 1] + 1]['s'] if k > 0 else rows[0]['s']
+t1 = rows[ends[k]]['s'] + rows[ends[k]]['d'] + 0.05
 def flops(r):
     n, b = r['n'], r['b']
     if n.startswith('gemm_f64_kernel') or n.startswith('gemm3_f64_kernel'):

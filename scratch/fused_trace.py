@@ -6,22 +6,14 @@ for ln in gzip.open(sys.argv[1], 'rt'):
     p = ln.split(None, 4)
     rows.append(dict(s=int(p[0]) / 10.0, d=int(p[1]) / 10.0, q=p[2], b=int(p[3]), n=p[4].strip()))
 for r in rows: r['e'] = r['s'] + r['d']
-NP = 132
-pt = [i for i, r in enumerate(rows) if 'potrf_tile' in r['n']]
-nstep = len(pt) // NP
+# steps end with the column reduction of the prediction (col_reduce2_kernel / col_reduce_kernel): step k = the launches after
+# the end of step k - 1 up to and including that kernel
+ends = [i for i, r in enumerate(rows) if r['n'].startswith('col_reduce')]
+nstep = len(ends)
 k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].lstrip('-').isdigit() else 2
-# step boundaries: widest gap before the first potrf of step k / k+1
-def boundary(i_first):
-    lo = rows[pt[i_first - 1]]['e'] if i_first > 0 else rows[0]['s']
-    hi = rows[pt[i_first]]['s']
-    ks = [r for r in rows if lo <= r['s'] <= hi]
-    best, cut, end = -1, None, lo
-    for r in ks:
-        if r['s'] - end > best: best, cut = r['s'] - end, r['s']
-        end = max(end, r['e'])
-    return cut
-t0 = boundary(NP * k)
-t1 = boundary(NP * (k + 1)) if NP * (k + 1) < len(pt) else rows[-1]['e']
+i_lo = ends[k - 1] + 1 if k > 0 else 0
+t0 = rows[i_lo]['s']
+t1 = rows[ends[k]]['s'] + rows[ends[k]]['d'] + 0.05
 sel = [r for r in rows if t0 <= r['s'] < t1]
 tend = max(r['e'] for r in sel)
 print(f"steps in trace {nstep}; step {k}: {len(sel)} launches, {(tend - t0) / 1e3:.3f} ms")

@@ -1,0 +1,21 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"
+D=gpurun_out/r5_15; rm -rf $D; mkdir -p $D
+b() { local name=$1; shift
+  env "$@" LPGP_BENCH_NO_MODES=1 timeout 600 python bench.py --steps $STEPS --warmup 3 --no-cpu $WL > $D/$name.json 2> $D/$name.err
+  python -c "
+import json
+try:
+    d=json.loads(open('$D/$name.json').read().strip().splitlines()[-1]); print('$name', round(d['ms_per_step'],3), 'roof', round(d['roofline']['frac'],3), 'step', round(d['roofline']['step_frac_of_peak'],3))
+except Exception as e: print('$name FAILED', e)"
+}
+STEPS=30; WL=""
+b c3_a LPGP_X=1
+b c3_old1 LPGP_RIDE_OLD_UNGATED=1
+b c3_b LPGP_X=1
+b c3_old1b LPGP_RIDE_OLD_UNGATED=1
+b c3_eager LPGP_BENCH_EAGER=1
+WL="--workload heat1d"; STEPS=10
+b c5_a LPGP_X=1
+b c5_old1 LPGP_RIDE_OLD_UNGATED=1
