@@ -571,6 +571,8 @@ def main():
             lp.config.lazy_factorization, lp.config.variance_with_mean = False, False
             eager_ms, _ = timed(step)
             seq_eager_ms, (m_e, s_e) = timed(sequence)
+            lp.config.variance_with_mean = True
+            seq_eager_vwm_ms, (m_v, s_v) = timed(sequence)
             lp.config.lazy_factorization, lp.config.variance_with_mean = True, True
             seq_lazy_ms, (m_l, s_l) = timed(sequence)
             lp.config.lazy_factorization, lp.config.variance_with_mean = saved
@@ -587,20 +589,21 @@ def main():
                                            "LinAlgError itself, as the reference does (_conditional.py:44,83,280-282); predict is a second pipeline"}}
         ref_seq = {
             "calls": "u = prior.condition_on_observations(...) x blocks; u.mean(x); u.std(x)   (experiments/0001_poisson_dirichlet_2d.ipynb cell 22)",
-            "default_mode_ms": seq_eager_ms, "lazy_mode_ms": seq_lazy_ms, "predict_ms": dt / args.steps * 1e3,
+            "default_mode_ms": seq_eager_ms, "default_mode_variance_with_mean_ms": seq_eager_vwm_ms, "lazy_mode_ms": seq_lazy_ms,
+            "predict_ms": dt / args.steps * 1e3,
             "overhead_vs_predict_default_mode": seq_eager_ms / eager_ms - 1.0,
             "overhead_vs_predict_lazy_mode": seq_lazy_ms / (dt / args.steps * 1e3) - 1.0,
             "steps": k_m,
-            "mean_vs_predict_rel": float(max(np.max(np.abs(m_e - mean)), np.max(np.abs(m_l - mean))) / scale_m),
+            "mean_vs_predict_rel": float(max(np.max(np.abs(m_e - mean)), np.max(np.abs(m_l - mean)), np.max(np.abs(m_v - mean))) / scale_m),
             # (compared on the VARIANCE scale: where the posterior variance is ~0 -- c2: 1e-7 of the prior's -- a rounding error of
             #  the variance is amplified by 1 / (2 std) in the standard deviation, for `predict` and the sequence alike)
             "var_from_std_vs_predict_rel": float(max(np.max(np.abs(s_e**2 - np.maximum(var, 0.0))), np.max(np.abs(s_l**2 - np.maximum(var, 0.0))))
                                                  / max(float(np.max(np.abs(var))), 1e-300)),
             "std_vs_predict_rel": float(max(np.max(np.abs(s_e - sd)), np.max(np.abs(s_l - sd))) / scale_s),
             "note": "default mode: mean(x) solves for the representer weights (two triangular solves with one right-hand side), std(x) "
-                    "assembles the cross-covariance again and runs the blocked forward substitution; lazy mode with "
-                    "lp.config.variance_with_mean: mean(x) takes the fused factor-and-predict pipeline and keeps the variance, "
-                    "std(x) is served from it",
+                    "assembles the cross-covariance again and runs the blocked forward substitution; with lp.config.variance_with_mean "
+                    "mean(x) computes the variance in the same pass -- in lazy mode the fused factor-and-predict pipeline -- and std(x) "
+                    "is served from it",
         }
         e2e = {"e2e_with_h2d_ms": e2e_ms,
                "h2d_bytes_per_step": int(sum(o_.X.nbytes + o_.Y.nbytes for o_ in wl.observations) + wl.Xtest.nbytes),

@@ -27,10 +27,11 @@ use_grid_assembly: bool = True
 # Multi-GPU jobs always check inside `condition_on_observations` (the ranks agree on the status collectively).
 lazy_factorization: bool = False
 
-# Lazy mode only: a MEAN-only request (`u.mean(x)`) on a posterior whose factorisation is still deferred takes the fused
-# factor-and-predict pipeline and keeps the variance for the `u.std(x)` / `u.var(x)` on the same points that usually
-# follows (notebook 0001 cell 22 calls `u.mean(grid)`, then `u.std(grid)`): the pair then costs one `predict`.  Off by
-# default: a caller who never asks for the variance would pay the forward substitution of the cross-covariance for nothing.
+# A MEAN-only request (`u.mean(x)`) computes the marginal variance in the same pass and keeps it for the `u.std(x)` /
+# `u.var(x)` on the same points that usually follows (notebook 0001 cell 22 calls `u.mean(grid)`, then `u.std(grid)`): the pair
+# then costs one `predict` -- in lazy mode the fused factor-and-predict pipeline -- instead of a solve for the representer
+# weights plus a second cross-covariance assembly and the forward substitution.  Off by default: a caller who never asks for
+# the variance would pay the forward substitution of the cross-covariance for nothing.
 # (Independently of this flag every posterior keeps its LAST prediction, so `mean(x)` after `predict(x)` is free.)
 variance_with_mean: bool = False
 

@@ -560,7 +560,10 @@ class ConditionalGaussianProcess(GaussianProcess):
             if not return_var:
                 return mean
             return mean, np.concatenate([p[1] for p in parts]).reshape(batch)
-        mean, var = self._predict_local(x, X, return_var, speculative)
+        from .. import config
+        # `config.variance_with_mean`: a mean-only request computes the variance in the same pass and keeps it for the `std(x)`
+        # that usually follows (either mode; in lazy mode that pass is the fused factor-and-predict pipeline)
+        mean, var = self._predict_local(x, X, return_var or bool(config.variance_with_mean), speculative)
         if speculative:
             self._verify_after()
         self._pred_cache = (_engine.option_epoch(), X.copy(), mean.copy(), None if var is None else var.copy())
@@ -588,10 +591,9 @@ class ConditionalGaussianProcess(GaussianProcess):
         st = self._state
         pts = _engine.as_points(st.ctx, x_original, X)
         # A factorisation that is still deferred (lazy mode, this object's own block): the prediction rides INSIDE it
-        # (`lpgp_potrf_predict`) -- for mean and variance together; a mean-only request takes that pipeline too if
-        # `config.variance_with_mean` is set (the variance is kept for the `std(x)` that usually follows), else it enqueues
-        # the factorisation and solves for the weights
-        fuse = speculative and st.deferred and self._representer_weights is None and (return_var or config.variance_with_mean)
+        # (`lpgp_potrf_predict`) -- for mean and variance together (a mean-only request arrives here as one if
+        # `config.variance_with_mean` is set); a plain mean-only request enqueues the factorisation and solves for the weights
+        fuse = speculative and st.deferred and self._representer_weights is None and return_var
         if not fuse:
             st.flush()
         rhs = self._cross(pts)

@@ -7,6 +7,7 @@ set -u
 ROUND=$1; TAG=$2; shift 2
 ARGS="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export LPGP_BENCH_NO_MODES=1      # the profiled runs contain the timed mode only (the default-mode / reference-sequence passes of the bench line would mix two schedules into one table)
 export LPGP_BENCH_PROF_STEPS=3      # bench.py's per-kernel HIP-event passes: short under the profiler (as in the committed r03 collections)
 D=gpurun_out/${ROUND}_${TAG}
 rm -rf "$D"; mkdir -p "$D"
@@ -22,5 +23,6 @@ run pmc_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "
 run pmc_write rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$D/pmc_write" -- python3 bench.py $PMC_ARGS
 run pmc_mfma rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$D/pmc_mfma" -- python3 bench.py $PMC_ARGS
 echo "python3 bench.py --steps 5 --warmup 2 --no-cpu $ARGS" >> "$D/commands.txt"
+unset LPGP_BENCH_NO_MODES
 python3 bench.py --steps 5 --warmup 2 --no-cpu $ARGS 2> "$D/bench.err" | tail -1 > "$D/bench.json"
 python3 scratch/summarize_profiles.py "$ROUND" "$TAG"
