@@ -290,7 +290,10 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     // there.
     if (p2 < cl) {
       const double narrow_frac = ctx->cus > 0 ? (double)ctx->cus / (double)(ctx->cus - ctx->reserve_narrow) : 1.0;
-      hipStream_t sB = (ctx->s_upd_narrow && t_b_us * narrow_frac < t_chain_us) ? ctx->s_upd_narrow : sU;
+      // (a riding substitution that runs its second half on the update stream has it to itself once its gate is open: the
+      //  remainder updates move to the narrow stream from then on)
+      const bool ride_has_upd = ride && ride->open && ride->stream2 == sU;
+      hipStream_t sB = (ctx->s_upd_narrow && (t_b_us * narrow_frac < t_chain_us || ride_has_upd)) ? ctx->s_upd_narrow : sU;
       if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
       if (dep_pending_u) {
         LPGP_HIP(hipStreamWaitEvent(sB, dep, 0));
