@@ -231,8 +231,10 @@ int  lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat);
  * of lpgp_gram_assemble_grid) --, add the noise b.cov (a scalar variance, or noise_diag[n], or noise_dense[n x n], at most
  * one of them), and factor: lazy == 0 factors and returns the status in *info (the reference's order of events); lazy == 1
  * enqueues the factorisation (lpgp_potrf_enqueue; status by lpgp_mat_check); lazy == 2 assembles only and leaves the
- * factorisation to whichever call needs the factor first -- the next lpgp_mat_condition (which enqueues it before it
- * declares its own block), lpgp_potrf / lpgp_potrf_enqueue, or lpgp_potrf_predict, inside which the prediction rides.  On an error -- and on info != 0 -- the block is dropped again (lpgp_mat_pop_block):
+ * factorisation to whichever call needs the factor first -- lpgp_potrf / lpgp_potrf_enqueue, or lpgp_potrf_predict, inside
+ * which the prediction rides; further lazy == 2 conditionings may follow first: all blocks that were only assembled are then
+ * factored TOGETHER, one factorisation from the first unfactored column on (a chain of small conditionings costs one panel
+ * chain instead of one per block; a large block in the MIDDLE of a chain -- c5 -- is factored with the prediction riding inside it).  On an error -- and on info != 0 -- the block is dropped again (lpgp_mat_pop_block):
  * the matrix is what it was before the call.  The same launches as the separate calls, in the same order; what it saves
  * is host time: nrow + 3 calls through the binding per conditioning (at N_tot ~ 1 000 a conditioning is bound by the
  * host), and the synchronisation the noise upload of lpgp_mat_add_diag needs for its borrowed host vector (here the

@@ -1139,8 +1139,11 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
   LPGP_CHECK(lazy == 0 || !ctx->distributed(), "lpgp_mat_condition: lazy status on a single GPU only");
   LPGP_DEVICE(ctx);
   if (info) *info = 0;
-  if (lazy != 0 && mat->pn_fact < mat->pn) LPGP_TRY(lpgp_potrf_enqueue(ctx, mat));     // an earlier block deferred with lazy == 2
-  LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_condition: earlier blocks are not factored (lpgp_potrf first)");
+  // earlier blocks that were only assembled (lazy == 2): another deferred block joins them -- they are factored TOGETHER by
+  // whoever needs the factor first, one factorisation from the first unfactored column on (lpgp_potrf_predict: with the
+  // prediction riding inside all of it); lazy == 1 enqueues their factorisation first, lazy == 0 requires them factored
+  if (lazy == 1 && mat->pn_fact < mat->pn) LPGP_TRY(lpgp_potrf_enqueue(ctx, mat));
+  LPGP_CHECK(lazy == 2 || mat->pn_fact == mat->pn, "lpgp_mat_condition: earlier blocks are not factored (lpgp_potrf first)");
   const int bi = lpgp_mat_add_block(ctx, mat, n);
   if (bi < 0) return bi;
   int rc = 0;

@@ -45,3 +45,8 @@ matrix_free_preconditioner_rank: int = 200      # pivoted-Cholesky rank (0: plai
 matrix_free_rtol: float = 1e-10                  # relative residual of every CG solve
 matrix_free_maxiter: int = 5000
 matrix_free_rhs_chunk: int = 64                  # prediction points per block of variance solves
+
+# Lazy mode: a block that was only assembled stays unfactored across FURTHER conditionings -- to be factored together with them,
+# the prediction riding inside -- only if it has at least this many rows; smaller ones are factored when the next conditioning
+# arrives (their kernels run while the host prepares it).
+defer_min_rows: int = 4096

@@ -61,7 +61,8 @@ def test_fused_pipeline_equals_two_pipelines_and_oracle(lazy, name, make):
     ref = owl.run(wl)
     assert_posterior_close(m1, v1, ref["mean"], ref["var"])
     # the factor the fused pipeline left behind IS the factor: weights, a second prediction elsewhere, the covariance
-    np.testing.assert_allclose(u1.representer_weights, u0.representer_weights, rtol=0, atol=1e-9 * np.max(np.abs(u0.representer_weights)))
+    # (the representer weights carry the condition number: two orders of elimination agree to cond x eps, not to 1e-12)
+    np.testing.assert_allclose(u1.representer_weights, u0.representer_weights, rtol=0, atol=1e-7 * np.max(np.abs(u0.representer_weights)))
     xs = wl.Xtest[:5]
     np.testing.assert_allclose(u1.cov.matrix(xs), u0.cov.matrix(xs), rtol=0, atol=1e-12 * max(sv, 1e-3))
     m2, v2 = u1.predict(wl.Xtest[::3])            # (another number of right-hand sides: other kernels, other blocking -> 1e-10)
@@ -212,3 +213,31 @@ def test_two_level_ride(lazy, make, halves):
         for k, v in saved.items():
             ctx.set_option(k, v)
     assert np.max(np.abs(m1 - m0)) <= 1e-11 * np.max(np.abs(m0)) and np.max(np.abs(v1 - v0)) <= 1e-11 * np.max(np.abs(v0)) + 1e-13
+
+
+def test_a_large_block_in_the_middle_of_a_chain_stays_deferred(lazy):
+    """Lazy mode: a block of at least `config.defer_min_rows` rows that is followed by further conditionings is factored TOGETHER with
+    them at the first use, the prediction riding inside all of it (c5's shape: collocation block, then interior values)."""
+    from linpde_gp_amd import problems
+    lp = lazy
+    saved = lp.config.defer_min_rows
+    wl = problems.heat_1d(nt=48, nx=24, m_side=20)          # blocks of 64, 256, 256, 1 152, 256 rows
+    try:
+        lp.config.lazy_factorization = False
+        _, m0, v0 = problems.condition_and_predict(wl)
+        lp.config.lazy_factorization = True
+        for thr, expect_joint in ((1000, True), (10**9, False)):
+            lp.config.defer_min_rows = thr
+            prior = problems.build_prior(wl)
+            u = prior
+            seen = []
+            for o in wl.observations:
+                X, Y = o.X_as_given()
+                b = None if o.noise_var is None else lp.randvars.Normal(np.zeros(Y.shape), np.full(o.X.shape[0], o.noise_var))
+                u = u.condition_on_observations(Y, X=X, L=problems.operator_of(o.op, wl.d), b=b)
+                seen.append(u._state.deferred_rows)
+            assert seen[3] == 1152 and seen[4] == (1152 + 256 if expect_joint else 256), seen
+            m1, v1 = u.predict(wl.Xtest)
+            assert np.max(np.abs(m1 - m0)) <= 1e-11 * np.max(np.abs(m0)) and np.max(np.abs(v1 - v0)) <= 1e-11 * np.max(np.abs(v0)) + 1e-13
+    finally:
+        lp.config.defer_min_rows = saved
