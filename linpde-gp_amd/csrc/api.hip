@@ -173,6 +173,22 @@ __global__ void clear_rows_kernel(double* a, int64_t ld, int64_t r0, int64_t nr,
   const int64_t lr = cyc_local(lay.rows, r0 + i), lc = cyc_local(lay.cols, c0 + c);
   if (lr >= 0 && lc >= 0) a[lr + lc * ld] = 0.0;
 }
+// identity tail of a block in ONE launch (round 5; three launches until then: a chain of small conditionings is launch-bound):
+// pad rows [r0, r0 + pad) x columns [0, r0) <- 0;  rows [r0, cap) x pad columns [r0, r0 + pad) <- 0, ones on the diagonal
+__global__ void pad_block_kernel(double* a, int64_t ld, int64_t r0, int64_t pad, int64_t cap, Layout2D lay) {
+  const int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;          // columns [0, r0 + pad)
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= r0 + pad) return;
+  const int64_t row = r0 + i;
+  if (row >= (c < r0 ? r0 + pad : cap)) return;
+  const int64_t lr = cyc_local(lay.rows, row), lc = cyc_local(lay.cols, c);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] = (row == c) ? 1.0 : 0.0;
+}
+static void launch_pad_block(hipStream_t st, double* a, int64_t ld, int64_t r0, int64_t pad, int64_t cap, const Layout2D& lay) {
+  const int64_t nc = r0 + pad, nr = cap - r0;
+  const unsigned gy = (unsigned)(nc < 65535 ? nc : 65535), gz = (unsigned)((nc + 65534) / 65535);
+  hipLaunchKernelGGL(pad_block_kernel, dim3((unsigned)((nr + 255) / 256), gy, gz), dim3(256), 0, st, a, ld, r0, pad, cap, lay);
+}
 static void launch_clear_rows(hipStream_t st, double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc, const Layout2D& lay) {
   if (nr <= 0 || nc <= 0) return;
   const unsigned gy = (unsigned)(nc < 65535 ? nc : 65535), gz = (unsigned)((nc + 65534) / 65535);
@@ -845,10 +861,7 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
     // pad columns (all rows down to the capacity), then ones on the diagonal
     const Layout2D lay = mat_layout(ctx);
     const int64_t r0 = b.poff + b.n;
-    launch_clear_rows(ctx->s_main, mat->a, mat->lr_cap, r0, pad, 0, b.poff + b.pn, lay);
-    launch_clear_rows(ctx->s_main, mat->a, mat->lr_cap, r0, mat->cap - r0, r0, pad, lay);
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, ctx->s_main, mat->a,
-                       mat->lr_cap, r0, r0 + pad, lay);
+    launch_pad_block(ctx->s_main, mat->a, mat->lr_cap, r0, pad, mat->cap, lay);
     LPGP_HIP(hipGetLastError());
   }
   mat->blocks.push_back(b);
