@@ -170,6 +170,19 @@ def test_random_problem_matches_oracle(seed):
     cond2 = ogp.cond2_estimate(post.G, post.chol)
     _assert_as_good_as_lapack("mean", mean, post.mean(Xt), m_exact, cond2)
     _assert_as_good_as_lapack("variance", var, post.var(Xt), v_exact, cond2)
+    # the same problem through the opt-in throughput mode -- deferred factorisation, the prediction riding inside it, resident
+    # panel chain -- against the same exact posterior with the same bar (round 5)
+    saved = lp.config.lazy_factorization
+    lp.config.lazy_factorization = True
+    try:
+        u_f = _random_problem(lp, seed)[0]
+        mean_f, var_f = u_f.predict(Xt if d > 1 else Xt[:, 0])
+        assert u_f._state.deferred is False and u_f._state.pending is False
+    finally:
+        lp.config.lazy_factorization = saved
+    _assert_as_good_as_lapack("mean (fused pipeline)", mean_f, post.mean(Xt), m_exact, cond2)
+    _assert_as_good_as_lapack("variance (fused pipeline)", var_f, post.var(Xt), v_exact, cond2)
+    del u_f
     # the two parts of that distance: (entries) the matrices as the device evaluates them ...
     G_dev, K_dev = device_matrices(u, oblocks, Xt, d)
     K_np = ogp.cross_cov(okern, oblocks, Xt)
