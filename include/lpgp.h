@@ -276,6 +276,17 @@ int  lpgp_rhs_destroy(lpgp_rhs* rhs);
 int  lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                          const lpgp_pts* X_obs, const lpgp_pts* X_test,
                          lpgp_rhs* rhs, const lpgp_mat* mat, int32_t bi);
+/* The same for ALL observation blocks in one call (round 5): blocks[bi] = {descriptor, observation points} of block bi (kd == NULL:
+ * the block has no cross-covariance with the prediction points, its rows stay zero).  Consecutive blocks that share a descriptor
+ * -- value observations on several boundary pieces -- are assembled by ONE launch (a table of point sets in the kernel
+ * arguments), as lpgp_mat_condition does for a block row of the Gram matrix (_conditional.py:140-153, :270).        */
+typedef struct lpgp_cross_block {
+  const lpgp_kdesc* kd;
+  int32_t ngroups;
+  const lpgp_pts* X_obs;
+} lpgp_cross_block;
+int  lpgp_cross_assemble_row(lpgp_ctx* ctx, const lpgp_cross_block* blocks, int32_t nblocks, const lpgp_pts* X_test,
+                             lpgp_rhs* rhs, const lpgp_mat* mat);
 /* mean_host[j] = prior_mean_host[j] + K_Xx[:, j] . w     (prior_mean_host may be NULL)
  * var_host[j]  = kxx_host[j] - || L^{-1} K_Xx[:, j] ||^2  (skipped if var_host == NULL)
  * K_Xx is overwritten by V = L^{-1} K_Xx when the variance is requested.  If no weights

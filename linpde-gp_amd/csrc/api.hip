@@ -412,6 +412,8 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_ASM_FACTORS")) ctx->asm_factors = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_ASM_FAST")) ctx->asm_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_ASM_CT")) ctx->asm_ct = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("LPGP_ASM_BATCH")) ctx->asm_batch = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LPGP_KRON_WIDE")) ctx->kron_wide = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_COLLECTIVE")) ctx->dist_bcast = std::strcmp(e, "bcast") == 0;
   if (const char* e = std::getenv("LPGP_DIST_SPLIT_GATHER")) ctx->split_gather = std::atoi(e) != 0;
   if (const char* e = std::getenv("LPGP_DIST_SCOPED_GATHER")) ctx->scoped_gather = std::atoi(e) != 0;
@@ -515,6 +517,8 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "small_tiles_max") == 0) *value = ctx->small_tiles_max;
   else if (std::strcmp(key, "live_mats") == 0) *value = ctx->live_mats;
   else if (std::strcmp(key, "asm_ct") == 0) *value = ctx->asm_ct;
+  else if (std::strcmp(key, "asm_batch") == 0) *value = ctx->asm_batch;
+  else if (std::strcmp(key, "kron_wide") == 0) *value = ctx->kron_wide;
   else if (std::strcmp(key, "asm_fast") == 0) *value = ctx->asm_fast;
   else if (std::strcmp(key, "fused_ahead") == 0) *value = ctx->fused_ahead;
   else if (std::strcmp(key, "fused_ahead_min_us") == 0) *value = ctx->fused_ahead_min_us;
@@ -562,6 +566,10 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->asm_factors = value != 0;
   } else if (std::strcmp(key, "asm_fast") == 0) {
     ctx->asm_fast = value != 0;
+  } else if (std::strcmp(key, "asm_batch") == 0) {
+    ctx->asm_batch = value != 0;
+  } else if (std::strcmp(key, "kron_wide") == 0) {
+    ctx->kron_wide = value != 0;
   } else if (std::strcmp(key, "asm_ct") == 0) {
     LPGP_CHECK(value >= 1 && value <= 64, "asm_ct must be in 1 .. 64");
     ctx->asm_ct = (int)value;
@@ -1160,6 +1168,42 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
   const int bi = lpgp_mat_add_block(ctx, mat, n);
   if (bi < 0) return bi;
   int rc = 0;
+  if (ctx->asm_batch && !ctx->distributed()) {
+    // the block row with as few launches as it has DIFFERENT descriptors: consecutive entries of the per-entry path that
+    // share one (value observations against value observations: the whole row incl. the diagonal block; the cross blocks
+    // of a differential block against the boundary blocks) go into one launch (assemble.hip: launch_assemble_batch)
+    const lpgp_block Bi = mat->blocks[bi];
+    std::vector<DevDesc> descs((size_t)nrow);
+    std::vector<AsmJob> jobs;
+    int run_start = -1;
+    auto flush = [&](int upto) -> int {
+      if (run_start < 0 || jobs.empty()) { run_start = -1; jobs.clear(); return 0; }
+      int r = launch_assemble_batch(ctx, ctx->s_main, descs[(size_t)run_start], jobs.data(), (int)jobs.size(), mat->a, mat->lr_cap, mat_layout(ctx));
+      (void)upto;
+      run_start = -1;
+      jobs.clear();
+      return r;
+    };
+    for (int j = 0; j < nrow && rc == 0; ++j) {
+      const lpgp_cond_block& e = row[j];
+      if (e.F0) {
+        rc = flush(j);
+        if (rc == 0) rc = lpgp_gram_assemble_grid(ctx, e.kd, e.ngroups, e.F0, j == bi ? nullptr : e.F1, mat, bi, j);
+        continue;
+      }
+      const lpgp_pts* Xc = (j == bi) ? X_new : e.X1;
+      const lpgp_block& Bj = mat->blocks[j];
+      LPGP_CHECK(X_new && Xc && e.kd, "lpgp_mat_condition: null point set or descriptor in row entry %d", j);
+      LPGP_CHECK(X_new->n == Bi.n && Xc->n == Bj.n && Xc->d == X_new->d && e.kd[0].d == X_new->d, "lpgp_mat_condition: shape mismatch in row entry %d", j);
+      rc = lower_kdesc(e.kd, e.ngroups, &descs[(size_t)j]);
+      if (rc != 0) break;
+      if (run_start >= 0 && !assemble_same_fast(descs[(size_t)run_start], descs[(size_t)j])) rc = flush(j);
+      if (rc != 0) break;
+      if (run_start < 0) run_start = j;
+      jobs.push_back(AsmJob{X_new->x, X_new->n, X_new->n_pad, Xc->x, Xc->n, Xc->n_pad, Bi.poff, Bj.poff, j == bi ? 1 : 0});
+    }
+    if (rc == 0) rc = flush(nrow);
+  } else
   for (int j = 0; j < nrow && rc == 0; ++j) {
     const lpgp_cond_block& e = row[j];
     if (e.F0)
@@ -1388,6 +1432,40 @@ int lpgp_cross_assemble(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, co
   rc = launch_assemble(ctx, ctx->s_main, desc, X_obs->x, X_obs->n, X_obs->n_pad, X_test->x, X_test->n,
                        X_test->n_pad, rhs->v, rhs->ld, B.poff, 0, 0);
   if (rc == 0 && bi < (int)rhs->assembled.size()) rhs->assembled[bi] = 1;
+  return rc;       // asynchronous (see lpgp_gram_assemble)
+}
+
+int lpgp_cross_assemble_row(lpgp_ctx* ctx, const lpgp_cross_block* blocks, int32_t nblocks, const lpgp_pts* X_test, lpgp_rhs* rhs,
+                            const lpgp_mat* mat) {
+  LPGP_CHECK(ctx && blocks && X_test && rhs && mat, "lpgp_cross_assemble_row: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(nblocks == (int32_t)mat->blocks.size(), "lpgp_cross_assemble_row: %d entries for %d blocks", nblocks, (int)mat->blocks.size());
+  LPGP_CHECK(rhs->ld == mat->pn && X_test->n == rhs->m, "lpgp_cross_assemble_row: rhs was created for a different matrix size or point count");
+  std::vector<DevDesc> descs((size_t)nblocks);
+  std::vector<AsmJob> jobs;
+  int run_start = -1, rc = 0;
+  auto flush = [&]() -> int {
+    int r = 0;
+    if (run_start >= 0 && !jobs.empty())
+      r = launch_assemble_batch(ctx, ctx->s_main, descs[(size_t)run_start], jobs.data(), (int)jobs.size(), rhs->v, rhs->ld, Layout2D());
+    run_start = -1;
+    jobs.clear();
+    return r;
+  };
+  for (int bi = 0; bi < nblocks && rc == 0; ++bi) {
+    const lpgp_cross_block& e = blocks[bi];
+    const lpgp_block& B = mat->blocks[(size_t)bi];
+    if (!e.kd || !e.X_obs) continue;                       // a block without cross-covariance: its rows stay zero (rhs_clear_unassembled)
+    LPGP_CHECK(e.X_obs->n == B.n && e.X_obs->d == X_test->d && e.kd[0].d == X_test->d, "lpgp_cross_assemble_row: shape mismatch in block %d", bi);
+    rc = lower_kdesc(e.kd, e.ngroups, &descs[(size_t)bi]);
+    if (rc != 0) break;
+    if (run_start >= 0 && !assemble_same_fast(descs[(size_t)run_start], descs[(size_t)bi])) rc = flush();
+    if (rc != 0) break;
+    if (run_start < 0) run_start = bi;
+    jobs.push_back(AsmJob{e.X_obs->x, e.X_obs->n, e.X_obs->n_pad, X_test->x, X_test->n, X_test->n_pad, B.poff, 0, 0});
+    if (bi < (int)rhs->assembled.size()) rhs->assembled[(size_t)bi] = 1;
+  }
+  if (rc == 0) rc = flush();
   return rc;       // asynchronous (see lpgp_gram_assemble)
 }
 

@@ -42,6 +42,23 @@ struct AsmArgs {
   Layout2D lay;                 // where element (row_off + i, col_off + j) lives on this rank (multi-GPU: only the owned tiles are written)
 };
 
+// A block ROW in one launch (round 5): up to ASM_MAXJ blocks that share ONE descriptor -- the cross blocks of a conditioning against
+// the earlier blocks (crosscov/linfunctls/_evaluation.py:163-173, _conditional.py:270), the rows of the cross-covariance
+// (_conditional.py:140-153) -- each with its own point sets and place in the output.  A workgroup finds its job by the prefix
+// of workgroup counts (a scalar search over the kernel arguments) and then runs exactly the single-block code.
+constexpr int ASM_MAXJ = 8;
+struct AsmJobDev {
+  const double* x0;
+  const double* x1;
+  int64_t n0, n1, n0_pad, n1_pad, row_off, col_off;
+  int32_t lower_only, tiles_r, tiles_c, ct;
+};
+struct AsmBatch {
+  int32_t njobs = 0;             // 0 / 1: the single block of AsmArgs
+  int32_t wg0[ASM_MAXJ + 1] = {};
+  AsmJobDev job[ASM_MAXJ];
+};
+
 // Per-point exponential factors of the Matern dimensions (eval_entries.h: `Fac`): for group g, dimension j and point p of
 // the tile, E+ = e^{-a (x_p - x0)} and E- = e^{+a (x_p - x0)} with the tile's own origin x0 (its first column point), rows
 // and columns in LDS: [g][j][sign][AT].  The arguments are carried in double-double (lpgp_exp_factors), so the accuracy of an
@@ -268,15 +285,26 @@ __device__ __forceinline__ void fast_entries(const FastDesc& fd, const double (&
 }
 
 template <int D, int N0, int N1, int MODE>       // MODE 0: general, 1: LIN, 2: LIN + EVEN (fast_entries)
-__global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a) {
+__global__ __launch_bounds__(256) void assemble_fast_kernel(FastDesc fd, AsmArgs a, AsmBatch bt) {
   constexpr int FE = 8;         // entries per thread per pass
   __shared__ double sx1[2][D][AT];
   __shared__ __attribute__((aligned(16))) double s_exp[2 * EXP_TAB_N];
+  int bx = blockIdx.x;
+  if (bt.njobs > 1) {
+    // which block of the row this workgroup belongs to (uniform: scalar loads from the kernel arguments)
+    int j = 0;
+    while (j + 1 < bt.njobs && bx >= bt.wg0[j + 1]) ++j;
+    bx -= bt.wg0[j];
+    const AsmJobDev& jb = bt.job[j];
+    a.x0 = jb.x0; a.x1 = jb.x1; a.n0 = jb.n0; a.n1 = jb.n1; a.n0_pad = jb.n0_pad; a.n1_pad = jb.n1_pad;
+    a.row_off = jb.row_off; a.col_off = jb.col_off; a.lower_only = jb.lower_only;
+    a.tiles_r = jb.tiles_r; a.tiles_c = jb.tiles_c; a.ct = jb.ct;
+  }
   // a workgroup owns `ct` consecutive column tiles of one tile row: the row coordinates and the exponential's table (4 KB
   // against 32 KB of output per tile) are set up once, the column coordinates of the next tile are staged while this one
   // is evaluated
-  const int tr = blockIdx.x % a.tiles_r;
-  const int tc0 = (blockIdx.x / a.tiles_r) * a.ct;
+  const int tr = bx % a.tiles_r;
+  const int tc0 = (bx / a.tiles_r) * a.ct;
   const int tc1 = tc0 + a.ct < a.tiles_c ? tc0 + a.ct : a.tiles_c;
   const int64_t r0 = (int64_t)tr * AT;
   if (a.lower_only && (int64_t)tc0 * AT > r0 + AT - 1) return;
@@ -411,10 +439,15 @@ static int fast_mode(const FastDesc& fd, int d) {
     if (fd.parity[c] & mask) return 1;
   return 2;
 }
+static thread_local const AsmBatch* g_asm_batch = nullptr;      // the job table of the assembly launch being dispatched (launch_fast below)
 template <int KIND, int D, int N0, int N1, int MODE, class Args>
 static void launch_fast_mode(dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
-  if constexpr (KIND == 0) hipLaunchKernelGGL((assemble_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a);
-  else hipLaunchKernelGGL((matvec_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a);
+  if constexpr (KIND == 0) {
+    static const AsmBatch none{};
+    hipLaunchKernelGGL((assemble_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a, g_asm_batch ? *g_asm_batch : none);
+  } else {
+    hipLaunchKernelGGL((matvec_fast_kernel<D, N0, N1, MODE>), grid, dim3(256), 0, stream, fd, a);
+  }
 }
 template <int KIND, int D, int N0, int N1, class Args>
 static void launch_fast_one(dim3 grid, hipStream_t stream, const FastDesc& fd, const Args& a) {
@@ -541,6 +574,71 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
   LPGP_HIP(hipGetLastError());
   LPGP_HIP(hipEventRecord(slot.done, stream));
   slot.used = true;
+  return 0;
+}
+
+// column tiles per workgroup of a rectangular block (see launch_assemble)
+static int fast_ct(const lpgp_ctx* ctx, int tiles_r, int tiles_c, int lower_only) {
+  int ct = 1;
+  while (!lower_only && ct < ctx->asm_ct && (int64_t)tiles_r * ((tiles_c + 2 * ct - 1) / (2 * ct)) >= 16 * (int64_t)(ctx->cus > 0 ? ctx->cus : 256)) ct *= 2;
+  return ct;
+}
+
+bool assemble_same_fast(const DevDesc& p, const DevDesc& q) {
+  FastDesc fp, fq;
+  std::memset(&fp, 0, sizeof(fp));          // (the comparison below is over the bytes, padding included)
+  std::memset(&fq, 0, sizeof(fq));
+  int a0, a1, b0, b1;
+  if (p.d != q.d || !fast_shape(p, &fp, &a0, &a1) || !fast_shape(q, &fq, &b0, &b1) || a0 != b0 || a1 != b1) return false;
+  return std::memcmp(&fp, &fq, sizeof(FastDesc)) == 0;
+}
+
+// Several blocks that share `host_desc` in as few launches as the job table allows (ASM_MAXJ per launch); descriptors outside the
+// specialised kernel's shapes, per-point factors or the measurement aids: one launch_assemble per block, as before.
+int launch_assemble_batch(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const AsmJob* jobs, int njobs, double* out, int64_t ld,
+                          const Layout2D& lay) {
+  FastDesc fd;
+  int N0 = 0, N1 = 0;
+  static const int diag = [] { const char* e = std::getenv("LPGP_ASM_DIAG"); return e ? std::atoi(e) : 0; }();
+  const bool fast = ctx->asm_fast && ctx->asm_batch && diag == 0 && !(ctx->asm_factors && host_desc.ngroups <= FACT_MAXG) && fast_shape(host_desc, &fd, &N0, &N1);
+  if (!fast || njobs <= 1) {
+    for (int j = 0; j < njobs; ++j)
+      LPGP_TRY_RC(launch_assemble(ctx, stream, host_desc, jobs[j].x0, jobs[j].n0, jobs[j].n0_pad, jobs[j].x1, jobs[j].n1, jobs[j].n1_pad, out, ld,
+                                  jobs[j].row_off, jobs[j].col_off, jobs[j].lower_only, lay));
+    return 0;
+  }
+  for (int j0 = 0; j0 < njobs; j0 += ASM_MAXJ) {
+    AsmBatch bt;
+    double entries = 0.0;
+    int wgs = 0;
+    for (int j = j0; j < njobs && j < j0 + ASM_MAXJ; ++j) {
+      const AsmJob& J = jobs[j];
+      const int tr = (int)((J.n0 + AT - 1) / AT), tc = (int)((J.n1 + AT - 1) / AT);
+      if (tr == 0 || tc == 0) continue;
+      AsmJobDev& d = bt.job[bt.njobs];
+      d.x0 = J.x0; d.x1 = J.x1; d.n0 = J.n0; d.n1 = J.n1; d.n0_pad = J.n0_pad; d.n1_pad = J.n1_pad;
+      d.row_off = J.row_off; d.col_off = J.col_off; d.lower_only = J.lower_only;
+      d.tiles_r = tr; d.tiles_c = tc; d.ct = fast_ct(ctx, tr, tc, J.lower_only);
+      bt.wg0[bt.njobs] = wgs;
+      wgs += tr * ((tc + d.ct - 1) / d.ct);
+      ++bt.njobs;
+      entries += J.lower_only ? 0.5 * (double)J.n0 * ((double)J.n0 + 1.0) : (double)J.n0 * (double)J.n1;
+    }
+    if (bt.njobs == 0) continue;
+    bt.wg0[bt.njobs] = wgs;
+    AsmArgs a;                       // the first job's fields (a launch with ONE job runs on them alone)
+    const AsmJobDev& f = bt.job[0];
+    a.x0 = f.x0; a.x1 = f.x1; a.n0 = f.n0; a.n1 = f.n1; a.n0_pad = f.n0_pad; a.n1_pad = f.n1_pad;
+    a.out = out; a.ld = ld; a.row_off = f.row_off; a.col_off = f.col_off; a.lower_only = f.lower_only; a.lay = lay;
+    a.tiles_r = f.tiles_r; a.tiles_c = f.tiles_c; a.ct = f.ct; a.flags = 0;
+    prof_begin(ctx, stream, LPGP_K_ASSEMBLE, 0.0, 8.0 * entries);
+    g_asm_batch = &bt;
+    if (host_desc.d == 1) launch_fast<0, 1>(N0, N1, dim3((unsigned)wgs), stream, fd, a);
+    else launch_fast<0, 2>(N0, N1, dim3((unsigned)wgs), stream, fd, a);
+    g_asm_batch = nullptr;
+    prof_end(ctx, stream);
+    LPGP_HIP(hipGetLastError());
+  }
   return 0;
 }
 
@@ -910,6 +1008,72 @@ __global__ __launch_bounds__(256) void kron2_kernel(KronArgs a, int ftr, int ftc
   }
 }
 
+// The same tile walk with 16-BYTE stores (round 5): a lane owns TWO consecutive fast rows, a wave stores 128 rows x 1 column = 1 KB per
+// instruction, a workgroup a 128 x 32 tile per pair of slow indices -- half the store instructions and address arithmetic per byte
+// of kron2_kernel.  Single GPU, even fast extent (the rows of a pair then start on a 16-byte boundary), at most 4 distinct fast
+// matrices (two rows of each in registers: 64 doubles).
+template <int NU>
+__global__ __launch_bounds__(256) void kron2w_kernel(KronArgs a, int ftr, int ftc) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int b = blockIdx.x;
+  const int tr = b % ftr; b /= ftr;
+  const int tcf = b % ftc;
+  const int chunk = b / ftc;
+  const int n0s = a.n0d[0], n1s = a.n1d[0], n0f = a.n0d[1], n1f = a.n1d[1];
+  const int if0 = tr * 128 + 2 * lane;                 // first of this lane's two fast rows (n0f even: both valid or neither)
+  const int jf0 = tcf * 32 + w * 8;
+  const int nu = a.nuniq[1];
+  const int64_t sfast = (int64_t)n1f * a.ldu[1];
+  const bool row_ok = if0 < n0f;
+  double v0[NU][8], v1[NU][8];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int jf = jf0 + x;
+      const bool ok = u < nu && row_ok && jf < n1f;
+      const double* src = a.u[1] + (int64_t)u * sfast + (int64_t)jf * a.ldu[1] + if0;
+      v0[u][x] = ok ? src[0] : 0.0;
+      v1[u][x] = ok ? src[1] : 0.0;
+    }
+  const int64_t sslow = (int64_t)n1s * a.ldu[0];
+  const int64_t npairs = (int64_t)n0s * n1s;
+  int64_t p = (int64_t)chunk * KR_PAIRS;
+  int is = (int)(p % n0s), js = (int)(p / n0s);
+  for (int it = 0; it < KR_PAIRS && p < npairs; ++it, ++p) {
+    const int64_t rtile = (int64_t)is * n0f + tr * 128;
+    const int64_t ctile = (int64_t)js * n1f + tcf * 32;
+    const bool skip = a.lower_only && ctile > rtile + 127;
+    if (!skip) {
+      double q[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) q[u] = 0.0;
+      for (int t = 0; t < a.nterms; ++t) {
+        const double pv = a.coef[t] * a.u[0][(int64_t)a.which[t][0] * sslow + (int64_t)js * a.ldu[0] + is];
+        const int uu = a.which[t][1];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) q[u] += (uu == u) ? pv : 0.0;
+      }
+      double* outp = a.out + (a.row_off + (int64_t)is * n0f + if0) + (a.col_off + (int64_t)js * n1f + jf0) * a.ld;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          a0 = fma(q[u], v0[u][x], a0);
+          a1 = fma(q[u], v1[u][x], a1);
+        }
+        if (row_ok && jf0 + x < n1f) *reinterpret_cast<double2*>(outp + (int64_t)x * a.ld) = make_double2(a0, a1);
+      }
+    }
+    if (++is == n0s) {
+      is = 0;
+      ++js;
+    }
+  }
+}
+
 template <int D>
 static void launch_kron_nu(dim3 grid, hipStream_t stream, const KronArgs& a) {
   const int nu = a.nuniq[D - 1];
@@ -1030,11 +1194,15 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
   const double entries = lower_only ? 0.5 * (double)a.n0 * ((double)a.n0 + 1.0) : (double)a.n0 * (double)a.n1;
   prof_begin(ctx, stream, LPGP_K_ASSEMBLE_GRID, 0.0, 8.0 * entries);
   if (D == 2 && a.nuniq[1] <= 8 && a.n0d[1] >= 32 && a.n1d[1] >= 16) {
+    const bool dist = lay.rows.P > 1 || lay.cols.P > 1;
     const int ftr = (a.n0d[1] + 63) / 64, ftc = (a.n1d[1] + 31) / 32;
     const int64_t chunks = ((int64_t)a.n0d[0] * a.n1d[0] + KR_PAIRS - 1) / KR_PAIRS;
     dim3 g2((unsigned)((int64_t)ftr * ftc * chunks));
-    const bool dist = lay.rows.P > 1 || lay.cols.P > 1;
-    if (a.nuniq[1] <= 4) {
+    if (!dist && ctx->kron_wide && a.n0d[1] % 2 == 0 && a.nuniq[1] <= 4 && ((a.row_off | a.ld) & 1) == 0) {
+      // 16-byte stores: a lane owns two consecutive fast rows (kron2w_kernel)
+      const int ftrw = (a.n0d[1] + 127) / 128;
+      hipLaunchKernelGGL((kron2w_kernel<4>), dim3((unsigned)((int64_t)ftrw * ftc * chunks)), dim3(256), 0, stream, a, ftrw, ftc);
+    } else if (a.nuniq[1] <= 4) {
       if (dist) hipLaunchKernelGGL((kron2_kernel<4, true>), g2, dim3(256), 0, stream, a, ftr, ftc);
       else hipLaunchKernelGGL((kron2_kernel<4, false>), g2, dim3(256), 0, stream, a, ftr, ftc);
     } else {

@@ -130,6 +130,8 @@ struct lpgp_ctx {
   int gemm_band = 8;               // GEMM grid: tile rows per band of the dense enumeration (an XCD works on band x 64/band tiles at a time)
   int fused_solve = 1;             // forward substitution: one launch per panel of <= 512 rows (panel_solve_kernel); 0: a tile solve and an update per tile
   int asm_fast = 1;                // per-entry assembly: descriptors of the common shapes (D <= 2, one group, <= 2 parity classes, degrees <= 4) on the specialised kernel (assemble_fast_kernel; bit-identical to the generic one)
+  int kron_wide = 1;               // Kronecker expansion with 16-byte stores where the fast extent is even (kron2w_kernel)
+  int asm_batch = 1;               // blocks of a block row that share a descriptor are assembled in one launch (assemble.hip: launch_assemble_batch)
   int asm_ct = 4;                  // assemble_fast_kernel: column tiles per workgroup, at most (LPGP_ASM_CT)
   int asm_factors = 0;             // per-entry assembly / matrix-free product: exponentials of Matern dimensions from per-point factors (eval_entries.h);
                                    // +13 % on the kernel, ~4x the rounding noise of the entries (two exps and a product instead of one exp): off by default
@@ -376,6 +378,16 @@ int launch_assemble(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc,
                     int64_t n0, int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad,
                     double* out, int64_t ld, int64_t row_off, int64_t col_off, int lower_only,
                     const Layout2D& lay = Layout2D());
+// several blocks with ONE descriptor (a block row of a conditioning, the rows of a cross-covariance) in one launch
+struct AsmJob {
+  const double* x0; int64_t n0, n0_pad;
+  const double* x1; int64_t n1, n1_pad;
+  int64_t row_off, col_off;
+  int lower_only;
+};
+bool assemble_same_fast(const DevDesc& p, const DevDesc& q);
+int launch_assemble_batch(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const AsmJob* jobs, int njobs, double* out, int64_t ld,
+                          const Layout2D& lay);
 int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd, int ngroups,
                          const double* const* F0, const int64_t* n0d, const double* const* F1, const int64_t* n1d,
                          double* work, size_t work_doubles, double* out, int64_t ld, int64_t row_off,

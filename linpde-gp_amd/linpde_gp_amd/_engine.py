@@ -494,6 +494,16 @@ class Rhs:
         check(lib.lpgp_cross_assemble(self.ctx._h, arr, len(arr), X_obs._h, X_test._h, self._h, self.mat._h, bi),
               "lpgp_cross_assemble")
 
+    def cross_assemble_row(self, entries, X_test: Points):
+        """All observation blocks in one call (`lpgp_cross_assemble_row`): entries = [(kdesc, X_obs)] per block, in block order."""
+        arr = (_lib.CrossBlock * len(entries))()
+        keep = []
+        for e, (kdesc, X_obs) in zip(arr, entries):
+            kd = _kdesc_array(kdesc)
+            keep.append(kd)
+            e.kd, e.ngroups, e.X_obs = C.cast(kd, C.POINTER(_lib.KDesc)), len(kd), X_obs._h
+        check(lib.lpgp_cross_assemble_row(self.ctx._h, arr, len(arr), X_test._h, self._h, self.mat._h), "lpgp_cross_assemble_row")
+
     def trsm_lower(self):
         check(lib.lpgp_trsm_lower(self.ctx._h, self.mat._h, self._h), "lpgp_trsm_lower")
 

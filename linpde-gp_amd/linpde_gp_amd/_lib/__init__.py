@@ -47,6 +47,11 @@ class CondBlock(C.Structure):
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32)
 
 
+class CrossBlock(C.Structure):
+    """`lpgp_cross_block` (include/lpgp.h): one observation block of a cross-covariance row."""
+    _fields_ = [("kd", C.POINTER(KDesc)), ("ngroups", C.c_int32), ("X_obs", C.c_void_p)]
+
+
 class LpgpError(RuntimeError):
     pass
 
@@ -112,6 +117,7 @@ def _load() -> C.CDLL:
     sig("lpgp_rhs_create", C.c_int, vp, vp, i64, C.POINTER(vp))
     sig("lpgp_rhs_destroy", C.c_int, vp)
     sig("lpgp_cross_assemble", C.c_int, vp, pk, i32, vp, vp, vp, vp, i32)
+    sig("lpgp_cross_assemble_row", C.c_int, vp, C.POINTER(CrossBlock), i32, vp, vp, vp)
     sig("lpgp_predict", C.c_int, vp, vp, vp, pd, pd, pd, pd)
     sig("lpgp_potrf_predict", C.c_int, vp, vp, vp, pd, pd, pd, pd)
     sig("lpgp_trsm_lower", C.c_int, vp, vp, vp)
@@ -138,7 +144,7 @@ EXPORTED = [
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
-    "lpgp_cross_assemble", "lpgp_predict", "lpgp_potrf_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
+    "lpgp_cross_assemble", "lpgp_cross_assemble_row", "lpgp_predict", "lpgp_potrf_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_kron_fits", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get",
     ]

@@ -519,9 +519,9 @@ class ConditionalGaussianProcess(GaussianProcess):
         st = self._state
         rhs = _engine.Rhs(st.ctx, st.mat, Xtest_pts.n)
         base = self._prior.cov
-        for bi, ob in enumerate(self._blocks):
-            # (L_obs k Ltest'^*)(X_obs, x)  == (Ltest k L_obs'^*)(x, X_obs) for the symmetric priors here
-            rhs.cross_assemble(_lowered(base, ob.coeffs, self._test_coeffs), ob.points, Xtest_pts, bi)
+        # (L_obs k Ltest'^*)(X_obs, x)  == (Ltest k L_obs'^*)(x, X_obs) for the symmetric priors here; one call for the whole row
+        # (blocks that share a descriptor share a launch)
+        rhs.cross_assemble_row([(_lowered(base, ob.coeffs, self._test_coeffs), ob.points) for ob in self._blocks], Xtest_pts)
         return rhs
 
     def _prior_diag(self) -> float:

@@ -241,3 +241,44 @@ def test_a_large_block_in_the_middle_of_a_chain_stays_deferred(lazy):
             assert np.max(np.abs(m1 - m0)) <= 1e-11 * np.max(np.abs(m0)) and np.max(np.abs(v1 - v0)) <= 1e-11 * np.max(np.abs(v0)) + 1e-13
     finally:
         lp.config.defer_min_rows = saved
+
+
+def test_batched_block_rows_are_bit_identical():
+    """Round 5: the blocks of a block row that share a descriptor are assembled by ONE launch (a table of point sets in the kernel
+    arguments; `lpgp_mat_condition`, `lpgp_cross_assemble_row`).  Same code per workgroup: the factor and the cross-covariance
+    are bit-identical to the one-launch-per-block path (`asm_batch = 0`)."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _engine, problems
+    ctx = _engine.default_context()
+    wl = problems.poisson_2d(n_side=20, n_bdry=37, m_side=9)            # four ragged boundary blocks + a grid block
+    out = {}
+    saved = ctx.get_option("asm_batch")
+    try:
+        for batch in (1, 0):
+            ctx.set_option("asm_batch", batch)
+            u, m, v = problems.condition_and_predict(wl)
+            out[batch] = (u.gram.cholesky(), m, v, u._cross(_engine.Points(ctx, wl.Xtest)).to_host())
+            del u
+    finally:
+        ctx.set_option("asm_batch", saved)
+    for a, b in zip(out[1], out[0]):
+        np.testing.assert_array_equal(a, b)
+    # ... and nine value blocks in one chain: a row of more blocks than one job table holds (eight)
+    cf = lp.randprocs.covfuncs
+    prior = lp.GaussianProcess(lp.functions.Zero((1,)), cf.Matern((1,), nu=2.5, lengthscales=0.4))
+    rng = np.random.default_rng(8)
+    res = {}
+    try:
+        for batch in (1, 0):
+            ctx.set_option("asm_batch", batch)
+            r2 = np.random.default_rng(8)
+            u = prior
+            for k in range(10):
+                X = r2.uniform(-1, 1, (17 + 11 * k, 1))
+                u = u.condition_on_observations(np.sin(3 * X[:, 0]), X, b=lp.randvars.Normal(np.zeros(X.shape[0]), 1e-3 * np.eye(X.shape[0])))
+            res[batch] = u.predict(np.linspace(-1, 1, 50)[:, None])
+            del u
+    finally:
+        ctx.set_option("asm_batch", saved)
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
