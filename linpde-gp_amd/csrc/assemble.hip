@@ -1023,6 +1023,17 @@ __global__ __launch_bounds__(256) void kron2w_kernel(KronArgs a, int ftr, int ft
   const int n0s = a.n0d[0], n1s = a.n1d[0], n0f = a.n0d[1], n1f = a.n1d[1];
   const int if0 = tr * 128 + 2 * lane;                 // first of this lane's two fast rows (n0f even: both valid or neither)
   const int jf0 = tcf * 32 + w * 8;
+  if (a.lower_only) {
+    // a diagonal block: half of the pairs of slow indices lie above the diagonal -- a workgroup whose pairs ALL do leaves before
+    // it loads its 64 values per lane (scalar test over <= 16 pairs)
+    const int64_t np_ = (int64_t)n0s * n1s;
+    bool any = false;
+    for (int64_t pp = (int64_t)chunk * KR_PAIRS; pp < np_ && pp < (int64_t)(chunk + 1) * KR_PAIRS; ++pp) {
+      const int64_t is_ = pp % n0s, js_ = pp / n0s;
+      any = any || !(js_ * n1f + tcf * 32 > is_ * n0f + tr * 128 + 127);
+    }
+    if (!any) return;
+  }
   const int nu = a.nuniq[1];
   const int64_t sfast = (int64_t)n1f * a.ldu[1];
   const bool row_ok = if0 < n0f;

@@ -282,3 +282,30 @@ def test_batched_block_rows_are_bit_identical():
         ctx.set_option("asm_batch", saved)
     np.testing.assert_array_equal(res[1][0], res[0][0])
     np.testing.assert_array_equal(res[1][1], res[0][1])
+
+
+def test_kronecker_expansion_with_16_byte_stores_is_bit_identical():
+    """Round 5: `kron2w_kernel` (a lane owns two consecutive fast rows: 16-byte stores) against `kron2_kernel`, diagonal (lower-only)
+    and cross blocks, fast extents that are multiples of 128, even but ragged, and odd (falls back to the 8-byte kernel)."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _engine
+    from linpde_gp_amd.linfuncops import diffops
+    ctx = _engine.default_context()
+    cf = lp.randprocs.covfuncs
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), 1.7 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=0.8), cf.Matern((), nu=3.5, lengthscales=1.1)))
+    saved = ctx.get_option("kron_wide")
+    try:
+        for n_slow, n_fast in ((9, 128), (7, 150), (6, 67), (3, 256)):
+            g0 = lp.domains.TensorProductGrid(np.linspace(-1, 1, n_slow), np.linspace(-1, 1, n_fast))
+            g1 = lp.domains.TensorProductGrid(np.linspace(-0.9, 0.8, 5), np.linspace(-1, 1, 40))
+            res = {}
+            for wide in (1, 0):
+                ctx.set_option("kron_wide", wide)
+                u = prior.condition_on_observations(np.zeros(g1.shape[:-1]), X=g1, b=lp.randvars.Normal(np.zeros(g1.shape[:-1]), 1e-2 * np.ones(200)))
+                u = u.condition_on_observations(np.ones(g0.shape[:-1]), X=g0, L=-1.0 * diffops.Laplacian((2,)),
+                                                b=lp.randvars.Normal(np.zeros(g0.shape[:-1]), 1e-3 * np.ones(n_slow * n_fast)))
+                res[wide] = u.gram.cholesky()
+                del u
+            np.testing.assert_array_equal(res[1], res[0])
+    finally:
+        ctx.set_option("kron_wide", saved)
