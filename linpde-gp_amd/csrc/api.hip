@@ -189,6 +189,36 @@ static void launch_pad_block(hipStream_t st, double* a, int64_t ld, int64_t r0, 
   const unsigned gy = (unsigned)(nc < 65535 ? nc : 65535), gz = (unsigned)((nc + 65534) / 65535);
   hipLaunchKernelGGL(pad_block_kernel, dim3((unsigned)((nr + 255) / 256), gy, gz), dim3(256), 0, st, a, ld, r0, pad, cap, lay);
 }
+// ... and, for lpgp_mat_condition, together with the block's measurement noise on the diagonal (sigma^2 I or a vector): ONE launch
+// behind the assembly instead of a padding launch in front of it and an add_diag launch behind it.  The padding is the
+// arithmetic of pad_block_kernel, the noise that of add_diag_kernel (one addition per diagonal entry: identical bits).
+__global__ void finish_block_kernel(double* a, int64_t ld, int64_t r0, int64_t pad, int64_t cap, Layout2D lay, int64_t ncols, int64_t d0, int64_t dn,
+                                    const double* dv, double dscalar) {
+  const int64_t c = blockIdx.y + (int64_t)blockIdx.z * 65535;          // columns [0, ncols): padding; slice ncols: the noise
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c == ncols) {
+    if (i < dn) {
+      const int64_t lr = cyc_local(lay.rows, d0 + i), lc = cyc_local(lay.cols, d0 + i);
+      if (lr >= 0 && lc >= 0) a[lr + lc * ld] += (dv ? dv[i] : 0.0) + dscalar;
+    }
+    return;
+  }
+  if (c > ncols) return;
+  const int64_t row = r0 + i;
+  if (row >= (c < r0 ? r0 + pad : cap)) return;
+  const int64_t lr = cyc_local(lay.rows, row), lc = cyc_local(lay.cols, c);
+  if (lr >= 0 && lc >= 0) a[lr + lc * ld] = (row == c) ? 1.0 : 0.0;
+}
+// pad == 0: noise only; dn == 0: padding only
+static void launch_finish_block(hipStream_t st, double* a, int64_t ld, int64_t r0, int64_t pad, int64_t cap, const Layout2D& lay, int64_t d0, int64_t dn,
+                                const double* dv, double dscalar) {
+  const int64_t ncols = pad > 0 ? r0 + pad : 0, nr = pad > 0 ? cap - r0 : 0;
+  if (ncols == 0 && dn == 0) return;
+  const int64_t rows = nr > dn ? nr : dn, slices = ncols + (dn > 0 ? 1 : 0);
+  const unsigned gy = (unsigned)(slices < 65535 ? slices : 65535), gz = (unsigned)((slices + 65534) / 65535);
+  hipLaunchKernelGGL(finish_block_kernel, dim3((unsigned)((rows + 255) / 256), gy, gz), dim3(256), 0, st, a, ld, r0, pad, cap, lay, ncols, d0, dn, dv,
+                     dscalar);
+}
 static void launch_clear_rows(hipStream_t st, double* a, int64_t ld, int64_t r0, int64_t nr, int64_t c0, int64_t nc, const Layout2D& lay) {
   if (nr <= 0 || nc <= 0) return;
   const unsigned gy = (unsigned)(nc < 65535 ? nc : 65535), gz = (unsigned)((nc + 65534) / 65535);
@@ -202,6 +232,16 @@ static int ensure_tmp(lpgp_ctx* ctx, int64_t n) {
   ctx->tmp_cap = 0;
   LPGP_HIP(hipMalloc(&ctx->d_tmp, (size_t)n * sizeof(double)));
   ctx->tmp_cap = n;
+  return 0;
+}
+
+static int ensure_stage(lpgp_ctx* ctx, int64_t n) {
+  if (n <= ctx->stage_cap) return 0;
+  if (ctx->h_stage) LPGP_HIP(hipHostFree(ctx->h_stage));
+  ctx->h_stage = nullptr;
+  ctx->stage_cap = 0;
+  LPGP_HIP(hipHostMalloc(&ctx->h_stage, (size_t)n * sizeof(double), hipHostMallocDefault));
+  ctx->stage_cap = n;
   return 0;
 }
 
@@ -366,6 +406,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_VCHAIN")) ctx->ride_vchain_max_wgs = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_ROWS")) ctx->ride_outer_rows = std::atol(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_MIN_TILES")) ctx->ride_outer_min_tiles = std::atoi(e);
@@ -456,6 +497,9 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   (void)hipFree(ctx->d_info);
   if (ctx->d_chain_flags) (void)hipFree(ctx->d_chain_flags);
   (void)hipHostFree(ctx->h_info_pinned);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_stage_r) (void)hipHostFree(ctx->h_stage_r);
+  if (ctx->ev_stage_r) (void)hipEventDestroy(ctx->ev_stage_r);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   for (size_t r = 0; r < ctx->ipc_peer.size(); ++r)
     if ((int)r != ctx->rank && ctx->ipc_peer[r]) (void)hipIpcCloseMemHandle(ctx->ipc_peer[r]);
@@ -529,6 +573,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
   else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
   else if (std::strcmp(key, "chain_resident_max_rows") == 0) *value = ctx->chain_resident_max_rows;
+  else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
   else if (std::strcmp(key, "ride_outer_rows") == 0) *value = ctx->ride_outer_rows;
@@ -610,6 +655,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->ride_stream = (int)value;
   } else if (std::strcmp(key, "chain_resident_max_rows") == 0) {
     ctx->chain_resident_max_rows = (int)value;
+  } else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) {
+    ctx->ride_vchain_max_wgs = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {
     ctx->ride_occ3 = value != 0;
   } else if (std::strcmp(key, "ride_gate_pct") == 0) {
@@ -842,7 +889,10 @@ int lpgp_mat_destroy(lpgp_mat* m) {
   return 0;
 }
 
-int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
+static int mat_add_block_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, bool pad_now);
+int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) { return mat_add_block_impl(ctx, mat, n, true); }
+// pad_now = false: the caller launches the identity tail itself (lpgp_mat_condition: together with the noise, launch_finish_block)
+static int mat_add_block_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, bool pad_now) {
   LPGP_CHECK(ctx && mat && n > 0, "lpgp_mat_add_block: bad argument");
   LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->hidden.empty(), "lpgp_mat_add_block: a strict prefix of the blocks is in view (lpgp_mat_set_view); extend a clone instead");
@@ -864,7 +914,7 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) {
     if (rc != 0) return rc;
   }
   const int64_t pad = b.pn - b.n;
-  if (pad > 0) {
+  if (pad > 0 && pad_now) {
     // identity tail of the block: zero the pad rows (all columns up to the block end) and the
     // pad columns (all rows down to the capacity), then ones on the diagonal
     const Layout2D lay = mat_layout(ctx);
@@ -1147,6 +1197,7 @@ int lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat) {
   if (rc != 0) return rc;
   mat->pn_fact = mat->pn;          // provisionally: lpgp_mat_check / lpgp_mat_truncate take it back on failure
   mat->unchecked = 1;
+  mat->status_known = 0;
   mat->has_w = 0;
   mat->has_r = 0;
   return 0;
@@ -1165,7 +1216,10 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
   // prediction riding inside all of it); lazy == 1 enqueues their factorisation first, lazy == 0 requires them factored
   if (lazy == 1 && mat->pn_fact < mat->pn) LPGP_TRY(lpgp_potrf_enqueue(ctx, mat));
   LPGP_CHECK(lazy == 2 || mat->pn_fact == mat->pn, "lpgp_mat_condition: earlier blocks are not factored (lpgp_potrf first)");
-  const int bi = lpgp_mat_add_block(ctx, mat, n);
+  // (the identity tail of the block is written by ONE launch together with its noise, behind the assembly -- fused_finish;
+  //  the assembly kernels touch logical entries only)
+  const bool fused_finish = ctx->asm_batch && !noise_dense;
+  const int bi = mat_add_block_impl(ctx, mat, n, !fused_finish);
   if (bi < 0) return bi;
   int rc = 0;
   if (ctx->asm_batch && !ctx->distributed()) {
@@ -1193,8 +1247,17 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
       }
       const lpgp_pts* Xc = (j == bi) ? X_new : e.X1;
       const lpgp_block& Bj = mat->blocks[j];
-      LPGP_CHECK(X_new && Xc && e.kd, "lpgp_mat_condition: null point set or descriptor in row entry %d", j);
-      LPGP_CHECK(X_new->n == Bi.n && Xc->n == Bj.n && Xc->d == X_new->d && e.kd[0].d == X_new->d, "lpgp_mat_condition: shape mismatch in row entry %d", j);
+      // (no early return in here: a failure must reach the roll-back of the new block below)
+      if (!(X_new && Xc && e.kd)) {
+        set_error("lpgp_mat_condition: null point set or descriptor in row entry %d", j);
+        rc = -1;
+        break;
+      }
+      if (!(X_new->n == Bi.n && Xc->n == Bj.n && Xc->d == X_new->d && e.kd[0].d == X_new->d)) {
+        set_error("lpgp_mat_condition: shape mismatch in row entry %d", j);
+        rc = -1;
+        break;
+      }
       rc = lower_kdesc(e.kd, e.ngroups, &descs[(size_t)j]);
       if (rc != 0) break;
       if (run_start >= 0 && !assemble_same_fast(descs[(size_t)run_start], descs[(size_t)j])) rc = flush(j);
@@ -1211,8 +1274,18 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
     else
       rc = lpgp_gram_assemble(ctx, e.kd, e.ngroups, X_new, j == bi ? nullptr : e.X1, mat, bi, j);
   }
-  if (rc == 0 && noise_scalar != 0.0) rc = lpgp_mat_add_diag(ctx, mat, bi, nullptr, noise_scalar);
+  if (rc == 0 && noise_scalar != 0.0 && !fused_finish) rc = lpgp_mat_add_diag(ctx, mat, bi, nullptr, noise_scalar);
   if (rc == 0 && noise_dense) rc = lpgp_mat_add_dense(ctx, mat, bi, noise_dense);
+  if (rc == 0 && fused_finish && !noise_diag) {
+    const lpgp_block& B = mat->blocks[bi];
+    launch_finish_block(ctx->s_main, mat->a, mat->lr_cap, B.poff + B.n, B.pn - B.n, mat->cap, mat_layout(ctx), B.poff, noise_scalar != 0.0 ? B.n : 0,
+                        nullptr, noise_scalar);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("lpgp_mat_condition: %s", hipGetErrorString(e));
+      rc = -1;
+    }
+  }
   if (rc == 0 && noise_diag) {
     // the vector is staged into the block's own segment of the weights buffer (unused until the first solve, which is
     // stream-ordered behind the kernel below) through a stream that is idle during conditionings: nothing waits for the
@@ -1226,6 +1299,12 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
     if (e != hipSuccess) {
       set_error("lpgp_mat_condition: noise upload: %s", hipGetErrorString(e));
       rc = -1;
+    } else if (fused_finish) {
+      launch_finish_block(ctx->s_main, mat->a, mat->lr_cap, B.poff + B.n, B.pn - B.n, mat->cap, mat_layout(ctx), B.poff, B.n, mat->w + B.poff, 0.0);
+      if ((e = hipGetLastError()) != hipSuccess) {
+        set_error("lpgp_mat_condition: %s", hipGetErrorString(e));
+        rc = -1;
+      }
     } else {
       rc = launch_add_diag(ctx->s_main, mat->a, mat->lr_cap, B.poff, B.n, mat->w + B.poff, 0.0, mat_layout(ctx));
     }
@@ -1250,8 +1329,13 @@ int lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block) 
   if (block) *block = -1;
   if (!mat->unchecked) return 0;
   int h = 0;
-  LPGP_HIP(hipMemcpyAsync(&h, mat->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
-  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  if (mat->status_known) {
+    h = mat->status_value;             // read back by lpgp_potrf_predict together with its results, nothing enqueued since
+  } else {
+    LPGP_HIP(hipMemcpyAsync(&h, mat->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
+    LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  }
+  mat->status_known = 0;
   mat->unchecked = 0;
   LPGP_CHECK(h >= 0, "resident panel chain: a hand-over between workgroups timed out (device status %d); set LPGP_CHAIN_RESIDENT=-1", h);
   *info = h;
@@ -1277,6 +1361,7 @@ int lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks) {
   if (mat->pn_fact > mat->pn) mat->pn_fact = mat->pn;
   LPGP_HIP(hipMemset(mat->d_status, 0, sizeof(int)));
   mat->unchecked = 0;
+  mat->status_known = 0;
   mat->has_w = 0;
   mat->has_r = 0;
   return 0;
@@ -1352,6 +1437,31 @@ int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
   LPGP_CHECK(ctx && mat && r_host, "lpgp_mat_set_residual: null argument");
   LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn > 0, "lpgp_mat_set_residual: empty matrix");      // (factored or not: lpgp_potrf_predict takes it along)
+  if (!ctx->distributed() && !ctx->single_stream) {
+    // Through pinned staging on the panel stream, NO wait (round 5): every reader of the residual is a kernel or a copy on the
+    // panel stream (lpgp_predict, lpgp_potrf_predict, lpgp_solve_weights), the caller's vector has been consumed when this
+    // returns; the staging buffer is reused only after the previous upload has completed (an event, long signalled when the
+    // next call comes).  Until round 5: a copy from pageable memory on a side stream and a wait for it, ~15 us of a host that a
+    // small problem's step is bound by.
+    if (ctx->stage_r_cap < mat->pn) {
+      if (ctx->h_stage_r) {
+        LPGP_HIP(hipEventSynchronize(ctx->ev_stage_r));
+        LPGP_HIP(hipHostFree(ctx->h_stage_r));
+      }
+      ctx->h_stage_r = nullptr;
+      ctx->stage_r_cap = 0;
+      LPGP_HIP(hipHostMalloc(&ctx->h_stage_r, (size_t)mat->pn * sizeof(double), hipHostMallocDefault));
+      ctx->stage_r_cap = mat->pn;
+      if (!ctx->ev_stage_r) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_stage_r, hipEventDisableTiming));
+    } else {
+      LPGP_HIP(hipEventSynchronize(ctx->ev_stage_r));
+    }
+    scatter_padded(mat, r_host, ctx->h_stage_r);
+    LPGP_HIP(hipMemcpyAsync(mat->r(), ctx->h_stage_r, (size_t)mat->pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+    LPGP_HIP(hipEventRecord(ctx->ev_stage_r, ctx->s_main));
+    mat->has_r = 1;
+    return 0;
+  }
   std::vector<double> hp((size_t)mat->pn);
   scatter_padded(mat, r_host, hp.data());
   // NOT on the panel stream: the residual's place in HBM is touched by no kernel of the factorisation, so the upload need
@@ -1367,6 +1477,26 @@ int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
 }
 
 // ---- prediction -----------------------------------------------------------------------------
+// What lpgp_rhs_create has to clear -- the rows of the blocks' padding tails (all logical columns) and the spare columns (all
+// rows) -- in ONE launch (until round 5: a memset for the spare columns and a 2-D memset per padded block; five launches in
+// front of every prediction of the reference's 2-D Poisson problem).  Job j < nj: rows [row0[j], row0[j] + nr[j]) x m columns;
+// job nj: ld x (m_pad - m) doubles from column m on.
+constexpr int RHS_PAD_JOBS = 15;
+struct RhsPadJobs { int64_t row0[RHS_PAD_JOBS]; int32_t nr[RHS_PAD_JOBS]; int32_t nj; };
+__global__ void rhs_pad_kernel(double* v, int64_t ld, int64_t m, int64_t m_pad, RhsPadJobs jb, int spare) {
+  const int j = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j < jb.nj) {
+    const int64_t nr = jb.nr[j], tot = nr * m;
+    double* p = v + jb.row0[j];
+    for (int64_t t = t0; t < tot; t += stride) p[(t % nr) + (t / nr) * ld] = 0.0;
+  } else if (spare) {
+    const int64_t tot = ld * (m_pad - m);
+    double* p = v + ld * m;
+    for (int64_t t = t0; t < tot; t += stride) p[t] = 0.0;
+  }
+}
+
 int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out) {
   LPGP_CHECK(ctx && mat && out && m >= 1, "lpgp_rhs_create: bad argument");
   LPGP_DEVICE(ctx);
@@ -1384,11 +1514,36 @@ int lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** ou
   r->v = (double*)pv;
   // lpgp_cross_assemble writes every logical row of every logical column: only the spare columns and
   // the rows of the blocks' padding tails have to be cleared (c3: 17 MB instead of 571 MB per prediction)
-  LPGP_HIP(hipMemsetAsync(r->v + (size_t)r->ld * m, 0, (size_t)r->ld * (r->m_pad - m) * sizeof(double), ctx->s_main));
-  for (const auto& b : mat->blocks)
-    if (b.pn > b.n)
-      LPGP_HIP(hipMemset2DAsync(r->v + b.poff + b.n, (size_t)r->ld * sizeof(double), 0, (size_t)(b.pn - b.n) * sizeof(double),
-                                (size_t)m, ctx->s_main));
+  {
+    RhsPadJobs jb;
+    jb.nj = 0;
+    int spare = 1;
+    int64_t work = r->ld * (r->m_pad - m);
+    auto flush = [&]() {
+      const int64_t wgs = (work + 2047) / 2048;
+      hipLaunchKernelGGL(rhs_pad_kernel, dim3((unsigned)(wgs < 1 ? 1 : (wgs > 2048 ? 2048 : wgs)), (unsigned)(jb.nj + spare)), dim3(256), 0, ctx->s_main,
+                         r->v, r->ld, m, r->m_pad, jb, spare);
+      jb.nj = 0;
+      spare = 0;
+      work = 0;
+    };
+    for (const auto& b : mat->blocks)
+      if (b.pn > b.n) {
+        jb.row0[jb.nj] = b.poff + b.n;
+        jb.nr[jb.nj] = (int32_t)(b.pn - b.n);
+        ++jb.nj;
+        work = std::max(work, (int64_t)(b.pn - b.n) * m);
+        if (jb.nj == RHS_PAD_JOBS) flush();
+      }
+    if (jb.nj > 0 || spare) flush();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("lpgp_rhs_create: %s", hipGetErrorString(e));
+      pool_free(ctx, r->v, (size_t)r->ld * r->m_pad * sizeof(double));
+      delete r;
+      return -1;
+    }
+  }
   r->assembled.assign(mat->blocks.size(), 0);
   ++ctx->live_mats;
   *out = r;
@@ -1492,7 +1647,11 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
   if (rc != 0) return rc;
   rc = rhs_clear_unassembled(ctx, mat, K);
   if (rc != 0) return rc;
-  std::vector<double> h((size_t)m), h2;
+  // results come back through pinned staging: the copy is asynchronous (the one wait polls, so that a failed peer of a
+  // multi-GPU job cannot block this rank inside a copy) and mean + variance are ONE copy, not two blocking round trips
+  rc = ensure_stage(ctx, 2 * K->m_pad);
+  if (rc != 0) return rc;
+  double* const hs = ctx->h_stage;
   // Mean and variance together: the variance needs V = L^{-1} K_Xx anyway, and
   //   K_xX G^{-1} r = V^T z  with  z = L^{-1} r,
   // so no representer weights are needed: the residual rides through the blocked solve as
@@ -1506,10 +1665,9 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
     hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                        (const double*)mat->w, ctx->d_tmp);
     LPGP_HIP(hipGetLastError());
+    LPGP_HIP(hipMemcpyAsync(hs, ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
     LPGP_TRY(sync_stream(ctx, ctx->s_main));
-    LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-    LPGP_TRY(sync_stream(ctx, ctx->s_main));
-    for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h[j];
+    for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + hs[j];
   }
   if (var_host) {
     LPGP_CHECK(kxx_host != nullptr, "lpgp_predict: kxx_host required for the variance");
@@ -1523,22 +1681,18 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
       hipLaunchKernelGGL(col_reduce2_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                          (const double*)zcol, ctx->d_tmp, ctx->d_tmp + K->m_pad);
       LPGP_HIP(hipGetLastError());
-      h2.resize((size_t)m);
+      LPGP_HIP(hipMemcpyAsync(hs, ctx->d_tmp, (size_t)(K->m_pad + m) * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
       LPGP_TRY(sync_stream(ctx, ctx->s_main));
-      LPGP_HIP(hipMemcpyAsync(h2.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-      LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp + K->m_pad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost,
-                              ctx->s_main));
-      LPGP_TRY(sync_stream(ctx, ctx->s_main));
-      for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h2[j];
+      for (int64_t j = 0; j < m; ++j) mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + hs[j];
+      for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - hs[K->m_pad + j];
     } else {
       hipLaunchKernelGGL(col_reduce_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn,
                          (const double*)nullptr, ctx->d_tmp);
       LPGP_HIP(hipGetLastError());
+      LPGP_HIP(hipMemcpyAsync(hs, ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
       LPGP_TRY(sync_stream(ctx, ctx->s_main));
-      LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-      LPGP_TRY(sync_stream(ctx, ctx->s_main));
+      for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - hs[j];
     }
-    for (int64_t j = 0; j < m; ++j) var_host[j] = kxx_host[j] - h[j];
   }
   return 0;
 }
@@ -1554,6 +1708,8 @@ int lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* 
   const int64_t m = K->m;
   int rc = ensure_tmp(ctx, 2 * K->m_pad);
   if (rc != 0) return rc;
+  rc = ensure_stage(ctx, 2 * K->m_pad);
+  if (rc != 0) return rc;
   rc = rhs_clear_unassembled(ctx, mat, K);
   if (rc != 0) return rc;
   double* zcol = K->v + (int64_t)m * K->ld;             // the residual rides as the spare column: z = L^{-1} r, mean = V^T z
@@ -1567,17 +1723,25 @@ int lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* 
     mat->unchecked = 1;
     mat->has_w = 0;
   }
+  mat->status_known = 0;
   hipLaunchKernelGGL(col_reduce2_kernel, dim3((unsigned)m), dim3(256), 0, ctx->s_main, K->v, K->ld, mat->pn, (const double*)zcol, ctx->d_tmp,
                      ctx->d_tmp + K->m_pad);
   LPGP_HIP(hipGetLastError());
-  std::vector<double> h((size_t)m), h2((size_t)m);
+  // mean, variance and the status word of the factorisation come back together: two asynchronous copies into pinned memory,
+  // ONE wait (until round 5: two blocking copies into pageable memory here and a third in lpgp_mat_check, ~25 us each --
+  // a tenth of a step of the reference's own problem sizes)
+  double* const hs = ctx->h_stage;
+  int* const hinfo = ctx->h_info_pinned + 4;
+  LPGP_HIP(hipMemcpyAsync(hs, ctx->d_tmp, (size_t)(K->m_pad + m) * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
+  LPGP_HIP(hipMemcpyAsync(hinfo, mat->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
   LPGP_TRY(sync_stream(ctx, ctx->s_main));
-  LPGP_HIP(hipMemcpyAsync(h2.data(), ctx->d_tmp, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-  LPGP_HIP(hipMemcpyAsync(h.data(), ctx->d_tmp + K->m_pad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-  LPGP_TRY(sync_stream(ctx, ctx->s_main));
+  if (mat->unchecked) {
+    mat->status_value = *hinfo;
+    mat->status_known = 1;
+  }
   for (int64_t j = 0; j < m; ++j) {
-    mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + h2[j];
-    var_host[j] = kxx_host[j] - h[j];
+    mean_host[j] = (prior_mean_host ? prior_mean_host[j] : 0.0) + hs[j];
+    var_host[j] = kxx_host[j] - hs[K->m_pad + j];
   }
   return 0;
 }

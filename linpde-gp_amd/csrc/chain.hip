@@ -95,7 +95,11 @@ __device__ __forceinline__ int* ch_U(const ChainArgs& g, int k) { return g.slot 
 
 // ---- rows: the fused panel chain of solve_panel.h (NT = 4, 32 rows per workgroup, row form) with hand-overs ----
 // tr: tile of the diagonal block the rows lie in (1..3), or 4 for rows below it; row_rel: first row relative to the block's first
-__device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr, const int64_t row_rel, double* smem) {
+// base / lane_step / cstep: element (workgroup-local row i, panel column c) of X at base[i * lane_step + c * cstep] -- rows of the
+// matrix: (g.a + first row, 1, g.ld); columns of a right-hand side V (X = V^T, the forward substitution's panel step): (V + first
+// column * ldv, ldv, 1)
+__device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr, double* base, const int64_t lane_step, const int64_t cstep,
+                                                double* smem) {
   constexpr int NT = 4, RG = 2;
   constexpr PsvSched<NT, 0> SCH = psv_make_sched<NT, 0>(4 / RG);
   static_assert(psv_sched_ok<NT, RG, 0>(), "resident chain: broken stage schedule");
@@ -152,8 +156,7 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
 
   // fragments: fragment (t, q) = element (row, panel column 128 t + 4 (cc + 4 q) + lj)
   double a[NT][8], x[8];
-  double* const pbase = g.a + row_rel + (rg * 16 + li) + (int64_t)(4 * cc + lj) * g.ld;
-  const int64_t cstep = g.ld;
+  double* const pbase = base + (int64_t)(rg * 16 + li) * lane_step + (int64_t)(4 * cc + lj) * cstep;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -294,10 +297,21 @@ __global__ __launch_bounds__(512, 1) void panel_chain_kernel(ChainArgs g) {
   }
   if (b <= 12) {
     const int tr = 1 + (b - 1) / 4, w = (b - 1) & 3;
-    chain_rows_role(g, tr, (int64_t)tr * TILE + 32 * w, sm);
+    chain_rows_role(g, tr, g.a + (int64_t)tr * TILE + 32 * w, 1, g.ld, sm);
   } else {
-    chain_rows_role(g, 4, (int64_t)4 * TILE + 32 * (int64_t)(b - 13), sm);
+    chain_rows_role(g, 4, g.a + (int64_t)4 * TILE + 32 * (int64_t)(b - 13), 1, g.ld, sm);
   }
+}
+
+// The panel step of the forward substitution that rides inside the factorisation (potrf.hip: ride_panel), for a panel the
+// resident chain factors: V[panel rows, 32 columns per workgroup] <- L_KK^{-1} V, the chain of panel_solve_kernel<4, 2, true> with
+// the hand-overs of the rows BELOW the block -- it follows the factor workgroup tile by tile through the SAME flags instead of
+// waiting for the whole chain kernel, so it ends one tile solve (~15 us) after the chain does, not one launch and a whole panel
+// chain (12 + 60 us) after it: the tail of every step of a small problem (N_tot = 1 152: 1.33 ms per step, two such panels).
+// Launched AFTER its chain kernel in host order, on the substitution's stream; reads the flags only.
+__global__ __launch_bounds__(512, 1) void panel_chain_v_kernel(ChainArgs g, double* V, int64_t ldv) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  chain_rows_role(g, 4, V + (int64_t)blockIdx.x * 32 * ldv, ldv, 1, sm);
 }
 
 // The chain of panel [p0, p0 + 4) of the padded matrix, all rows down to tile T, on `stream`.
@@ -313,6 +327,8 @@ int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0,
   g.linv = mat->linv + (int64_t)p0 * TILE * TILE;
   const int64_t n = ctx->chain_launches++;
   g.slot = ctx->d_chain_flags + (n % CH_SLOTS) * CH_SLOT_INTS;
+  ctx->chain_last_slot = g.slot;
+  ctx->chain_last_p0 = p0;
   g.slot_clear = ctx->d_chain_flags + ((n + CH_SLOTS / 2) % CH_SLOTS) * CH_SLOT_INTS;
   g.info = d_info;
   g.info_base = p0 * TILE;
@@ -323,6 +339,29 @@ int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0,
   // algorithmic flops of the panel's chain: four tile Choleskys + the triangular solve of the rows below against the block
   prof_begin(ctx, stream, LPGP_K_PANEL, 4.0 * TILE * TILE * TILE / 3.0 + (double)(T - p0 - 1) * TILE * 512.0 * 512.0 / 2.0, 0.0);
   hipLaunchKernelGGL(panel_chain_kernel, dim3((unsigned)(13 + g.n_below)), dim3(512), shmem, stream, g);
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// V: first row of the panel's rows of the right-hand side (rows p0 * 128 ...), `cols` columns (a multiple of 128); the chain of
+// panel p0 must be the LAST one launched (launch_panel_chain), its flag slot is the one this launch follows.
+int launch_panel_chain_v(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, double* V, int64_t ldv, int64_t cols, int* d_info) {
+  LPGP_CHECK(ctx->chain_last_slot && ctx->chain_last_p0 == p0, "resident chain: no chain launch of panel %d to follow", p0);
+  const int64_t ld = mat->cap;
+  ChainArgs g;
+  g.a = mat->a + (int64_t)p0 * TILE * (ld + 1);
+  g.ld = ld;
+  g.linv = mat->linv + (int64_t)p0 * TILE * TILE;
+  g.slot = ctx->chain_last_slot;
+  g.slot_clear = nullptr;
+  g.info = d_info;
+  g.info_base = p0 * TILE;
+  g.n_below = 0;
+  const size_t shmem = (size_t)(2 * 32 * 64 + TSV_RING) * sizeof(double);          // the row role's fragment image + stage ring
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_chain_v_kernel), shmem));
+  prof_begin(ctx, stream, LPGP_K_PANEL, (double)cols * 512.0 * 512.0, 0.0);
+  hipLaunchKernelGGL(panel_chain_v_kernel, dim3((unsigned)(cols / 32)), dim3(512), shmem, stream, g, V, ldv);
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;

@@ -101,6 +101,9 @@ struct lpgp_ctx {
   int chain_resident_max_rows = 32;
   int* d_chain_flags = nullptr;        // ring of flag slots (zeroed; a launch zeroes the slot half a ring ahead)
   int64_t chain_launches = 0;
+  int* chain_last_slot = nullptr;      // flag slot and panel of the last chain launch: the substitution's panel step that follows it
+  int chain_last_p0 = -1;              // through the same flags (panel_chain_v_kernel) ...
+  int ride_vchain_max_wgs = 96;        // ... for right-hand sides of at most this many 32-column workgroups (they wait ON the chip, one per CU; 0: never)
   int ride_same_stream_max_tiles = 0;  // ... on the panel stream itself for factors of at most this many tile rows
   int64_t ride_outer_rows = 2048;      // ... two-level form: rows below an outer block of this many rows are updated once per block (0: every panel updates all rows below) ...
   int ride_outer_min_tiles = 64;       // ... from this many tile rows on
@@ -152,6 +155,11 @@ struct lpgp_ctx {
   int* h_info_pinned = nullptr;    // pinned mirror (multi-GPU: a device-to-host copy into pageable memory would BLOCK behind a collective that waits for a dead peer)
   double* d_tmp = nullptr;         // small scratch (vectors)
   int64_t tmp_cap = 0;
+  double* h_stage = nullptr;       // pinned host staging for the results of a prediction: ONE asynchronous device-to-host copy and
+  double* h_stage_r = nullptr;     // ... and for the residual on its way up (lpgp_mat_set_residual: no wait at all)
+  int64_t stage_r_cap = 0;
+  hipEvent_t ev_stage_r = nullptr;
+  int64_t stage_cap = 0;           // one wait per call (a copy into pageable memory is a blocking round trip of its own, ~25 us each)
   // caching allocator: freed device buffers are kept for reuse (a hipMalloc/hipFree pair
   // of a multi-GB Gram matrix costs more than the factorisation of a small problem)
   struct PoolBuf { void* p; size_t bytes; };
@@ -242,6 +250,8 @@ struct lpgp_mat {
   int has_r;                       // residual resident (lpgp_mat_set_residual)
   int* d_status = nullptr;         // device word: first non-positive pivot of the factorisations enqueued since the last lpgp_mat_check (sticky)
   int unchecked = 0;               // a factorisation was enqueued (lpgp_potrf_enqueue) and its status not read yet
+  int status_known = 0;            // lpgp_potrf_predict read the status word back with its results: lpgp_mat_check needs no copy
+  int status_value = 0;
   double* r() const { return w + cap; }
 };
 
@@ -354,6 +364,7 @@ int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx,
 
 // chain.hip: the whole chain of panel [p0, p0 + 4) (rows down to tile T) in one launch
 int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info);
+int launch_panel_chain_v(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, double* V, int64_t ldv, int64_t cols, int* d_info);
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);
 int launch_potrf_tile(lpgp_ctx* ctx, hipStream_t stream, double* a, int64_t lda, double* linv,

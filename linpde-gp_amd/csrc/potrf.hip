@@ -109,11 +109,13 @@ struct Ride {
   int blk_q0 = 0;            // first tile row of the outer block the steps are in
   bool open = true;
   std::vector<std::pair<int, int>> held;
+  int64_t chain_launches0 = 0;   // resident chain launches before this factorisation (flag slots are recycled half a ring later)
 };
-static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first);
+static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first, bool resident = false);
 
 // panel [p0, p1) of the factor is final on the panel stream from here on: enqueue its substitution step(s)
-static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool old_panel = false) {
+// (resident: the panel's chain was the resident kernel, launched last on the panel stream -- the step may follow it flag by flag)
+static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool old_panel = false, bool resident = false) {
   // (steps of OLD panels -- a block append pushes its rows through them before it factors anything -- may pass the gate: they fill
   //  the start-up of the append, the first panel chain on an otherwise idle chip; ride_old_ungated)
   if (!rd->open && old_panel && ctx->ride_old_ungated && rd->held.empty()) return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
@@ -128,16 +130,27 @@ static int ride_panel(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride*
       LPGP_TRY(ride_panel_now(ctx, mat, T, h.first, h.second, rd, first));
       first = false;
     }
+    const bool none_held = rd->held.empty();
     rd->held.clear();
-    return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
+    return ride_panel_now(ctx, mat, T, p0, p1, rd, true, resident && none_held);
   }
-  return ride_panel_now(ctx, mat, T, p0, p1, rd, true);
+  return ride_panel_now(ctx, mat, T, p0, p1, rd, true, resident);
 }
 
-static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first) {
+static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, Ride* rd, bool sync_first, bool resident) {
   const int64_t ld = mat->cap, tb = TILE;
   const double* a = mat->a;
   const bool two = rd->stream2 != nullptr && rd->stream2 != rd->stream && rd->mtl >= 8;
+  // A panel of the RESIDENT chain, a right-hand side of few columns: the panel step does not wait for the chain kernel to end
+  // -- it follows the factor workgroup through the chain's own flags (chain.hip: panel_chain_v_kernel) and ends one tile solve
+  // after it.  Its workgroups wait on the chip, one per CU, hence the bound on their number; the flag slot is recycled 32 chain
+  // launches later, hence the bound on the resident launches of one factorisation (the substitution's stream may lag them).
+  // (the LAST panel has no update beside it that the waiting workgroups could be in the way of: any width that fits the chip)
+  const bool vchain = resident && sync_first && !two && ctx->fused_solve && p1 - p0 == 4 && ctx->ride_vchain_max_wgs > 0 &&
+                      (rd->mtl * 4 <= ctx->ride_vchain_max_wgs || (p1 == T && rd->mtl * 4 <= 224)) && ctx->chain_last_p0 == p0 &&
+                      ctx->chain_launches - rd->chain_launches0 <= 24;
+  if (vchain)
+    LPGP_TRY(launch_panel_chain_v(ctx, rd->stream, mat, p0, rd->v + (int64_t)p0 * tb, rd->ldv, (int64_t)rd->mtl * tb, ctx->d_info_cur));
   if (sync_first && (rd->stream != ctx->s_main || two)) {
     hipEvent_t ev = rd->ev[rd->it++ & 1];
     LPGP_HIP(hipEventRecord(ev, ctx->s_main));
@@ -167,7 +180,9 @@ static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, R
       double* vh = rd->v + (int64_t)c0 * tb * rd->ldv;
       const int mtl = c1 - c0;
       double* Vq = vh + (int64_t)q0 * tb;
-      if (ctx->fused_solve) {
+      if (vchain) {
+        // (done by panel_chain_v_kernel above)
+      } else if (ctx->fused_solve) {
         LPGP_TRY(launch_trsv_panel(ctx, sV, Vq, rd->ldv, mat->linv + (int64_t)q0 * tb * tb, a + (int64_t)q0 * tb * (ld + 1), ld, q1 - q0, mtl,
                                    LPGP_K_PANEL));
       } else {
@@ -249,7 +264,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
                                LPGP_K_SYRK_PANEL));
       }
     }
-    if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride));          // columns [p0, p1) are final: their substitution step follows on the ride stream
+    if (ride) LPGP_TRY(ride_panel(ctx, mat, T, p0, p1, ride, false, resident));          // columns [p0, p1) are final: their substitution step follows on the ride stream
     if (p1 >= cl) break;
     const int K = (p1 - p0) * TILE;
     const double* P = a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld;      // panel rows below
@@ -329,6 +344,7 @@ int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, i
 int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t T, double* v, int64_t ldv, int64_t m_pad) {
   Ride rd;
   rd.v = v; rd.ldv = ldv; rd.mtl = (int)(m_pad / TILE);
+  rd.chain_launches0 = ctx->chain_launches;
   // the ride streams: update streams that are idle during a factorisation of this size (HIP multiplexes a process's
   // streams over four hardware queues: no new stream).  ride_stream = first + 8 * second (second 7: none):
   // 0 s_outer (masked like s_upd), 1 s_upd_all (unmasked), 2 s_upd_narrow, 3 the panel stream itself, 4 s_upd

@@ -224,11 +224,11 @@ class _DeviceState:
     view (`lpgp_mat_set_view`), so earlier objects of the chain stay usable; conditioning an object
     that has already been extended (branching) continues on a copy of its part of the factor."""
 
-    def __init__(self, ctx, mat=None, blocks=()):
+    def __init__(self, ctx, mat=None, blocks=(), capacity_hint=0):
         from .. import config
 
         self.ctx = ctx
-        self.mat = mat if mat is not None else _engine.GramMatrix(ctx, capacity_hint=config.gram_capacity_hint)
+        self.mat = mat if mat is not None else _engine.GramMatrix(ctx, capacity_hint=config.gram_capacity_hint or capacity_hint)
         self.view = None             # number of blocks the device-resident weights / residual belong to
         self.weights_key = None
         self.residual_key = None
@@ -288,11 +288,17 @@ class _DeviceState:
             self.residual_key = None
 
 
+_ROWS_SEEN_MAX = 4096        # (a hint only, and only where re-allocation matters: 128 MB; beyond, a copy is noise against the O(n^3) work)
+
+
 class ConditionalGaussianProcess(GaussianProcess):
     @classmethod
     def from_observations(cls, prior: GaussianProcess, Y, X=None, *, L=None, b=None):
         Yf, Lf, bf, Xpts, coeffs, pred_mean = cls._preprocess_observations(prior=prior, Y=Y, X=X, L=L, b=b)
-        state = _DeviceState(_engine.default_context())
+        # (room for the longest chain this prior has been conditioned into so far: the same model is typically conditioned again
+        #  and again -- new data, new hyperparameters' worth of right-hand sides -- and a matrix that outgrows its allocation in the
+        #  middle of a chain is re-allocated and copied: eight launches of a 1 152-row problem's sixty)
+        state = _DeviceState(_engine.default_context(), capacity_hint=getattr(prior, "_rows_seen", 0))
         block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, Lf.device_points(state.ctx), pred_mean)
         return cls._extend(prior, state, (), block)
 
@@ -356,6 +362,9 @@ class ConditionalGaussianProcess(GaussianProcess):
             raise np.linalg.LinAlgError(
                 f"{info}-th leading minor of the (padded) Gram matrix is not positive definite")
         state.blocks.append(new_block)
+        rows = sum(-(-k // 128) * 128 for k in mat.block_sizes)
+        if getattr(prior, "_rows_seen", 0) < rows <= _ROWS_SEEN_MAX:
+            prior._rows_seen = rows
         state.pending = state.pending or lazy
         state.deferred_rows = (state.deferred_rows if state.deferred else 0) + n if lazy else 0
         state.deferred = lazy

@@ -107,21 +107,21 @@ class PivotedCholeskyPreconditioner:
         n = G.n
         d = G.diag().copy()
         d0 = float(np.max(d))
-        rows, piv = [], []
-        for _ in range(min(rank, n)):
+        L = np.zeros((min(rank, n), n))
+        k = 0
+        while k < L.shape[0]:
             p = int(np.argmax(d))
             if d[p] <= rtol * d0:
                 break
             r = G.row(p)
-            for lk, pk in zip(rows, piv):
-                r = r - lk[p] * lk
-            lk = r / np.sqrt(d[p])
-            rows.append(lk)
-            piv.append(p)
-            d = np.maximum(d - lk * lk, 0.0)
+            if k:
+                r = r - L[:k, p] @ L[:k]          # the part of row p the earlier pivots already explain
+            L[k] = r / np.sqrt(d[p])
+            d = np.maximum(d - L[k] * L[k], 0.0)
             d[p] = 0.0
-        self.L = np.array(rows) if rows else np.zeros((0, n))
-        self.rank = self.L.shape[0]
+            k += 1
+        self.L = L[:k]
+        self.rank = k
         self.delta = max(float(np.mean(d)), 1e-12 * d0)
         if self.rank:
             S = self.delta * np.eye(self.rank) + self.L @ self.L.T

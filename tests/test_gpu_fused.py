@@ -273,15 +273,83 @@ def test_batched_block_rows_are_bit_identical():
             ctx.set_option("asm_batch", batch)
             r2 = np.random.default_rng(8)
             u = prior
-            for k in range(10):
+            for k in range(17):                  # (17 ragged blocks: also more padding tails than one launch of rhs_pad_kernel takes)
                 X = r2.uniform(-1, 1, (17 + 11 * k, 1))
-                u = u.condition_on_observations(np.sin(3 * X[:, 0]), X, b=lp.randvars.Normal(np.zeros(X.shape[0]), 1e-3 * np.eye(X.shape[0])))
+                # noise: sigma^2 I or a vector -- the block's identity tail and its noise are one launch (finish_block_kernel)
+                b = [lp.randvars.Normal(np.zeros(X.shape[0]), 1e-3 * np.eye(X.shape[0])),
+                     lp.randvars.Normal(np.zeros(X.shape[0]), np.diag(1e-3 * (1.0 + r2.uniform(0, 1, X.shape[0]))))][k % 2]
+                u = u.condition_on_observations(np.sin(3 * X[:, 0]), X, b=b)
             res[batch] = u.predict(np.linspace(-1, 1, 50)[:, None])
             del u
     finally:
         ctx.set_option("asm_batch", saved)
     np.testing.assert_array_equal(res[1][0], res[0][0])
     np.testing.assert_array_equal(res[1][1], res[0][1])
+    assert prior._rows_seen == sum(-(-(17 + 11 * k) // 128) * 128 for k in range(17))        # (the next chain from this prior starts with room for it)
+
+
+@pytest.mark.parametrize("make", [lambda P: P.poisson_1d(512, n_bdry_repeats=16, noise_var=1e-4, m=256),        # one resident panel behind an old one
+                                  lambda P: P.poisson_2d(n_side=32, m_side=16),                                # two resident panels
+                                  lambda P: P.poisson_2d(n_side=40, n_bdry=40, m_side=24),                     # panels off the block grid, 640 columns
+                                  lambda P: P.heat_reference()])                                               # 2 560 columns: 80 waiting workgroups
+def test_substitution_follows_the_resident_chain_through_its_flags(lazy, make):
+    """Round 5: for a panel the resident chain factors, the substitution's panel step does not wait for the chain kernel to end: it
+    follows the factor workgroup through the chain's flags (`panel_chain_v_kernel`, option `ride_vchain_max_wgs`).  Same products in
+    the same order as the panel step it replaces: the prediction agrees with the one behind the event (option 0) to rounding, and
+    with the oracle; the factor is untouched by it."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _engine, problems
+    ctx = _engine.default_context()
+    wl = make(problems)
+    saved = ctx.get_option("ride_vchain_max_wgs")
+    out = {}
+    try:
+        for wgs in (96, 0):
+            ctx.set_option("ride_vchain_max_wgs", wgs)
+            u, m, v = problems.condition_and_predict(wl)
+            out[wgs] = (m, v, u.gram.cholesky())
+            del u
+    finally:
+        ctx.set_option("ride_vchain_max_wgs", saved)
+    np.testing.assert_array_equal(out[96][2], out[0][2])
+    sm, sv = np.max(np.abs(out[0][0])), np.max(np.abs(out[0][1]))
+    assert np.max(np.abs(out[96][0] - out[0][0])) <= 1e-12 * sm and np.max(np.abs(out[96][1] - out[0][1])) <= 1e-12 * sv + 1e-15
+    ref = owl.run(wl)
+    assert_posterior_close(out[96][0], out[96][1], ref["mean"], ref["var"])
+
+
+def test_misuse_of_the_conditioning_entry_point_rolls_the_block_back():
+    """`lpgp_mat_condition` with a row entry whose point set does not match the block it names (a C-API misuse the host package
+    never commits): the call fails AND the block it had declared is dropped again, on the batched row path like on the
+    per-entry one -- the matrix is as before and the same conditioning with the right points then succeeds."""
+    import linpde_gp_amd as lp
+    from linpde_gp_amd import _engine, _lib
+    from linpde_gp_amd.randprocs._gaussian_process import _lowered
+    ctx = _engine.default_context()
+    cf = lp.randprocs.covfuncs
+    k = cf.Matern((1,), nu=2.5, lengthscales=0.5)
+    rng = np.random.default_rng(17)
+    X1, X2, Xbad = rng.uniform(-1, 1, (40, 1)), rng.uniform(-1, 1, (25, 1)), rng.uniform(-1, 1, (31, 1))
+    ident = {(0,): 1.0}
+    kd = _lowered(k, ident, ident)
+    saved = ctx.get_option("asm_batch")
+    try:
+        for batch in (1, 0):
+            ctx.set_option("asm_batch", batch)
+            mat = _engine.GramMatrix(ctx)
+            P1, P2, Pbad = (_engine.Points(ctx, X) for X in (X1, X2, Xbad))
+            assert mat.condition(40, P1, [(kd, None)], noise_scalar=1e-2, lazy=0) == 0
+            size = (mat.n, mat.num_blocks_total, list(mat.block_sizes))
+            with pytest.raises(_lib.LpgpError, match="shape mismatch|size"):
+                mat.condition(25, P2, [(kd, Pbad), (kd, None)], noise_scalar=1e-2, lazy=0)        # 31 points named for a block of 40
+            assert (mat.n, mat.num_blocks_total, list(mat.block_sizes)) == size
+            assert mat.condition(25, P2, [(kd, P1), (kd, None)], noise_scalar=1e-2, lazy=0) == 0
+            assert mat.n == 65
+            G = np.asarray(k.matrix(np.vstack([X1, X2]))) + 1e-2 * np.eye(65)
+            L = np.tril(mat.todense("factor"))
+            assert np.max(np.abs(L @ L.T - G)) <= 1e-13 * np.max(np.abs(G))
+    finally:
+        ctx.set_option("asm_batch", saved)
 
 
 def test_kronecker_expansion_with_16_byte_stores_is_bit_identical():
