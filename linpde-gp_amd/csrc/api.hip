@@ -498,6 +498,12 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   if (ctx->d_chain_flags) (void)hipFree(ctx->d_chain_flags);
   (void)hipHostFree(ctx->h_info_pinned);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (auto& b : ctx->pts_pool) (void)hipFree(b.p);
+  ctx->pts_pool.clear();
+  for (auto& sl : ctx->pts_ring) {
+    if (sl.h) (void)hipHostFree(sl.h);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   if (ctx->h_stage_r) (void)hipHostFree(ctx->h_stage_r);
   if (ctx->ev_stage_r) (void)hipEventDestroy(ctx->ev_stage_r);
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
@@ -841,19 +847,79 @@ int lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, l
   p->n = n;
   p->d = d;
   p->n_pad = round_up(n > 0 ? n : 1, 64);
-  std::vector<double> soa((size_t)p->n_pad * d, 0.0);
-  for (int64_t i = 0; i < n; ++i)
-    for (int j = 0; j < d; ++j) soa[(size_t)j * p->n_pad + i] = X_host[i * d + j];
-  LPGP_HIP(hipMalloc(&p->x, soa.size() * sizeof(double)));
-  LPGP_HIP(hipMemcpy(p->x, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+  const size_t bytes = (size_t)p->n_pad * d * sizeof(double);
+  const bool recycle = !ctx->distributed() && !ctx->single_stream;
+  // the buffer: a recycled one of about the size (lpgp_internal.h: pts_pool), else a new one
+  p->x = nullptr;
+  if (recycle) {
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pts_pool.size(); ++i) {
+      const auto& b = ctx->pts_pool[i];
+      if (b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (best < 0 || b.bytes < ctx->pts_pool[best].bytes)) best = i;
+    }
+    if (best >= 0) {
+      p->x = (double*)ctx->pts_pool[best].p;
+      p->bytes = ctx->pts_pool[best].bytes;
+      ctx->pts_pool.erase(ctx->pts_pool.begin() + best);
+    }
+  }
+  if (!p->x) {
+    hipError_t e = hipMalloc(&p->x, bytes);
+    if (e != hipSuccess) {
+      set_error("lpgp_pts_create: device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+      delete p;
+      return -1;
+    }
+    p->bytes = bytes;
+  }
+  auto fill = [&](double* soa) {
+    std::memset(soa, 0, bytes);
+    for (int64_t i = 0; i < n; ++i)
+      for (int j = 0; j < d; ++j) soa[(size_t)j * p->n_pad + i] = X_host[i * d + j];
+  };
+  hipError_t e = hipSuccess;
+  if (recycle && bytes <= lpgp_ctx::PTS_SLOT_BYTES) {
+    // small: through the next pinned slot, on the panel stream, no wait (the slot is reused after its copy has completed)
+    lpgp_ctx::PtsSlot& sl = ctx->pts_ring[ctx->pts_next];
+    ctx->pts_next = (ctx->pts_next + 1) % lpgp_ctx::PTS_SLOTS;
+    if (!sl.h) {
+      e = hipHostMalloc(&sl.h, lpgp_ctx::PTS_SLOT_BYTES, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+    } else if (sl.used) {
+      e = hipEventSynchronize(sl.done);
+    }
+    if (e == hipSuccess) {
+      fill((double*)sl.h);
+      e = hipMemcpyAsync(p->x, sl.h, bytes, hipMemcpyHostToDevice, ctx->s_main);
+    }
+    if (e == hipSuccess) e = hipEventRecord(sl.done, ctx->s_main);
+    if (e == hipSuccess) sl.used = true;
+  } else {
+    std::vector<double> soa((size_t)p->n_pad * d);
+    fill(soa.data());
+    // (a recycled buffer may still be read by kernels on the panel stream: the copy is ordered behind them there)
+    e = hipMemcpyAsync(p->x, soa.data(), bytes, hipMemcpyHostToDevice, ctx->s_main);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_main);
+  }
+  if (e != hipSuccess) {
+    set_error("lpgp_pts_create: upload: %s", hipGetErrorString(e));
+    (void)hipFree(p->x);
+    delete p;
+    return -1;
+  }
   *out = p;
   return 0;
 }
 
 int lpgp_pts_destroy(lpgp_pts* p) {
   if (!p) return 0;
-  (void)hipSetDevice(p->ctx->device);
-  (void)hipFree(p->x);
+  lpgp_ctx* ctx = p->ctx;
+  (void)hipSetDevice(ctx->device);
+  // recycled: whatever still reads it runs on the panel stream, where the next owner's upload is ordered behind it
+  if (!ctx->distributed() && !ctx->single_stream && ctx->pts_pool.size() < 32 && p->bytes <= ((size_t)4 << 20))
+    ctx->pts_pool.push_back({p->x, p->bytes});
+  else
+    (void)hipFree(p->x);
   delete p;
   return 0;
 }

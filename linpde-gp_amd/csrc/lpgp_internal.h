@@ -164,6 +164,16 @@ struct lpgp_ctx {
   // of a multi-GB Gram matrix costs more than the factorisation of a small problem)
   struct PoolBuf { void* p; size_t bytes; };
   std::vector<PoolBuf> pool;
+  // Point sets handed over per call (the reference's calling convention: NumPy arrays) come and go with every step of a small
+  // problem: their device buffers are recycled here (hipMalloc + hipFree cost ~50 us a pair, and hipFree waits for the device),
+  // their uploads go through a ring of pinned slots on the panel stream -- where every kernel that reads a point set runs --
+  // without a wait (lpgp_pts_create / lpgp_pts_destroy; single GPU)
+  std::vector<PoolBuf> pts_pool;
+  static constexpr int PTS_SLOTS = 8;
+  static constexpr size_t PTS_SLOT_BYTES = 64 << 10;
+  struct PtsSlot { void* h = nullptr; hipEvent_t done = nullptr; bool used = false; };
+  PtsSlot pts_ring[PTS_SLOTS];
+  int pts_next = 0;
   // multi-GPU (one process per GPU): Pr x Pc process grid, rank = r * Pc + c; 2-D block-cyclic tiles
   int rank = 0, world = 1;
   int pr = 1, pc = 1;
@@ -222,6 +232,7 @@ struct lpgp_pts {
   int32_t d;
   double* x;                       // device, SoA: x[dim * n_pad + i]
   int64_t n_pad;
+  size_t bytes = 0;                // size of the allocation behind x
 };
 
 struct lpgp_block {

@@ -145,10 +145,11 @@ static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, R
   // -- it follows the factor workgroup through the chain's own flags (chain.hip: panel_chain_v_kernel) and ends one tile solve
   // after it.  Its workgroups wait on the chip, one per CU, hence the bound on their number; the flag slot is recycled 32 chain
   // launches later, hence the bound on the resident launches of one factorisation (the substitution's stream may lag them).
-  // (the LAST panel has no update beside it that the waiting workgroups could be in the way of: any width that fits the chip)
+  // (Wide right-hand sides stay behind the event: c3's 132 workgroups following the LAST panel -- no update beside it they could be
+  //  in the way of -- made the step 0.5 ms slower, 50.7-50.9 against 50.2-50.3: by then the substitution lags the chain anyway,
+  //  and 32 columns per workgroup is the slower panel step of the two when nothing is left to overlap with.)
   const bool vchain = resident && sync_first && !two && ctx->fused_solve && p1 - p0 == 4 && ctx->ride_vchain_max_wgs > 0 &&
-                      (rd->mtl * 4 <= ctx->ride_vchain_max_wgs || (p1 == T && rd->mtl * 4 <= 224)) && ctx->chain_last_p0 == p0 &&
-                      ctx->chain_launches - rd->chain_launches0 <= 24;
+                      rd->mtl * 4 <= ctx->ride_vchain_max_wgs && ctx->chain_last_p0 == p0 && ctx->chain_launches - rd->chain_launches0 <= 24;
   if (vchain)
     LPGP_TRY(launch_panel_chain_v(ctx, rd->stream, mat, p0, rd->v + (int64_t)p0 * tb, rd->ldv, (int64_t)rd->mtl * tb, ctx->d_info_cur));
   if (sync_first && (rd->stream != ctx->s_main || two)) {
@@ -501,9 +502,11 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
   if (ev_a1) LPGP_HIP(hipStreamWaitEvent(sP, ev_a1, 0));
   if (ev_b) LPGP_HIP(hipStreamWaitEvent(sP, ev_b, 0));
   if (!info) return 0;
-  int h_info = 0;
-  LPGP_HIP(hipMemcpyAsync(&h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
+  // (into pinned memory: a copy into pageable memory is staged and blocks twice; this wait is once per conditioning of the default mode)
+  int* const hp = ctx->h_info_pinned + 5;
+  LPGP_HIP(hipMemcpyAsync(hp, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
+  const int h_info = *hp;
   LPGP_CHECK(h_info >= 0, "resident panel chain: a hand-over between workgroups timed out (device status %d); set LPGP_CHAIN_RESIDENT=-1", h_info);
   *info = h_info;
   return 0;
