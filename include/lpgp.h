@@ -135,7 +135,10 @@ int  lpgp_dist_ipc_export(lpgp_ctx* ctx, int64_t window_bytes, char* handle64);
 int  lpgp_dist_init_ipc(lpgp_ctx* ctx, int32_t rank, int32_t world, const char* handles,
                         lpgp_host_exchange_fn fn, void* user);
 
-/* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) ----- */
+/* ---- point sets (X of `_EvaluationFunctional`, linfunctls/_evaluation.py:21-45) -----
+ * X_host is consumed when lpgp_pts_create returns.  On a single GPU the upload of a small set (<= 64 KB) is asynchronous on
+ * the panel stream (pinned staging ring), where every kernel that reads a point set runs, and lpgp_pts_destroy recycles the
+ * device buffer: the reference hands NumPy arrays over per call, a small problem's step creates and drops half a dozen sets. */
 int  lpgp_pts_create(lpgp_ctx* ctx, const double* X_host, int64_t n, int32_t d, lpgp_pts** out);
 int  lpgp_pts_destroy(lpgp_pts* pts);
 
@@ -265,11 +268,13 @@ int  lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host);
 /* ---- prediction: replaces `PriorPredictiveCrossCovariance._evaluate`
  *      (_conditional.py:140-153), `Mean._evaluate` (:193-197) and
  *      `CovarianceFunction._evaluate` (:223-231).                                       */
-/* STREAMS (for callers of the C API that keep work asynchronous): everything is ordered on the context's panel stream;
- * lpgp_mat_condition's noise upload and lpgp_mat_set_residual use an idle side stream ONLY while an enqueued
+/* STREAMS (for callers of the C API that keep work asynchronous): everything is ordered on the context's panel stream.
+ * lpgp_mat_set_residual (single GPU) copies r_host into pinned staging and enqueues the upload on the panel stream WITHOUT
+ * waiting for it -- r_host is consumed when it returns, every reader of the residual (lpgp_predict, lpgp_potrf_predict) is
+ * ordered behind the upload there.  lpgp_mat_condition's noise-vector upload uses an idle side stream ONLY while an enqueued
  * factorisation is in flight on the panel stream (`lpgp_potrf_enqueue` without `lpgp_mat_check` yet) -- then nothing else
- * can be reading the weights / residual buffer, because every entry point that reads it (lpgp_predict, lpgp_potrf_predict,
- * lpgp_solve_weights, lpgp_potrs) returns only after its device work has completed.                                  */
+ * can be reading the weights buffer it is staged in, because every entry point that reads it (lpgp_solve_weights, lpgp_potrs,
+ * lpgp_predict) returns only after its device work has completed.                                                     */
 int  lpgp_rhs_create(lpgp_ctx* ctx, const lpgp_mat* mat, int64_t m, lpgp_rhs** out);
 int  lpgp_rhs_destroy(lpgp_rhs* rhs);
 /* rows of block bi of K_Xx <- sum_g (kd[g])(X_obs, X_test)   (n_bi x m)                 */
@@ -303,9 +308,13 @@ int  lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K,
  * never on the factorisation's critical path (potrf.hip, `ride_panel`).  The algebra is `BlockMatrix2x2.L_A_inv_B`
  * (linops/_block.py:203-207) applied to the cross-covariance `PriorPredictiveCrossCovariance._evaluate`
  * (_conditional.py:140-153) panel by panel; the values are those of lpgp_potrf_enqueue + lpgp_predict, kernel for kernel.
- * The factorisation's status is NOT read: lpgp_mat_check afterwards (a Gram matrix that is not positive definite yields
- * a prediction computed on garbage, to be discarded).  If everything is factored already this is lpgp_predict.
- * Single GPU.                                                                                                       */
+ * The factorisation's status is not RETURNED here: lpgp_mat_check afterwards (a Gram matrix that is not positive definite
+ * yields a prediction computed on garbage, to be discarded) -- the status word travels back with mean and variance (one
+ * read-back into pinned memory, one wait), so that lpgp_mat_check costs no device round trip of its own.  If everything is
+ * factored already this is lpgp_predict.  Single GPU.
+ * For a panel the RESIDENT chain factors (chain.hip) and a right-hand side of at most 96 x 32 columns, the substitution's
+ * panel step follows the factor workgroup through the chain's device flags instead of waiting for the chain kernel
+ * (`panel_chain_v_kernel`; option `ride_vchain_max_wgs`, env LPGP_RIDE_VCHAIN, 0: off).                                */
 int  lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_mean_host,
                         const double* kxx_host, double* mean_host, double* var_host);
 /* V <- L^{-1} V  (forward substitution on all m columns)                                */

@@ -402,11 +402,13 @@ int lpgp_init(int device, lpgp_ctx** out) {
     LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_outer_a1[i], hipEventDisableTiming));
   }
   for (int i = 0; i < 4; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
+  LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_pre, hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_VCHAIN")) ctx->ride_vchain_max_wgs = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_VCHAIN_PRE")) ctx->ride_vchain_pre = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_ROWS")) ctx->ride_outer_rows = std::atol(e);
   if (const char* e = std::getenv("LPGP_RIDE_OUTER_MIN_TILES")) ctx->ride_outer_min_tiles = std::atoi(e);
@@ -482,6 +484,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
+  (void)hipEventDestroy(ctx->ev_chain_pre);
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);

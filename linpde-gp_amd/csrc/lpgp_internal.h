@@ -92,6 +92,8 @@ struct lpgp_ctx {
   int64_t nb_outer = 2048;             // far columns are updated once per nb_outer columns (0 or <= nb: every panel) ...
   int nb_outer_min_tiles = 192;        // ... while more than this many tile columns remain
   int reserve_narrow = 64;
+  hipEvent_t ev_chain_pre = nullptr;   // recorded on the panel stream right in front of a resident chain launch: a kernel that follows the chain through
+                                       // its flags (panel_chain_v_kernel) is not dispatched before the chain kernel itself can be
   hipEvent_t ev_ride[4] = {nullptr, nullptr, nullptr, nullptr};   // ride-along substitution (potrf_predict_blocked): panel hand-overs [0, 1], fork / join [2, 3]
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
   int ride_old_ungated = 1;            // ... the steps of old panels (block append) are not held back by the gate
@@ -103,6 +105,7 @@ struct lpgp_ctx {
   int64_t chain_launches = 0;
   int* chain_last_slot = nullptr;      // flag slot and panel of the last chain launch: the substitution's panel step that follows it
   int chain_last_p0 = -1;              // through the same flags (panel_chain_v_kernel) ...
+  int ride_vchain_pre = 1;             // ... dispatched only once the chain kernel itself can be (ev_chain_pre)
   int ride_vchain_max_wgs = 96;        // ... for right-hand sides of at most this many 32-column workgroups (they wait ON the chip, one per CU; 0: never)
   int ride_same_stream_max_tiles = 0;  // ... on the panel stream itself for factors of at most this many tile rows
   int64_t ride_outer_rows = 2048;      // ... two-level form: rows below an outer block of this many rows are updated once per block (0: every panel updates all rows below) ...

@@ -150,6 +150,10 @@ static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, R
   //  and 32 columns per workgroup is the slower panel step of the two when nothing is left to overlap with.)
   const bool vchain = resident && sync_first && !two && ctx->fused_solve && p1 - p0 == 4 && ctx->ride_vchain_max_wgs > 0 &&
                       rd->mtl * 4 <= ctx->ride_vchain_max_wgs && ctx->chain_last_p0 == p0 && ctx->chain_launches - rd->chain_launches0 <= 24;
+  // ... and are not dispatched before the chain kernel itself can be (everything in front of it on the panel stream is done):
+  // they would only hold their CUs waiting.  (Under a profiler that SERIALISES kernels -- rocprofv3 --pmc -- a follower that is
+  // picked before its chain kernel waits out its poll limit and the step fails with a negative status: LPGP_RIDE_VCHAIN=0 there.)
+  if (vchain && rd->stream != ctx->s_main && ctx->ride_vchain_pre) LPGP_HIP(hipStreamWaitEvent(rd->stream, ctx->ev_chain_pre, 0));
   if (vchain)
     LPGP_TRY(launch_panel_chain_v(ctx, rd->stream, mat, p0, rd->v + (int64_t)p0 * tb, rd->ldv, (int64_t)rd->mtl * tb, ctx->d_info_cur));
   if (sync_first && (rd->stream != ctx->s_main || two)) {
@@ -249,7 +253,10 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     }
     // panel factorisation on sP: the resident chain (one launch, chain.hip) where the chain is what bounds the pipeline ...
     const bool resident = ctx->chain_resident_max_rows >= 0 && p1 - p0 == 4 && T - p1 <= ctx->chain_resident_max_rows && !ctx->distributed();
-    if (resident) LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, T, ctx->d_info_cur));
+    if (resident) {
+      if (ride && ride->stream != sP && ctx->ride_vchain_pre) LPGP_HIP(hipEventRecord(ctx->ev_chain_pre, sP));      // (see ride_panel_now: the step that follows the chain's flags)
+      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, T, ctx->d_info_cur));
+    }
     // ... else tile by tile
     for (int jt = p0; jt < p1 && !resident; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
