@@ -3,7 +3,8 @@ import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'linpde-gp_amd')
 import linpde_gp_amd as lp
 from linpde_gp_amd import problems
-wl = problems.poisson_1d(512, n_bdry_repeats=16, noise_var=1e-4, m=256) if sys.argv[1] == "c1" else problems.poisson_2d(n_side=32, m_side=16)
+wl = {"c1": lambda: problems.poisson_1d(512, n_bdry_repeats=16, noise_var=1e-4, m=256), "p32": lambda: problems.poisson_2d(n_side=32, m_side=16),
+      "heat": problems.heat_reference}[sys.argv[1]]()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 lp.config.lazy_factorization = True
 dev = problems.upload(wl)
