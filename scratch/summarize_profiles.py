@@ -18,6 +18,7 @@ def newest(pattern):
 
 
 summary = {"round": rnd, "config": tag, "commands": commands}
+commands = [c for c in commands if not c.startswith("#")]        # (notes about the environment stay in summary["commands"])
 st = newest(f"{D}/stats/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
