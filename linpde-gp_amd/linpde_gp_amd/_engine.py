@@ -247,7 +247,8 @@ def _grid_factor_points(ctx: "Context", X_original, X_flat: np.ndarray):
     """Factor point sets of `X_original` if it is a `TensorProductGrid` (carries `.factors`) whose
     points, flattened in C order, are exactly `X_flat` (a sliced or reordered view is not)."""
     factors = getattr(X_original, "factors", None)
-    if not config.use_grid_assembly or factors is None or len(factors) != X_flat.shape[1] or len(factors) < 2:
+    if (not config.use_grid_assembly or factors is None or len(factors) != X_flat.shape[1] or len(factors) < 2
+            or X_flat.shape[0] < config.grid_assembly_min_points):
         return None
     factors = [np.ascontiguousarray(f, dtype=np.double).reshape(-1) for f in factors]
     if int(np.prod([f.size for f in factors])) != X_flat.shape[0]:

@@ -10,6 +10,13 @@ gram_capacity_hint: int = 0
 # `Box.uniform_grid`) are assembled as sums of Kronecker products of 1-D kernel matrices
 # (`lpgp_gram_assemble_grid`); False forces the generic per-entry evaluation.
 use_grid_assembly: bool = True
+# ... for grids of at least this many points.  Below, the per-entry kernel is the faster of the two: the Kronecker path costs eight
+# launches of 1-D factor matrices and an expansion kernel that is latency-bound on a small block (a 32 x 32 grid: 72 us against 8;
+# steps of 1 024 .. 9 216 grid points are 1.7 - 6.4 % faster entry by entry, at 16 384 points (c3) the two are equal, at 65 536 (c4)
+# the expansion's 5.3 TB/s wins; MEASUREMENTS.md round 5); the values agree to rounding either way
+# (`test_small_grids_take_the_per_entry_kernel_and_agree_with_the_kronecker_path`).  Env LPGP_GRID_MIN_POINTS overrides.
+import os as _os
+grid_assembly_min_points: int = int(_os.environ.get("LPGP_GRID_MIN_POINTS", 12000))
 
 # When a Gram matrix that is not positive definite is reported.
 # False (default): inside `condition_on_observations`, as in the reference -- its constructor evaluates the representer

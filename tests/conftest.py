@@ -47,6 +47,18 @@ def pytest_collection_modifyitems(config, items):
         it.add_marker(skip)
 
 
+@pytest.fixture
+def kronecker_everywhere():
+    """Tensor-grid blocks of ANY size through the Kronecker assembly (`lpgp_gram_assemble_grid`): by default grids below
+    `config.grid_assembly_min_points` points take the per-entry kernel (faster there); the full-size c3 / c4 / c5 tests go through the
+    Kronecker path as the product does."""
+    from linpde_gp_amd import config
+    saved = config.grid_assembly_min_points
+    config.grid_assembly_min_points = 0
+    yield
+    config.grid_assembly_min_points = saved
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

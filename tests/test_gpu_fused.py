@@ -318,6 +318,33 @@ def test_substitution_follows_the_resident_chain_through_its_flags(lazy, make):
     assert_posterior_close(out[96][0], out[96][1], ref["mean"], ref["var"])
 
 
+@pytest.mark.parametrize("make", [lambda P: P.poisson_2d(n_side=32, m_side=16), lambda P: P.poisson_2d(n_side=40, n_bdry=37, m_side=17),
+                                  lambda P: P.heat_reference(), lambda P: P.heat_1d(nt=48, nx=24, m_side=20)])
+def test_small_grids_take_the_per_entry_kernel_and_agree_with_the_kronecker_path(lazy, make):
+    """Round 5: grids below `config.grid_assembly_min_points` (12 000) points are assembled entry by entry -- eight launches of 1-D
+    factor matrices and a latency-bound expansion cost a 32 x 32 grid 72 us against 8 -- and the Kronecker path stays for the large
+    ones (c3 on).  Both evaluate the same product form: same Gram matrix to rounding, same posterior, both within the oracle's bar."""
+    from linpde_gp_amd import config, problems
+    wl = make(problems)
+    saved = config.grid_assembly_min_points
+    out = {}
+    try:
+        for thr in (saved, 0):
+            config.grid_assembly_min_points = thr
+            u, m, v = problems.condition_and_predict(wl)
+            out[thr] = (m, v, u.gram.cholesky())
+            del u
+    finally:
+        config.grid_assembly_min_points = saved
+    assert saved > 0
+    L1, L0 = out[saved][2], out[0][2]
+    G1, G0 = L1 @ L1.T, L0 @ L0.T
+    assert np.max(np.abs(G1 - G0)) <= 1e-12 * np.max(np.abs(G0))
+    ref = owl.run(wl)
+    for thr in out:
+        assert_posterior_close(out[thr][0], out[thr][1], ref["mean"], ref["var"])
+
+
 def test_misuse_of_the_conditioning_entry_point_rolls_the_block_back():
     """`lpgp_mat_condition` with a row entry whose point set does not match the block it names (a C-API misuse the host package
     never commits): the call fails AND the block it had declared is dropped again, on the batched row path like on the
@@ -352,7 +379,7 @@ def test_misuse_of_the_conditioning_entry_point_rolls_the_block_back():
         ctx.set_option("asm_batch", saved)
 
 
-def test_kronecker_expansion_with_16_byte_stores_is_bit_identical():
+def test_kronecker_expansion_with_16_byte_stores_is_bit_identical(kronecker_everywhere):
     """Round 5: `kron2w_kernel` (a lane owns two consecutive fast rows: 16-byte stores) against `kron2_kernel`, diagonal (lower-only)
     and cross blocks, fast extents that are multiples of 128, even but ragged, and odd (falls back to the 8-byte kernel)."""
     import linpde_gp_amd as lp

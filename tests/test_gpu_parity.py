@@ -224,7 +224,7 @@ def test_long_sums_and_many_terms(lp):
     assert _rel(A(B(k3, argnum=1), argnum=0).matrix(X0, X1), ocf.LkL(okern3, ca, cb, X0, X1)) < 1e-12
 
 
-def test_grid_blocks_beyond_the_kronecker_tables(lp):
+def test_grid_blocks_beyond_the_kronecker_tables(lp, kronecker_everywhere):
     """A sum on tensor grids that does not fit the fixed-size tables of the Kronecker path (`lpgp_kron_fits`: 48 terms,
     16 distinct 1-D matrices per dimension) is assembled entry-wise from the flattened grids -- round 3 raised an error --
     in `matrix`-free conditioning and prediction alike: same Gram matrix as scattered copies of the same points."""
@@ -405,7 +405,7 @@ def test_iterative_equals_oneshot_and_linop_readout(lp):
     np.testing.assert_allclose(rvL.cov, post.cov(Xt, Ltest=lap), rtol=1e-7, atol=1e-6)
 
 
-def test_tensor_grid_assembly_matches_generic(lp):
+def test_tensor_grid_assembly_matches_generic(lp, kronecker_everywhere):
     """Observations on a `TensorProductGrid` are assembled as sums of Kronecker products of 1-D
     kernel matrices (`lpgp_gram_assemble_grid`; the reference's Kronecker `linop`,
     covfuncs/_tensor_product.py:64-82, diffops/_tensor_product.py:140-156): same Gram matrix
