@@ -405,6 +405,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_pre, hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_VCHAIN")) ctx->ride_vchain_max_wgs = std::atoi(e);
@@ -1472,11 +1473,16 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
   LPGP_DEVICE(ctx);
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_solve_weights: matrix is not factored");
   const int64_t pn = mat->pn;
-  int rc = ensure_tmp(ctx, pn);
+  int rc = ensure_tmp(ctx, pn + 2);                 // (+ 2: the ticket words of the resident solve, trsv.hip)
   if (rc != 0) return rc;
-  std::vector<double> hp((size_t)pn);
-  scatter_padded(mat, r_host, hp.data());
-  LPGP_HIP(hipMemcpyAsync(mat->w, hp.data(), (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
+  // through pinned staging: the residual up and the weights + the solve's status word back are asynchronous copies, ONE wait
+  // (round 6; until then two blocking copies through pageable memory around 2 x T dependent launches)
+  rc = ensure_stage(ctx, pn);
+  if (rc != 0) return rc;
+  double* const hs = ctx->h_stage;
+  int* const hinfo = ctx->h_info_pinned + 6;
+  scatter_padded(mat, r_host, hs);
+  LPGP_HIP(hipMemcpyAsync(mat->w, hs, (size_t)pn * sizeof(double), hipMemcpyHostToDevice, ctx->s_main));
   if (ctx->distributed()) {
     // multi-GPU: the factor is streamed; the vector rides as column 0 of a 128-column block on every rank (all
     // ranks end with the same weights, no further communication)
@@ -1490,15 +1496,19 @@ int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, doubl
     if (rc == 0) rc = dist_fail(ctx, trsm_lower_t_dist(ctx, mat, pn / TILE, dv, pn, TILE));
     if (rc == 0 && hipMemcpyAsync(mat->w, dv, (size_t)pn * sizeof(double), hipMemcpyDeviceToDevice, ctx->s_main) != hipSuccess) rc = dist_fail(ctx, -1);
     pool_free(ctx, pv, vb);
+    *hinfo = 0;
   } else {
-    rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp);
+    LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->s_main));
+    rc = solve_vec(ctx, mat, pn / TILE, mat->w, ctx->d_tmp, ctx->d_info);
+    if (rc == 0) LPGP_HIP(hipMemcpyAsync(hinfo, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->s_main));
   }
   if (rc != 0) return rc;
+  if (ctx->distributed()) LPGP_TRY(sync_stream(ctx, ctx->s_main));      // (watched: a copy behind a streamed solve whose peer is gone would wait for ever)
+  LPGP_HIP(hipMemcpyAsync(hs, mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
   LPGP_TRY(sync_stream(ctx, ctx->s_main));
-  LPGP_HIP(hipMemcpyAsync(hp.data(), mat->w, (size_t)pn * sizeof(double), hipMemcpyDeviceToHost, ctx->s_main));
-  LPGP_TRY(sync_stream(ctx, ctx->s_main));
+  LPGP_CHECK(*hinfo >= 0, "resident single-vector solve: a hand-over between workgroups timed out (device status %d); set LPGP_TRSV_RESIDENT=0", *hinfo);
   mat->has_w = 1;
-  if (w_host) gather_padded(mat, hp.data(), w_host);
+  if (w_host) gather_padded(mat, hs, w_host);
   return 0;
 }
 

@@ -101,6 +101,7 @@ struct lpgp_ctx {
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
   // ONE launch whose workgroups hand over through device flags (-1: never)
   int chain_resident_max_rows = 32;
+  int trsv_resident = 1;               // single right-hand side: one resident launch per direction (trsv.hip); 0: one launch per tile (rounds 1-5)
   int* d_chain_flags = nullptr;        // ring of flag slots (zeroed; a launch zeroes the slot half a ring ahead)
   int64_t chain_launches = 0;
   int* chain_last_slot = nullptr;      // flag slot and panel of the last chain launch: the substitution's panel step that follows it
@@ -393,7 +394,9 @@ int factor_to_host_dist(lpgp_ctx* ctx, lpgp_mat* mat, double* out_padded /* pn x
 int copy2d(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols);
 int trsm_lower_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
 int trsm_lower_t_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, int64_t ldv, int64_t m_pad);
-int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp);
+// v <- G^{-1} v; tmp: T * 128 + 2 doubles of scratch; info: device status word (INT_MIN after a timed-out hand-over of the resident form)
+int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp, int* info);
+int solve_vec_resident(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T, double* v, double* tmp, int* info);      // trsv.hip
 int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T, double* b, double* x);
 
 // assemble.hip ----------------------------------------------------------------------------

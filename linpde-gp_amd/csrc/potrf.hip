@@ -926,7 +926,8 @@ int solve_vec_fwd(lpgp_ctx* ctx, hipStream_t st, lpgp_mat* mat, int64_t T64, dou
 }
 
 // v (padded length T*128, device) <- G^{-1} v, using scratch vector `tmp` of the same length
-int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp) {
+int solve_vec(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, double* tmp, int* info) {
+  if (ctx->trsv_resident) return solve_vec_resident(ctx, mat, T64, v, tmp, info);
   const int T = (int)T64;
   const int64_t ld = mat->cap;
   hipStream_t st = ctx->s_main;
