@@ -583,6 +583,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "chain_us_fixed") == 0) *value = (int64_t)ctx->chain_us_fixed;
   else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
   else if (std::strcmp(key, "chain_resident_max_rows") == 0) *value = ctx->chain_resident_max_rows;
+  else if (std::strcmp(key, "trsv_resident") == 0) *value = ctx->trsv_resident;
   else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
@@ -665,6 +666,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->ride_stream = (int)value;
   } else if (std::strcmp(key, "chain_resident_max_rows") == 0) {
     ctx->chain_resident_max_rows = (int)value;
+  } else if (std::strcmp(key, "trsv_resident") == 0) {
+    ctx->trsv_resident = value != 0;
   } else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) {
     ctx->ride_vchain_max_wgs = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {

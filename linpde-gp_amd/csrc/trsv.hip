@@ -5,10 +5,9 @@
 // a scalar GEMV, ~30 us each: 8 ms at c3 against 0.36 ms for reading the factor once at the achievable HBM rate).
 //
 // Forward (L y = b).  Workgroup i (tickets: in the order the workgroups start) owns the 128 rows of tile row i.  It streams the
-// tiles (i, 0), (i, 1), ... (i, i - 1) of its row strip through registers -- three rotating buffers, two tiles ahead of the one
-// it multiplies -- and multiplies tile (i, j) with y_j as soon as y_j has been PUBLISHED by workgroup j; the partial sums of a
-// thread stay in its registers over the whole strip.  Behind tile (i, i - 1) the same stream delivers Linv_i and L_ii: the
-// workgroup forms  b_i - sum_j L_ij y_j,  solves against its diagonal tile with the explicit tile inverse and ONE step of
+// tiles (i, 0), (i, 1), ... (i, i - 1) of its row strip through registers and multiplies tile (i, j) with y_j as soon as y_j
+// has been PUBLISHED by workgroup j; the partial sums of a thread stay in its registers over the whole strip.  Linv_i and L_ii
+// are in registers from the start: the workgroup forms  b_i - sum_j L_ij y_j,  solves against its diagonal tile with the explicit tile inverse and ONE step of
 // iterative refinement against the tile itself (x0 = Linv b', x = x0 + Linv (b' - L x0): the arithmetic of tile_solve_kernel and
 // of the step kernels this replaces), and publishes y_i.
 // Backward (L^T x = y): workgroup k owns tile COLUMN i = T - 1 - k, streams (T - 1, i), ..., (i + 1, i), accumulates the
@@ -25,6 +24,7 @@
 // operands already in registers.  Everything else -- 8 N^2 / 2 bytes of factor per direction -- streams underneath it.
 
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 #include "lpgp_internal.h"
@@ -44,6 +44,7 @@ struct TrsvArgs {
   int* ticket;             // starts at -1
   int* info;               // status word: INT_MIN if a hand-over timed out
   int32_t T;
+  int32_t flags;           // measurement aids (LPGP_TRSV_FLAGS): 1 no refinement step (WRONG results beyond eps cond), 2 polls without s_sleep
 };
 
 __device__ __forceinline__ unsigned long long trsv_ld(const double* p) {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void trsv_st(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // `v`: the value of a first load issued earlier (so that it is in front of the tile loads in the memory queue)
-__device__ __forceinline__ double trsv_poll(const double* p, unsigned long long v, int* info) {
+__device__ __forceinline__ double trsv_poll(const double* p, unsigned long long v, int* info, bool nosleep = false) {
   int spins = 0;
   while (v == TRSV_SENT) {
     if (++spins > TRSV_SPIN_LIMIT) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ double trsv_poll(const double* p, unsigned long long 
       v = TRSV_QNAN;
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
+    if (!nosleep) __builtin_amdgcn_s_sleep(1);
     v = trsv_ld(p);
   }
   return __longlong_as_double((long long)v);
@@ -149,8 +150,9 @@ __device__ __forceinline__ double trsv_mv(const double2 (&M)[16], const double* 
 // asks for; returns x[t] in the threads t < 128
 template <bool TRANS>
 __device__ __forceinline__ double trsv_diag_solve(const double2 (&LI)[16], const double2 (&LD)[16], const double* sb, double* s1, double* s2,
-                                                  double* part, int t) {
+                                                  double* part, int t, bool refine = true) {
   const double x0 = trsv_mv<TRANS>(LI, sb, part, t);
+  if (!refine) return x0;
   if (t < TILE) s1[t] = x0;
   __syncthreads();
   const double lx = trsv_mv<TRANS>(LD, s1, part, t);
@@ -160,11 +162,14 @@ __device__ __forceinline__ double trsv_diag_solve(const double2 (&LI)[16], const
   return x0 + dx;
 }
 
-// The streaming loop of both kernels is written WITHOUT a conditional around any memory instruction: every step issues its
-// sixteen tile loads and its first poll, whatever its place in the stream (out-of-range elements are clamped to a valid tile and
-// multiplied by zeros), because hipcc counts outstanding loads only along straight-line code -- behind a conditional load it
-// falls back to `s_waitcnt vmcnt(0)`, which here means: no load ever in flight across a step.  All 512 threads poll (four
-// per entry of the vector): one instruction stream for the eight waves.
+// Register plan (both kernels): Linv_i and L_ii are loaded FIRST and stay in registers (2 x 64); the row strip streams through
+// ONE tile buffer (64), re-loaded right behind the product that consumed it.  So when the chain reaches a workgroup -- the poll
+// for the last solution block it needs -- the workgroup has NO load in flight: the price of a hand-over sits in the consumer
+// CU's own memory queue (MI355X_MICROARCH.md, handoff-1to1: 1.1 us between unloaded CUs, 2.9 between streaming ones; the first
+// form of this kernel, which kept prefetching L_ii behind the poll, took 4.5 us per tile row, and neither the refinement's
+// two products nor the poll's s_sleep showed in it).  The loop has no conditional around a memory instruction (the last tile is
+// peeled): behind a conditional load hipcc falls back to `s_waitcnt vmcnt(0)` everywhere.  All 512 threads poll (four per
+// entry): one instruction stream for the eight waves.
 __global__ __launch_bounds__(512, 1) void trsv_fwd_resident_kernel(TrsvArgs g) {
   __shared__ __attribute__((aligned(16))) double sx[2][TILE];
   __shared__ __attribute__((aligned(16))) double part[8 * TILE];
@@ -175,48 +180,32 @@ __global__ __launch_bounds__(512, 1) void trsv_fwd_resident_kernel(TrsvArgs g) {
   __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane(s_ticket);
   if (i >= g.T) return;
-  const double bi = g.b[(int64_t)i * TILE + (t & 127)];
   const unsigned lane_bytes = 16u * (unsigned)rp;
-
-  // the stream of this workgroup: elements 0 .. i - 1 = tiles (i, e); i = Linv_i; i + 1 = L_ii
-  auto issue = [&](double2 (&buf)[16], int e) {
-    e = e < 0 ? 0 : e;
-    const double* base = g.L + (int64_t)i * TILE + (int64_t)e * TILE * g.ld;
-    int64_t ldm = g.ld;
-    if (e == i) { base = g.linv + (int64_t)i * TILE * TILE; ldm = TILE; }
-    if (e > i) base = g.L + (int64_t)i * TILE * (g.ld + 1);
-    trsv_load_rows(buf, base + (int64_t)(16 * cg) * ldm, ldm, lane_bytes);
-  };
+  double2 LI[16], LD[16], B[16];
+  trsv_load_rows(LI, g.linv + (int64_t)i * TILE * TILE + (int64_t)(16 * cg) * TILE, TILE, lane_bytes);
+  trsv_load_rows(LD, g.L + (int64_t)i * TILE * (g.ld + 1) + (int64_t)(16 * cg) * g.ld, g.ld, lane_bytes);
+  const double bi = g.b[(int64_t)i * TILE + (t & 127)];
+  const double* strip = g.L + (int64_t)i * TILE + (int64_t)(16 * cg) * g.ld;       // tile (i, j) at strip + j * 128 * ld
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int par = 0;
-  // one step: the tile in `cur` is element e; element e + 2 goes into `nxt`.  e < 0: a padding step (multiplies by zeros)
-  auto step = [&](const double2 (&cur)[16], double2 (&nxt)[16], int e) {
-    const double* px = e < 0 ? g.b + (t & 127) : g.x + (int64_t)e * TILE + (t & 127);
-    __builtin_amdgcn_sched_barrier(0);               // (the loads below stay behind the last use of `nxt`'s old contents: no fourth tile in registers)
-    unsigned long long v = trsv_ld(px);              // (in front of the tile loads: its answer does not wait for them)
-    issue(nxt, e + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    const double xv = trsv_poll(px, v, g.info);
-    if (t < TILE) sx[par][t] = e < 0 ? 0.0 : xv;
+  // y_j arrives, tile (i, j) (in B) is multiplied with it
+  auto consume = [&](int j) {
+    const double* px = g.x + (int64_t)j * TILE + (t & 127);
+    const double xv = trsv_poll(px, trsv_ld(px), g.info, (g.flags & 2) != 0);
+    if (t < TILE) sx[par][t] = xv;
     __syncthreads();
-    trsv_fma_rows(cur, &sx[par][16 * cg], a0, a1, a2, a3);
-    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (the products stay HERE: sunk into the next step's block -- their only use -- they keep `cur` and the vector alive across its loads)
+    trsv_fma_rows(B, &sx[par][16 * cg], a0, a1, a2, a3);
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (the products stay HERE, in front of the re-load of B)
     par ^= 1;
   };
-  // the stream is padded IN FRONT so that its length is a multiple of three: the last three elements -- tile (i, i - 1), Linv_i,
-  // L_ii -- always end up in B0, B1, B2
-  double2 B0[16], B1[16], B2[16];
-  const int pad = (3 - (i + 2) % 3) % 3;
-  const int n = i + 2 + pad;
-  issue(B0, -pad);
-  issue(B1, 1 - pad);
-  for (int q = 0; q < n - 3; q += 3) {
-    const int e = q - pad;
-    step(B0, B2, e);
-    step(B1, B0, e + 1);
-    step(B2, B1, e + 2);
+  if (i > 0) {
+    trsv_load_rows(B, strip, g.ld, lane_bytes);
+    for (int j = 0; j < i - 1; ++j) {
+      consume(j);
+      trsv_load_rows(B, strip + (int64_t)(j + 1) * TILE * g.ld, g.ld, lane_bytes);
+    }
+    consume(i - 1);
   }
-  step(B0, B2, i - 1);                               // (loads L_ii into B2; i == 0: a padding step)
   *reinterpret_cast<double2*>(part + cg * TILE + 2 * rp) = make_double2(a0 + a2, a1 + a3);
   __syncthreads();
   if (t < TILE) {
@@ -226,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void trsv_fwd_resident_kernel(TrsvArgs g) {
     sb[t] = bi - s;
   }
   __syncthreads();
-  const double xi = trsv_diag_solve<false>(B1, B2, sb, s1, s2, part, t);
+  const double xi = trsv_diag_solve<false>(LI, LD, sb, s1, s2, part, t, !(g.flags & 1));
   if (t < TILE) trsv_st(g.x + (int64_t)i * TILE + t, xi);
 }
 
@@ -243,71 +232,50 @@ __global__ __launch_bounds__(512, 1) void trsv_bwd_resident_kernel(TrsvArgs g) {
   const int k = __builtin_amdgcn_readfirstlane(s_ticket);
   if (k >= g.T) return;
   const int i = g.T - 1 - k;                     // this workgroup's tile column
-  const double yi = g.b[(int64_t)i * TILE + (t & 127)];
   const unsigned lane_bulk = 16u * (unsigned)rq + (unsigned)ch * (unsigned)(8 * g.ld * 8);
   const unsigned lane_linv = (unsigned)(2 * ln) * (unsigned)(TILE * 8), lane_diag = (unsigned)(2 * ln) * (unsigned)(g.ld * 8);
-
-  // the stream: elements 0 .. k - 1 = tiles (T - 1 - e, i), four rows x 8 columns per lane; k = Linv_i, k + 1 = L_ii in column form
-  auto issue_bulk = [&](double2 (&buf)[16], int e) {
-    e = e < 0 ? 0 : (e >= k ? (k > 0 ? k - 1 : 0) : e);        // (k == 0: the diagonal tile itself, multiplied by zeros)
-    const __amdgpu_buffer_rsrc_t r = trsv_rsrc(g.L + (int64_t)(g.T - 1 - e) * TILE + ((int64_t)i * TILE + 16 * cg) * g.ld);
+  double2 LI[16], LD[16], B[16];
+  trsv_load_cols(LI, g.linv + (int64_t)i * TILE * TILE + 16 * cg, TILE, lane_linv);
+  trsv_load_cols(LD, g.L + (int64_t)i * TILE * (g.ld + 1) + 16 * cg, g.ld, lane_diag);
+  const double yi = g.b[(int64_t)i * TILE + (t & 127)];
+  const double* strip = g.L + ((int64_t)i * TILE + 16 * cg) * g.ld;       // tile (j, i) at strip + j * 128
+  auto load_bulk = [&](int j) {
+    const __amdgpu_buffer_rsrc_t r = trsv_rsrc(strip + (int64_t)j * TILE);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {          // (a load instruction reads 512 contiguous bytes of each of two columns)
-      buf[2 * c] = trsv_ldb(r, lane_bulk, (int64_t)c * g.ld);
-      buf[2 * c + 1] = trsv_ldb(r, lane_bulk, (int64_t)c * g.ld + 64);
+      B[2 * c] = trsv_ldb(r, lane_bulk, (int64_t)c * g.ld);
+      B[2 * c + 1] = trsv_ldb(r, lane_bulk, (int64_t)c * g.ld + 64);
     }
   };
   double acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.0;
   int par = 0;
-  // DIAG = 0: element e + 2 is a bulk tile; 1: Linv_i; 2: L_ii (column form)
-  auto step = [&](const double2 (&cur)[16], double2 (&nxt)[16], int e, auto DIAG_) {
-    constexpr int DIAG = decltype(DIAG_)::value;
-    const double* px = e < 0 ? g.b + (t & 127) : g.x + (int64_t)(g.T - 1 - e) * TILE + (t & 127);
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned long long v = trsv_ld(px);
-    if constexpr (DIAG == 0) issue_bulk(nxt, e + 2);
-    else if constexpr (DIAG == 1) trsv_load_cols(nxt, g.linv + (int64_t)i * TILE * TILE + 16 * cg, TILE, lane_linv);
-    else trsv_load_cols(nxt, g.L + (int64_t)i * TILE * (g.ld + 1) + 16 * cg, g.ld, lane_diag);
-    __builtin_amdgcn_sched_barrier(0);
-    const double xv = trsv_poll(px, v, g.info);
-    if (t < TILE) sx[par][t] = e < 0 ? 0.0 : xv;
+  auto consume = [&](int j) {
+    const double* px = g.x + (int64_t)j * TILE + (t & 127);
+    const double xv = trsv_poll(px, trsv_ld(px), g.info, (g.flags & 2) != 0);
+    if (t < TILE) sx[par][t] = xv;
     __syncthreads();
     const double2 xa = *reinterpret_cast<const double2*>(&sx[par][2 * rq]);
     const double2 xb = *reinterpret_cast<const double2*>(&sx[par][64 + 2 * rq]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      double s = fma(cur[2 * c].x, xa.x, acc[c]);
-      s = fma(cur[2 * c].y, xa.y, s);
-      s = fma(cur[2 * c + 1].x, xb.x, s);
-      acc[c] = fma(cur[2 * c + 1].y, xb.y, s);
+      double s = fma(B[2 * c].x, xa.x, acc[c]);
+      s = fma(B[2 * c].y, xa.y, s);
+      s = fma(B[2 * c + 1].x, xb.x, s);
+      acc[c] = fma(B[2 * c + 1].y, xb.y, s);
     }
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
     par ^= 1;
   };
-  using I0 = std::integral_constant<int, 0>;
-  double2 B0[16], B1[16], B2[16];
-  const int pad = (3 - (k + 2) % 3) % 3;
-  const int n = k + 2 + pad;
-  // the last three elements -- tile (i + 1, i), Linv_i, L_ii -- end up in B0, B1, B2; the loop's steps load bulk tiles only
-  // except the very last one (position n - 4 loads position n - 2 = Linv_i), which is peeled off with the final step
-  issue_bulk(B0, -pad);
-  if (n > 3) issue_bulk(B1, 1 - pad);
-  else trsv_load_cols(B1, g.linv + (int64_t)i * TILE * TILE + 16 * cg, TILE, lane_linv);
-  for (int q = 0; q < n - 6; q += 3) {
-    const int e = q - pad;
-    step(B0, B2, e, I0{});
-    step(B1, B0, e + 1, I0{});
-    step(B2, B1, e + 2, I0{});
+  if (k > 0) {
+    load_bulk(g.T - 1);
+    for (int j = g.T - 1; j > i + 1; --j) {
+      consume(j);
+      load_bulk(j - 1);
+    }
+    consume(i + 1);
   }
-  if (n > 3) {
-    const int e = n - 6 - pad;
-    step(B0, B2, e, I0{});
-    step(B1, B0, e + 1, I0{});
-    step(B2, B1, e + 2, std::integral_constant<int, 1>{});
-  }
-  step(B0, B2, k - 1, std::integral_constant<int, 2>{});      // (k == 0: a padding step)
   // sum over the 32 lanes rq: red[column][rq], then four lanes per column
 #pragma unroll
   for (int c = 0; c < 8; ++c) red[(16 * cg + 8 * ch + c) * 32 + rq] = acc[c];
@@ -325,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void trsv_bwd_resident_kernel(TrsvArgs g) {
   __syncthreads();
   if (t < TILE) sb[t] = yi - part[t];
   __syncthreads();
-  const double xi = trsv_diag_solve<true>(B1, B2, sb, s1, s2, part, t);
+  const double xi = trsv_diag_solve<true>(LI, LD, sb, s1, s2, part, t, !(g.flags & 1));
   if (t < TILE) trsv_st(g.x + (int64_t)i * TILE + t, xi);
 }
 
@@ -337,6 +305,8 @@ int solve_vec_resident(lpgp_ctx* ctx, lpgp_mat* mat, int64_t T64, double* v, dou
   const size_t nb = (size_t)T * TILE * sizeof(double);
   TrsvArgs g;
   g.L = mat->a; g.ld = mat->cap; g.linv = mat->linv; g.info = info; g.T = T;
+  static const int dbg_flags = [] { const char* e = std::getenv("LPGP_TRSV_FLAGS"); return e ? std::atoi(e) : 0; }();
+  g.flags = dbg_flags;
   // forward: L tmp = v
   LPGP_HIP(hipMemsetAsync(tmp, 0xFF, nb + 2 * sizeof(double), st));           // the sentinel, and both tickets at -1
   g.b = v; g.x = tmp; g.ticket = reinterpret_cast<int*>(tmp + (size_t)T * TILE);
