@@ -323,6 +323,17 @@ int  lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V);
 int  lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host);
 /* logical rows, n x m C-order                                                           */
 int  lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* out_host);
+/* *out_new = a NEW block  A[:, :ma] B  with B_host (ma x m, C-order; ma = columns of A) sharing A's row layout (lpgp_rhs_destroy):
+ * the product behind the posterior covariance AS A LINEAR OPERATOR -- `(k_xx - kLas_x0 @ gram.solve(kLas_x1.T)) @ V`,
+ * `_conditional.py:245-251` -- as  k(x0, x1) V - V0^T (V1 V)  with V0 = L^{-1} K_Xx0, V1 = L^{-1} K_Xx1 resident: the n0 x n1
+ * matrix never exists.  Single GPU.                                                                                   */
+int  lpgp_rhs_matmul(lpgp_ctx* ctx, const lpgp_rhs* A, const double* B_host, int64_t m, lpgp_rhs** out_new);
+/* C (m x n) = alpha op(A) op(B) + beta C on HOST arrays (all C-order; op(A) is m x k: A is m x k, or k x m with transa != 0;
+ * likewise B) through the fp64 MFMA kernel: the dense products the reference leaves to NumPy around the path --
+ * `A @ Sigma0`, `crosscov @ A.T`, `Sigma0 - crosscov.T @ gain` of the finite-dimensional conditioning (`randvars/_normal.py:8-71`),
+ * `L @ L.T` of `gram.todense()`.  beta == 0: C is not read.  Single GPU.                                           */
+int  lpgp_gemm_host(lpgp_ctx* ctx, int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, double alpha,
+                    const double* A_host, const double* B_host, double beta, double* C_host);
 /* diag of sum_g (kd[g])(x, x): a constant for the stationary kernels supported here     */
 int  lpgp_kernel_diag(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, double* out_value);
 

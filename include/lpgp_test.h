@@ -49,6 +49,10 @@ int  lpgp_debug_tile_xcc(lpgp_ctx* ctx, int32_t* out8, int32_t reset);
 int  lpgp_probe_mfma_f64(lpgp_ctx* ctx, double* tflops);
 int  lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps);
 
+/* leaves the sticky status word of `mat` as an enqueued factorisation that ended with `value` would (value < 0: a hand-over of
+ * a resident kernel timed out): the error path of lpgp_mat_check without a broken device                          */
+int  lpgp_test_force_status(lpgp_ctx* ctx, lpgp_mat* mat, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif

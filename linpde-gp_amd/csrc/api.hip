@@ -408,6 +408,10 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
+  // A profiler that SERIALISES kernels (rocprofv3 --pmc / counter groups: ROCPROF_COUNTER_COLLECTION) breaks the one assumption of
+  // the follower -- that its chain kernel is dispatched beside it: it would wait out its poll limit, ~1 s per panel, and the step
+  // would fail with a negative status.  Off there unless asked for explicitly.
+  if (const char* e = std::getenv("ROCPROF_COUNTER_COLLECTION")) { if (e[0] != '\0' && e[0] != '0' && e[0] != 'F' && e[0] != 'f') ctx->ride_vchain_max_wgs = 0; }
   if (const char* e = std::getenv("LPGP_RIDE_VCHAIN")) ctx->ride_vchain_max_wgs = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_VCHAIN_PRE")) ctx->ride_vchain_pre = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_GATE_PCT")) ctx->ride_gate_pct = std::atoi(e);
@@ -968,6 +972,7 @@ int lpgp_mat_add_block(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n) { return mat_add
 static int mat_add_block_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, bool pad_now) {
   LPGP_CHECK(ctx && mat && n > 0, "lpgp_mat_add_block: bad argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_mat_add_block");
   LPGP_CHECK(mat->hidden.empty(), "lpgp_mat_add_block: a strict prefix of the blocks is in view (lpgp_mat_set_view); extend a clone instead");
   lpgp_block b;
   b.n = n;
@@ -1047,6 +1052,7 @@ int lpgp_mat_set_view(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks) {
 int lpgp_mat_clone(lpgp_ctx* ctx, const lpgp_mat* src, int32_t nblocks, lpgp_mat** out) {
   LPGP_CHECK(ctx && src && out, "lpgp_mat_clone: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(src, "lpgp_mat_clone");
   LPGP_CHECK(!ctx->distributed(), "lpgp_mat_clone: not available in a multi-GPU job");
   std::vector<lpgp_block> all = src->blocks;
   all.insert(all.end(), src->hidden.begin(), src->hidden.end());
@@ -1188,6 +1194,7 @@ static int dist_fail(lpgp_ctx* ctx, int rc) {
 int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_host) {
   LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_to_host: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_mat_to_host");
   LPGP_CHECK(what == 0 || what == 1, "lpgp_mat_to_host: what must be 0 or 1");
   if (what == 0) LPGP_CHECK(mat->pn_fact == 0, "lpgp_mat_to_host: Gram no longer available after potrf");
   if (what == 1) LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_to_host: matrix is not (fully) factored");
@@ -1218,6 +1225,7 @@ int lpgp_mat_to_host(lpgp_ctx* ctx, lpgp_mat* mat, int32_t what, double* out_hos
 int lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host) {
   LPGP_CHECK(ctx && mat && out_host, "lpgp_mat_factor_diag: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_mat_factor_diag");
   LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_factor_diag: matrix is not (fully) factored");
   const int64_t pn = mat->pn;
   if (pn == 0) return 0;
@@ -1244,6 +1252,7 @@ int lpgp_mat_factor_diag(lpgp_ctx* ctx, lpgp_mat* mat, double* out_host) {
 int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   LPGP_CHECK(ctx && mat, "lpgp_potrf: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_potrf");
   if (info) *info = 0;
   if (mat->pn_fact == mat->pn) return 0;
   LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf: a strict prefix of the blocks is in view");
@@ -1252,7 +1261,10 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
   int rc = ctx->distributed()
                ? dist_fail(ctx, potrf_dist(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h))
                : potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, &h);
-  if (rc != 0) return rc;
+  if (rc != 0) {
+    mat->poisoned = 1;               // (the matrix is partly overwritten in place, pn_fact unchanged: not a state to factor again from)
+    return rc;
+  }
   if (info) *info = h;
   if (h == 0) mat->pn_fact = mat->pn;
   mat->has_w = 0;
@@ -1263,11 +1275,15 @@ int lpgp_potrf(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info) {
 int lpgp_potrf_enqueue(lpgp_ctx* ctx, lpgp_mat* mat) {
   LPGP_CHECK(ctx && mat, "lpgp_potrf_enqueue: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_potrf_enqueue");
   if (mat->pn_fact == mat->pn) return 0;
   LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf_enqueue: a strict prefix of the blocks is in view");
   LPGP_CHECK(!ctx->distributed(), "lpgp_potrf_enqueue: single GPU only (the multi-GPU factorisation agrees on its status collectively: lpgp_potrf)");
   int rc = potrf_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, nullptr);
-  if (rc != 0) return rc;
+  if (rc != 0) {
+    mat->poisoned = 1;
+    return rc;
+  }
   mat->pn_fact = mat->pn;          // provisionally: lpgp_mat_check / lpgp_mat_truncate take it back on failure
   mat->unchecked = 1;
   mat->status_known = 0;
@@ -1283,6 +1299,7 @@ int lpgp_mat_condition(lpgp_ctx* ctx, lpgp_mat* mat, int64_t n, const lpgp_pts* 
   LPGP_CHECK((noise_diag != nullptr) + (noise_dense != nullptr) + (noise_scalar != 0.0) <= 1, "lpgp_mat_condition: more than one form of noise");
   LPGP_CHECK(lazy == 0 || !ctx->distributed(), "lpgp_mat_condition: lazy status on a single GPU only");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_mat_condition");
   if (info) *info = 0;
   // earlier blocks that were only assembled (lazy == 2): another deferred block joins them -- they are factored TOGETHER by
   // whoever needs the factor first, one factorisation from the first unfactored column on (lpgp_potrf_predict: with the
@@ -1410,6 +1427,7 @@ int lpgp_mat_check(lpgp_ctx* ctx, lpgp_mat* mat, int32_t* info, int32_t* block) 
   }
   mat->status_known = 0;
   mat->unchecked = 0;
+  if (h < 0) mat->poisoned = 1;      // (not a pivot: the panel's contents are undefined and the status word stays at INT_MIN, so no later pivot failure could be recorded either)
   LPGP_CHECK(h >= 0, "resident panel chain: a hand-over between workgroups timed out (device status %d); set LPGP_CHAIN_RESIDENT=-1", h);
   *info = h;
   if (h > 0 && block) {
@@ -1443,6 +1461,7 @@ int lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks) {
 int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
   LPGP_CHECK(ctx && mat && b_host && nrhs >= 1, "lpgp_potrs: bad argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_potrs");
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_potrs: matrix is not factored");
   const int64_t pn = mat->pn, n = mat->n, m_pad = round_up(nrhs, TILE);
   double* dv = nullptr;
@@ -1474,6 +1493,7 @@ int lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs) {
 int lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host) {
   LPGP_CHECK(ctx && mat && r_host, "lpgp_solve_weights: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_solve_weights");
   LPGP_CHECK(mat->pn_fact == mat->pn && mat->pn > 0, "lpgp_solve_weights: matrix is not factored");
   const int64_t pn = mat->pn;
   int rc = ensure_tmp(ctx, pn + 2);                 // (+ 2: the ticket words of the resident solve, trsv.hip)
@@ -1544,6 +1564,7 @@ int lpgp_mat_set_residual(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host) {
     mat->has_r = 1;
     return 0;
   }
+  LPGP_CHECK(mat->pn_fact == mat->pn, "lpgp_mat_set_residual: matrix is not factored");      // (this branch has no lpgp_potrf_predict to consume an unfactored one)
   std::vector<double> hp((size_t)mat->pn);
   scatter_padded(mat, r_host, hp.data());
   // NOT on the panel stream: the residual's place in HBM is touched by no kernel of the factorisation, so the upload need
@@ -1709,6 +1730,7 @@ int lpgp_cross_assemble_row(lpgp_ctx* ctx, const lpgp_cross_block* blocks, int32
 int lpgp_trsm_lower(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* V) {
   LPGP_CHECK(ctx && mat && V, "lpgp_trsm_lower: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_trsm_lower");
   LPGP_CHECK(mat->pn_fact == mat->pn && V->ld == mat->pn, "lpgp_trsm_lower: matrix not factored or size mismatch");
   int rc = rhs_clear_unassembled(ctx, mat, V);
   if (rc != 0) return rc;
@@ -1723,6 +1745,7 @@ int lpgp_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* prior_
                  const double* kxx_host, double* mean_host, double* var_host) {
   LPGP_CHECK(ctx && mat && K, "lpgp_predict: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_predict");
   LPGP_CHECK(mat->pn_fact == mat->pn && K->ld == mat->pn, "lpgp_predict: matrix not factored or size mismatch");
   const int64_t m = K->m;
   int rc = ensure_tmp(ctx, 2 * K->m_pad);
@@ -1783,6 +1806,7 @@ int lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* 
                        double* mean_host, double* var_host) {
   LPGP_CHECK(ctx && mat && K && kxx_host && mean_host && var_host, "lpgp_potrf_predict: null argument");
   LPGP_DEVICE(ctx);
+  LPGP_MAT_ALIVE(mat, "lpgp_potrf_predict");
   LPGP_CHECK(!ctx->distributed(), "lpgp_potrf_predict: single GPU only (a multi-GPU job factors collectively: lpgp_potrf, lpgp_predict)");
   LPGP_CHECK(mat->hidden.empty(), "lpgp_potrf_predict: a strict prefix of the blocks is in view");
   LPGP_CHECK(K->ld == mat->pn && mat->pn > 0, "lpgp_potrf_predict: right-hand side built for another matrix size");
@@ -1799,7 +1823,10 @@ int lpgp_potrf_predict(lpgp_ctx* ctx, lpgp_mat* mat, lpgp_rhs* K, const double* 
   const bool fresh = mat->pn_fact < mat->pn;
   ctx->d_info_cur = mat->d_status;
   rc = potrf_predict_blocked(ctx, mat, mat->pn_fact / TILE, mat->pn / TILE, K->v, K->ld, K->m_pad);
-  if (rc != 0) return rc;
+  if (rc != 0) {
+    if (fresh) mat->poisoned = 1;    // (partly factored in place with pn_fact unchanged -- a retry would factor a half-factored matrix)
+    return rc;
+  }
   if (fresh) {
     mat->pn_fact = mat->pn;          // provisionally, as lpgp_potrf_enqueue: lpgp_mat_check / lpgp_mat_truncate take it back on failure
     mat->unchecked = 1;
@@ -1848,6 +1875,104 @@ int lpgp_rhs_inner(lpgp_ctx* ctx, lpgp_rhs* A, lpgp_rhs* B, double* out_host) {
   for (int64_t i = 0; i < A->m; ++i)
     for (int64_t j = 0; j < B->m; ++j) out_host[i * B->m + j] = h[(size_t)(i + j * ma)];
   return 0;
+}
+
+int lpgp_rhs_matmul(lpgp_ctx* ctx, const lpgp_rhs* A, const double* B_host, int64_t m, lpgp_rhs** out_new) {
+  LPGP_CHECK(ctx && A && B_host && out_new && m >= 1, "lpgp_rhs_matmul: bad argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed(), "lpgp_rhs_matmul: single GPU only");
+  // the result shares A's row layout whatever the matrix A was created for has become since (a posterior is a value: later
+  // conditionings extend the shared matrix); every element of it is written by the product (beta = 0): no clearing
+  lpgp_rhs* out = new lpgp_rhs();
+  out->ctx = ctx;
+  out->ld = A->ld;
+  out->m = m;
+  out->m_pad = round_up(m + 1, TILE);
+  out->v = nullptr;
+  {
+    void* pv = nullptr;
+    if (pool_alloc(ctx, &pv, (size_t)out->ld * out->m_pad * sizeof(double), nullptr) != 0) {
+      delete out;
+      return -1;
+    }
+    out->v = (double*)pv;
+  }
+  out->assembled.assign(A->assembled.size(), 1);
+  ++ctx->live_mats;
+  const int64_t ka = A->m_pad, mp = out->m_pad;
+  // B, zero-padded to (columns of A incl. its spare ones) x (columns of out incl. its spare ones), column-major: the spare
+  // columns of A meet zero rows, the spare columns of out come out as zeros
+  std::vector<double> hb((size_t)ka * mp, 0.0);
+  for (int64_t kk = 0; kk < A->m; ++kk)
+    for (int64_t j = 0; j < m; ++j) hb[(size_t)(kk + j * ka)] = B_host[kk * m + j];
+  void* pb = nullptr;
+  const size_t bb = hb.size() * sizeof(double);
+  if (pool_alloc(ctx, &pb, bb, nullptr) != 0) return -1;
+  int rc = 0;
+  if (hipMemcpyAsync(pb, hb.data(), bb, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) rc = -1;
+  if (rc == 0) {
+    GemmArgs g;
+    g.A = A->v; g.B = (const double*)pb; g.C = out->v; g.lda = A->ld; g.ldb = ka; g.ldc = out->ld;
+    g.mt = (int)(out->ld / TILE); g.nt = (int)(mp / TILE); g.k = (int)ka; g.alpha = 1.0; g.beta = 0.0;
+    g.tri = 0;
+    rc = launch_gemm(ctx, ctx->s_main, 0, 1, g, LPGP_K_GEMM);
+  }
+  if (rc == 0 && hipStreamSynchronize(ctx->s_main) != hipSuccess) rc = -1;      // (the staging vector is borrowed by the copy)
+  pool_free(ctx, pb, bb);
+  if (rc != 0) {
+    if (rc == -1) set_error("lpgp_rhs_matmul: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+    (void)lpgp_rhs_destroy(out);
+    return rc;
+  }
+  *out_new = out;
+  return 0;
+}
+
+int lpgp_gemm_host(lpgp_ctx* ctx, int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, double alpha,
+                   const double* A_host, const double* B_host, double beta, double* C_host) {
+  LPGP_CHECK(ctx && A_host && B_host && C_host && m >= 1 && n >= 1 && k >= 1, "lpgp_gemm_host: bad argument");
+  LPGP_DEVICE(ctx);
+  LPGP_CHECK(!ctx->distributed(), "lpgp_gemm_host: single GPU only");
+  // The kernel computes column-major  C' = op(A') op(B')  on whole 128 x 128 tiles.  A C-order m x n result is the column-major
+  // n x m matrix C^T = op(B)^T op(A)^T in the same memory: A' = op(B)^T (n x k), B' = op(A)^T (k x m), both read in place --
+  // a C-order k x n array IS column-major n x k (ta = 0), a C-order n x k one is its k-fastest form (ta = 1); likewise for B'.
+  const int64_t np_ = round_up(n, TILE), mp = round_up(m, TILE), kp = round_up(k, 16);
+  // zero-padded device images (rows beyond the logical extent must be zeros, not stale pool contents: 0 * NaN)
+  const int64_t a_ld = transb ? kp : np_, a_cols = transb ? np_ : kp;     // A' image: leading dimension x columns
+  const int64_t b_ld = transa ? mp : kp, b_cols = transa ? kp : mp;
+  const int64_t a_src_ld = transb ? k : n, a_src_cols = transb ? n : k;   // the host array behind it, as column-major ld x cols
+  const int64_t b_src_ld = transa ? m : k, b_src_cols = transa ? k : m;
+  const size_t ab = (size_t)a_ld * a_cols * sizeof(double), bb = (size_t)b_ld * b_cols * sizeof(double), cb = (size_t)np_ * mp * sizeof(double);
+  void *pa = nullptr, *pb = nullptr, *pc = nullptr;
+  if (pool_alloc(ctx, &pa, ab, nullptr) != 0) return -1;
+  if (pool_alloc(ctx, &pb, bb, nullptr) != 0) { pool_free(ctx, pa, ab); return -1; }
+  if (pool_alloc(ctx, &pc, cb, nullptr) != 0) { pool_free(ctx, pa, ab); pool_free(ctx, pb, bb); return -1; }
+  hipStream_t st = ctx->s_main;
+  int rc = 0;
+  auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == 0) { rc = -1; set_error("lpgp_gemm_host: %s", hipGetErrorString(e)); } };
+  ok(hipMemsetAsync(pa, 0, ab, st));
+  ok(hipMemsetAsync(pb, 0, bb, st));
+  ok(hipMemcpy2DAsync(pa, (size_t)a_ld * sizeof(double), B_host, (size_t)a_src_ld * sizeof(double), (size_t)a_src_ld * sizeof(double), (size_t)a_src_cols,
+                      hipMemcpyHostToDevice, st));
+  ok(hipMemcpy2DAsync(pb, (size_t)b_ld * sizeof(double), A_host, (size_t)b_src_ld * sizeof(double), (size_t)b_src_ld * sizeof(double), (size_t)b_src_cols,
+                      hipMemcpyHostToDevice, st));
+  if (beta != 0.0) {
+    ok(hipMemsetAsync(pc, 0, cb, st));
+    ok(hipMemcpy2DAsync(pc, (size_t)np_ * sizeof(double), C_host, (size_t)n * sizeof(double), (size_t)n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, st));
+  }
+  if (rc == 0) {
+    GemmArgs g;
+    g.A = (const double*)pa; g.B = (const double*)pb; g.C = (double*)pc; g.lda = a_ld; g.ldb = b_ld; g.ldc = np_;
+    g.mt = (int)(np_ / TILE); g.nt = (int)(mp / TILE); g.k = (int)kp; g.alpha = alpha; g.beta = beta;
+    g.tri = 0;
+    rc = launch_gemm(ctx, st, transb ? 1 : 0, transa ? 0 : 1, g, LPGP_K_GEMM);
+  }
+  if (rc == 0) ok(hipMemcpy2DAsync(C_host, (size_t)n * sizeof(double), pc, (size_t)np_ * sizeof(double), (size_t)n * sizeof(double), (size_t)m, hipMemcpyDeviceToHost, st));
+  if (hipStreamSynchronize(st) != hipSuccess && rc == 0) { rc = -1; set_error("lpgp_gemm_host: synchronisation failed"); }
+  pool_free(ctx, pa, ab);
+  pool_free(ctx, pb, bb);
+  pool_free(ctx, pc, cb);
+  return rc;
 }
 
 int lpgp_rhs_to_host(lpgp_ctx* ctx, const lpgp_mat* mat, lpgp_rhs* rhs, double* out_host) {

@@ -267,6 +267,8 @@ struct lpgp_mat {
   int unchecked = 0;               // a factorisation was enqueued (lpgp_potrf_enqueue) and its status not read yet
   int status_known = 0;            // lpgp_potrf_predict read the status word back with its results: lpgp_mat_check needs no copy
   int status_value = 0;
+  int poisoned = 0;                // a factorisation of this matrix ended undefined -- a hand-over of a resident kernel timed out (device status < 0), or a
+                                   // launch failed half way through the in-place factorisation: every entry point that reads or extends the factor fails from then on
   double* r() const { return w + cap; }
 };
 
@@ -282,6 +284,10 @@ struct lpgp_rhs {
 namespace lpgp {
 
 // every C-ABI entry point runs on its context's device whatever the calling thread's current device is
+// (a negative status used to be reported ONCE -- lpgp_mat_check cleared `unchecked` first -- and the next prediction ran on a garbage factor)
+#define LPGP_MAT_ALIVE(mat, fn) \
+  LPGP_CHECK(!(mat)->poisoned, fn ": the factor of this matrix is undefined (an earlier factorisation timed out or failed half way); condition again from the prior")
+
 #define LPGP_DEVICE(ctx)                                        \
   do {                                                          \
     LPGP_CHECK((ctx) != nullptr, "null context handle");        \

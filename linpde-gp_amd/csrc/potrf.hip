@@ -514,6 +514,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
   LPGP_HIP(hipMemcpyAsync(hp, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sP));
   LPGP_HIP(hipStreamSynchronize(sP));
   const int h_info = *hp;
+  if (h_info < 0) mat->poisoned = 1;
   LPGP_CHECK(h_info >= 0, "resident panel chain: a hand-over between workgroups timed out (device status %d); set LPGP_CHAIN_RESIDENT=-1", h_info);
   *info = h_info;
   return 0;

@@ -244,4 +244,15 @@ int lpgp_probe_hbm_write(lpgp_ctx* ctx, int64_t bytes, double* gbps) {
   return 0;
 }
 
+// the status word of `mat` as an enqueued factorisation that ended with `value` would leave it (value < 0: a timed-out hand-over)
+int lpgp_test_force_status(lpgp_ctx* ctx, lpgp_mat* mat, int32_t value) {
+  LPGP_CHECK(ctx && mat, "lpgp_test_force_status: null argument");
+  LPGP_DEVICE(ctx);
+  LPGP_HIP(hipStreamSynchronize(ctx->s_main));
+  LPGP_HIP(hipMemcpy(mat->d_status, &value, sizeof(int), hipMemcpyHostToDevice));
+  mat->unchecked = 1;
+  mat->status_known = 0;
+  return 0;
+}
+
 }  // extern "C"

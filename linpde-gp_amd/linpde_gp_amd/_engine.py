@@ -535,6 +535,17 @@ class Rhs:
         check(lib.lpgp_rhs_inner(self.ctx._h, self._h, other._h, as_pd(out)), "lpgp_rhs_inner")
         return out
 
+    def matmul(self, B: np.ndarray) -> "Rhs":
+        """A new block  self[:, :m] @ B  (B: m x k on the host) with the same row layout (`lpgp_rhs_matmul`)."""
+        B = np.ascontiguousarray(B, dtype=np.double)
+        if B.ndim != 2 or B.shape[0] != self.m:
+            raise ValueError(f"shape mismatch: ({self.mat.n}, {self.m}) @ {B.shape}")
+        h = C.c_void_p()
+        check(lib.lpgp_rhs_matmul(self.ctx._h, self._h, as_pd(B), B.shape[1], C.byref(h)), "lpgp_rhs_matmul")
+        out = Rhs.__new__(Rhs)
+        out.ctx, out.mat, out.m, out._h = self.ctx, self.mat, int(B.shape[1]), h
+        return out
+
     def to_host(self) -> np.ndarray:
         out = np.empty((self.mat.n, self.m))
         check(lib.lpgp_rhs_to_host(self.ctx._h, self.mat._h, self._h, as_pd(out)), "lpgp_rhs_to_host")
@@ -550,6 +561,33 @@ def lowered_array(kdesc):
     """The C-ABI form of a lowered kernel, built once: callers that assemble the same block structure again and again
     (a chain of conditionings, one posterior per step of a sweep) keep it instead of the Python description."""
     return _lib.make_kdesc_array(kdesc)
+
+
+def gemm(ctx: Context, A: np.ndarray, B: np.ndarray, *, transa: bool = False, transb: bool = False, alpha: float = 1.0,
+         beta: float = 0.0, C: np.ndarray | None = None) -> np.ndarray:
+    """alpha op(A) op(B) + beta C  on the device's fp64 MFMA kernel (`lpgp_gemm_host`): the dense products the reference leaves
+    to NumPy around the path (`randvars/_normal.py:8-71`, `gram.todense()`).  Host arrays in, a fresh host array out."""
+    A = np.ascontiguousarray(A, dtype=np.double)
+    B = np.ascontiguousarray(B, dtype=np.double)
+    if A.ndim != 2 or B.ndim != 2:
+        raise ValueError("`gemm` needs two matrices")
+    m, k = (A.shape[1], A.shape[0]) if transa else A.shape
+    k2, n = (B.shape[1], B.shape[0]) if transb else B.shape
+    if k != k2:
+        raise ValueError(f"shape mismatch: op(A) is {m} x {k}, op(B) is {k2} x {n}")
+    if beta != 0.0:
+        if C is None or C.shape != (m, n):
+            raise ValueError("`beta != 0` needs C of the result's shape")
+        out = np.array(C, dtype=np.double, order="C", copy=True)
+    else:
+        out = np.empty((m, n))
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out * beta if beta != 0.0 else np.zeros((m, n))
+    check(lib.lpgp_gemm_host(ctx._h, int(transa), int(transb), m, n, k, float(alpha), as_pd(A), as_pd(B), float(beta), as_pd(out)),
+          "lpgp_gemm_host")
+    return out
 
 
 def kernel_diag(ctx: Context, kdesc) -> float:

@@ -122,6 +122,8 @@ def _load() -> C.CDLL:
     sig("lpgp_potrf_predict", C.c_int, vp, vp, vp, pd, pd, pd, pd)
     sig("lpgp_trsm_lower", C.c_int, vp, vp, vp)
     sig("lpgp_rhs_inner", C.c_int, vp, vp, vp, pd)
+    sig("lpgp_rhs_matmul", C.c_int, vp, vp, pd, C.c_int64, C.POINTER(vp))
+    sig("lpgp_gemm_host", C.c_int, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_double, pd, pd, C.c_double, pd)
     sig("lpgp_rhs_to_host", C.c_int, vp, vp, vp, pd)
     sig("lpgp_kernel_diag", C.c_int, vp, pk, i32, pd)
     sig("lpgp_kernel_matrix", C.c_int, vp, pk, i32, vp, vp, pd)
@@ -144,7 +146,7 @@ EXPORTED = [
     "lpgp_mat_num_blocks_total", "lpgp_mat_clone", "lpgp_mat_size", "lpgp_mat_padded_size",
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
-    "lpgp_cross_assemble", "lpgp_cross_assemble_row", "lpgp_predict", "lpgp_potrf_predict", "lpgp_trsm_lower", "lpgp_rhs_inner",
+    "lpgp_cross_assemble", "lpgp_cross_assemble_row", "lpgp_predict", "lpgp_potrf_predict", "lpgp_trsm_lower", "lpgp_rhs_inner", "lpgp_rhs_matmul", "lpgp_gemm_host",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_kron_fits", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get",
     ]

@@ -138,7 +138,7 @@ class _GramOperator:
 
     def todense(self):
         Lf = self.cholesky(True)
-        return Lf @ Lf.T
+        return _engine.gemm(self._cgp._state.ctx, Lf, Lf, transb=True)      # L L^T on the device (round 6; an O(n^3) NumPy product until then)
 
     def logabsdet(self) -> float:
         """log det G = 2 sum_i log L_ii from the diagonal of the resident factor (`lpgp_mat_factor_diag`)."""
@@ -261,7 +261,16 @@ class _DeviceState:
         if not self.pending:
             return
         self.pending = False
-        info, block = self.mat.check()
+        try:
+            info, block = self.mat.check()
+        except _engine._lib.LpgpError as exc:
+            # not a pivot: a hand-over inside a resident kernel timed out and the factor is undefined (the library keeps the
+            # matrix marked so, every later call on it fails).  EVERY object of the chain is dead from here on -- ADVICE r5: the
+            # error used to be raised once, and the next `predict` ran on the garbage factor as if it had been verified
+            self.failure = str(exc)
+            del self.blocks[:]
+            self.invalidate()
+            raise
         if info == 0:
             return
         self.failure = f"{info}-th leading minor of the (padded) Gram matrix is not positive definite"
@@ -619,8 +628,9 @@ class ConditionalGaussianProcess(GaussianProcess):
         if fuse:
             self._ensure_residual()
             kxx = np.full(X.shape[0], self._prior_diag())
+            out = rhs.potrf_predict(pm, kxx)          # (a failing call leaves the block deferred: nothing has been factored -- or the matrix is marked undefined)
             st.deferred, st.deferred_rows = False, 0
-            return rhs.potrf_predict(pm, kxx)
+            return out
         if return_var and self._representer_weights is None:
             self._ensure_residual()
         else:
@@ -716,6 +726,12 @@ class _PosteriorCovarianceFunction(covfuncs.CovarianceFunction):
             V1.trsm_lower()
         return k_xx - V0.inner(V1)
 
+    def linop(self, x0, x1=None) -> "PosteriorCovarianceOperator":
+        """The posterior covariance between two point sets AS A LINEAR OPERATOR (`_conditional.py:245-251`:
+        `k_xx - kLas_x0 @ gram.solve(kLas_x1.T)` built from probnum linear operators): products run on the device and the
+        n0 x n1 matrix never exists; `.T` and `todense()` as the callers of a `LinearOperator` expect."""
+        return PosteriorCovarianceOperator(self._cgp, x0, x1)
+
     def __call__(self, x0, x1=None):
         if x1 is None:
             return self._cgp.var(x0)
@@ -726,6 +742,64 @@ class _PosteriorCovarianceFunction(covfuncs.CovarianceFunction):
         i0 = np.broadcast_to(np.arange(X0.shape[0]).reshape(b0), out_shape)
         i1 = np.broadcast_to(np.arange(X1.shape[0]).reshape(b1), out_shape)
         return K[i0, i1]
+
+
+class PosteriorCovarianceOperator:
+    """`Sigma(x0, x1) = k(x0, x1) - K_x0X G^{-1} K_Xx1` as a matrix-free operator (`_conditional.py:245-251`).
+
+    Resident on the device: V0 = L^{-1} K_Xx0 and V1 = L^{-1} K_Xx1 (one forward substitution each, at construction; the same
+    block when x1 is x0).  A product is  k(x0, x1) @ V  -- every kernel entry evaluated on the fly, `lpgp_kernel_matvec` --
+    minus  V0^T (V1 V)  -- two MFMA products, `lpgp_rhs_matmul` and `lpgp_rhs_inner`: O((n0 + n1) N m) work and no n0 x n1
+    array anywhere.  The operator is a value like the posterior it belongs to: later conditionings of that posterior do not
+    change it."""
+
+    def __init__(self, cgp: "ConditionalGaussianProcess", x0, x1=None, _parts=None):
+        self.dtype = np.dtype(np.double)
+        if _parts is not None:
+            self._kop, self._V0, self._V1, self.shape = _parts
+            return
+        cgp._check_current()
+        X0, b0 = cgp._flat(x0)
+        X1, b1 = (X0, b0) if x1 is None else cgp._flat(x1)
+        if len(b0) != 1 or len(b1) != 1:
+            raise ValueError("`linop` needs inputs of shape (N,) + input_shape")
+        base = cgp._prior.cov
+        kxx_f = covfuncs.DifferentiatedCovarianceFunction(covfuncs._base(base), *_combine(base, cgp._test_coeffs, cgp._test_coeffs))
+        a0 = X0 if cgp.input_ndim else X0[:, 0]
+        a1 = a0 if x1 is None else (X1 if cgp.input_ndim else X1[:, 0])
+        self._kop = covfuncs.KernelLinearOperator(kxx_f, a0, a1)
+        self.shape = (X0.shape[0], X1.shape[0])
+        self._V0 = self._V1 = None
+        if cgp._blocks and X0.shape[0] and X1.shape[0]:
+            self._V0 = cgp._cross(self._kop._P0)
+            self._V0.trsm_lower()
+            if x1 is None:
+                self._V1 = self._V0
+            else:
+                self._V1 = cgp._cross(self._kop._P1)
+                self._V1.trsm_lower()
+
+    def __matmul__(self, V):
+        V = np.asarray(V, dtype=np.double)
+        if V.ndim not in (1, 2) or V.shape[0] != self.shape[1]:
+            raise ValueError(f"shape mismatch: {self.shape} @ {V.shape}")
+        V2 = V[:, None] if V.ndim == 1 else V
+        if self.shape[0] == 0 or self.shape[1] == 0 or V2.shape[1] == 0:
+            return np.zeros((self.shape[0],) + V.shape[1:])
+        out = self._kop @ V2
+        if self._V0 is not None:
+            out = out - self._V0.inner(self._V1.matmul(V2))
+        return out[:, 0] if V.ndim == 1 else out
+
+    matmul = __matmul__
+
+    @property
+    def T(self) -> "PosteriorCovarianceOperator":
+        return PosteriorCovarianceOperator(None, None, _parts=(self._kop.T, self._V1, self._V0, self.shape[::-1]))
+
+    def todense(self) -> np.ndarray:
+        K = self._kop.todense()
+        return K if self._V0 is None else K - self._V0.inner(self._V1)
 
 
 # ---- L(posterior) read-outs (`_conditional.py:432-467`) -------------------------------------

@@ -336,6 +336,12 @@ class _TransposedKernelOperator:
             raise ValueError(f"shape mismatch: {self.shape} @ {V.shape}")
         return _engine.kernel_matvec(self._op._ctx, self._desc, self._op._P1, self._op._P0, V)
 
+    matmul = __matmul__
+
+    @property
+    def T(self):
+        return self._op
+
     def todense(self):
         return self._op.todense().T
 

@@ -117,16 +117,17 @@ def condition_normal_on_observations(prior: Normal, observations, noise: Normal 
             noise = Normal(np.asarray(noise.mean).reshape(1), np.asarray(noise.cov).reshape(1, 1))
     mu0 = np.asarray(prior.mean, dtype=np.double).reshape(-1)
     S0 = np.asarray(prior.cov, dtype=np.double).reshape(mu0.size, mu0.size)
-    crosscov = S0 if A is None else A @ S0                      # Cov(y, x), (n_obs, n)
+    ctx = _engine.default_context()
+    # (the three dense products of the update run on the device's MFMA kernel since round 6 -- `lpgp_gemm_host`; NumPy until then)
+    crosscov = S0 if A is None else _engine.gemm(ctx, A, S0)     # Cov(y, x), (n_obs, n)
     pred_mean = mu0 if A is None else A @ mu0
-    pred_cov = S0 if A is None else crosscov @ A.T
+    pred_cov = S0 if A is None else _engine.gemm(ctx, crosscov, A, transb=True)
     if noise is not None:
         pred_mean = pred_mean + np.asarray(noise.mean, dtype=np.double).reshape(-1)
         pred_cov = pred_cov + np.asarray(noise.cov, dtype=np.double).reshape(pred_cov.shape)
     n_obs = pred_mean.size
     if observations.reshape(-1).size != n_obs:
         raise ValueError(f"expected {n_obs} observations, got shape {observations.shape}")
-    ctx = _engine.default_context()
     mat = _engine.GramMatrix(ctx, n_obs)
     bi = mat.add_block(n_obs)
     pts = _engine.Points(ctx, np.zeros((n_obs, 1)))
@@ -139,7 +140,8 @@ def condition_normal_on_observations(prior: Normal, observations, noise: Normal 
     rhs = np.concatenate([crosscov, (observations.reshape(-1) - pred_mean)[:, None]], axis=1)
     sol = mat.potrs(rhs)
     gain_t, w = sol[:, :-1], sol[:, -1]
-    return Normal(mean=(mu0 + crosscov.T @ w).reshape(np.shape(prior.mean)), cov=S0 - crosscov.T @ gain_t)
+    return Normal(mean=(mu0 + crosscov.T @ w).reshape(np.shape(prior.mean)),
+                  cov=_engine.gemm(ctx, crosscov, gain_t, transa=True, alpha=-1.0, beta=1.0, C=S0))
 
 
 Normal.condition_on_observations = condition_normal_on_observations

@@ -17,7 +17,7 @@ from linpde_gp_amd._lib import check
 HOOKS_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "liblpgp_testhooks.so")
 
 EXPORTED = ["lpgp_test_stair_enumerate", "lpgp_test_gemm", "lpgp_test_potrf_tile", "lpgp_test_tile_step", "lpgp_test_panel_solve",
-            "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64", "lpgp_probe_hbm_write"]
+            "lpgp_debug_tile_xcc", "lpgp_probe_mfma_f64", "lpgp_probe_hbm_write", "lpgp_test_force_status"]
 
 
 def _load() -> C.CDLL:
@@ -40,6 +40,7 @@ def _load() -> C.CDLL:
     sig("lpgp_test_panel_solve", C.c_int, vp, i32, pd, i32, i64, pd, pd, pd)
     sig("lpgp_probe_mfma_f64", C.c_int, vp, pd)
     sig("lpgp_probe_hbm_write", C.c_int, vp, i64, pd)
+    sig("lpgp_test_force_status", C.c_int, vp, vp, i32)
     return lib
 
 
@@ -114,3 +115,8 @@ def test_potrf_tile(ctx: Context, T: np.ndarray):
     check(lib.lpgp_test_potrf_tile(ctx._h, T.ctypes.data_as(pd), Linv.ctypes.data_as(pd), C.byref(info)),
           "lpgp_test_potrf_tile")
     return T, Linv, info.value
+
+
+def force_status(ctx: Context, mat, value: int) -> None:
+    """Leave the status word of `mat` (a `_engine.GramMatrix`) as an enqueued factorisation ending with `value` would."""
+    check(lib.lpgp_test_force_status(ctx._h, mat._h, int(value)), "lpgp_test_force_status")

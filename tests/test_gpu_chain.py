@@ -80,3 +80,37 @@ def test_resident_chain_in_an_appended_block(ctx):
     m, v = u.predict(Xt)
     assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
     assert np.max(np.abs(v - post.var(Xt))) <= 1e-8 * np.max(np.abs(post.var(Xt)))
+
+
+def test_a_timed_out_hand_over_kills_the_chain_for_good(ctx):
+    """a negative device status (a hand-over inside a resident kernel timed out: the panel's contents are undefined)
+    was reported ONCE -- `lpgp_mat_check` cleared `unchecked` before failing, `verify` cleared `pending` before the check raised --
+    and the next `predict` ran on the garbage factor as if it had been verified.  Now the library keeps the matrix marked undefined
+    and every object of the chain raises from then on.  The status is forced through a test hook (a real time-out needs a
+    serialising profiler)."""
+    import linpde_gp_amd as lp
+    import _hooks
+    from linpde_gp_amd._lib import LpgpError
+    prior, okern, X, Y, b = _posterior(lp, 700, seed=2)
+    Xt = np.random.default_rng(1).uniform(-1, 1, (9, 2))
+    lp.config.lazy_factorization = True
+    try:
+        u = prior.condition_on_observations(Y, X, b=b)
+        u._state.flush()                                        # enqueued, status not read yet
+        assert u._state.pending
+        _hooks.force_status(ctx, u._state.mat, -(2**31))
+        with pytest.raises(LpgpError, match="timed out"):
+            u.predict(Xt)
+        # the second use does not run on the undefined factor: the object is dead, the library refuses the matrix
+        with pytest.raises(np.linalg.LinAlgError, match="timed out"):
+            u.predict(Xt)
+        with pytest.raises(np.linalg.LinAlgError):
+            u.condition_on_observations(Y[:5], X[:5] + 0.01, b=lp.randvars.Normal(np.zeros(5), 1e-3 * np.eye(5)))
+        with pytest.raises(LpgpError, match="undefined"):
+            u._state.mat.solve_weights(Y)
+        # the prior is untouched: a fresh conditioning works
+        m, v = prior.condition_on_observations(Y, X, b=b).predict(Xt)
+        post = ogp.condition(okern, [ogp.ObsBlock(X, ocf.identity(2), Y, 0.0, 1e-3)])
+        assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
+    finally:
+        lp.config.lazy_factorization = False
