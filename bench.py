@@ -488,6 +488,10 @@ def main():
     skipped_trials = []
     if distributed and world >= 4 and world % 2 == 0 and not pinned:
         variants = [("Px1_p2p_split", (world, 1), 0), ("P/2x2_p2p", (world // 2, 2), 0), ("Px1_bcast", (world, 1), 1)]
+        if world == 8:
+            # north_star's own grid first (BASELINE.json: "2D block-cyclic tiles across the 8 GPUs", SURVEY section 8e: Pr x Pc = 2 x 4), so that
+            # a budget that cuts the list still measures it; the product's default (P x 1: one exchange per panel, lpgp.h) second
+            variants = [("2x4_p2p", (2, 4), 0), ("Px1_p2p_split", (8, 1), 0), ("P/2x2_p2p", (4, 2), 0), ("Px1_bcast", (8, 1), 1)]
         trials = {}
         lp.config.gram_capacity_hint = wl.n_total
         last_cost = 0.0
@@ -495,6 +499,7 @@ def main():
             left = budget_left()
             if trials and left < 1.5 * last_cost:          # the first variant always runs (it is the default configuration's warm-up anyway)
                 skipped_trials.append({"variant": name, "reason": f"{left:.0f} s of the {budget_s:.0f}-s calibration budget left, the previous trial took {last_cost:.0f} s"})
+                trials[name] = {"grid": list(grid), "collective": "bcast" if bc else "p2p", "ms_per_step": None, "skipped": skipped_trials[-1]["reason"]}
                 continue
             t_tr = time.time()
             ctx.dist_set_grid(*grid)
@@ -507,13 +512,15 @@ def main():
             del dev_t, prior_t, last_t          # every matrix of this grid must be gone before the next lpgp_dist_set_grid
             gc.collect()
             last_cost = comm.allreduce_max(time.time() - t_tr)
-        chosen = min(trials, key=lambda k_: trials[k_]["ms_per_step"])
+        chosen = min((k_ for k_ in trials if trials[k_]["ms_per_step"] is not None), key=lambda k_: trials[k_]["ms_per_step"])
         _, grid, bc = next(v for v in variants if v[0] == chosen)
         ctx.dist_set_grid(*grid)
         ctx.set_option("dist_bcast", bc)
     calibration_s = time.time() - t_cal0
 
-    lp.config.gram_capacity_hint = wl.n_total
+    # (the augmented form of the fused pipeline keeps the prediction's right-hand side as ROWS below the matrix's blocks: room for them)
+    aug_rows = ((wl.Xtest.shape[0] + 1 + 127) // 128) * 128 if (not distributed and ctx.get_option("ride_aug")) else 0
+    lp.config.gram_capacity_hint = ((wl.n_total + 127) // 128) * 128 + 128 * len(wl.observations) + aug_rows if aug_rows else wl.n_total
     dev = problems.upload(wl)                # point sets resident in HBM before timing
     prior = problems.build_prior(wl)
 
@@ -536,6 +543,26 @@ def main():
     phase_rows = comm.gather([min(p_[0] for p_ in ph) * 1e3, min(p_[1] for p_ in ph) * 1e3])
 
     # ---- what a user of the reference would call, and what it costs (N = 1) ----
+    # The schedule of the timed region, by name, and the step time of the TWO-PIPELINE schedule beside it on every line: multi-GPU jobs
+    # always run the two pipelines (the ranks agree on the factorisation's status inside the conditioning; lpgp_potrf_predict is
+    # single-GPU), so a scaling curve must be read against `two_pipeline_ms_per_step` of the N = 1 line, not against its fused
+    # `ms_per_step`.
+    mode_name = "two_pipelines" if (distributed or not bench_lazy) else "fused_factor_and_predict"
+    two_pipeline_ms = dt / args.steps * 1e3 if mode_name == "two_pipelines" else None
+    if two_pipeline_ms is None:
+        saved_lazy = lp.config.lazy_factorization
+        try:
+            lp.config.lazy_factorization = False
+            step(); ctx.sync()
+            k_tp = max(3, min(args.steps, 10))
+            t0_tp = time.perf_counter()
+            for _ in range(k_tp):
+                last_tp = step()
+            ctx.sync()
+            two_pipeline_ms = (time.perf_counter() - t0_tp) / k_tp * 1e3
+            del last_tp
+        finally:
+            lp.config.lazy_factorization = saved_lazy
     modes, ref_seq, e2e = None, None, None
     if world == 1 and not os.environ.get("LPGP_BENCH_NO_MODES"):
         k_m = max(3, min(args.steps, 10))
@@ -841,6 +868,9 @@ def main():
                              "the two phases add up to more than ms_per_step); best of two, max over ranks"},
         "posterior": {"mean_max": float(np.max(mean)), "var_min": float(np.min(var)), "var_max": float(np.max(var))},
     }
+    out["mode"] = mode_name
+    out["two_pipeline_ms_per_step"] = two_pipeline_ms
+    out["two_pipeline_value"] = (world if replicas else 1) * flops / (two_pipeline_ms * 1e-3) / 1e9
     out["config"]["lazy_factorization"] = bool(lp.config.lazy_factorization) and not distributed
     out["config"]["fused_factor_and_predict"] = bool(lp.config.lazy_factorization) and not distributed
     if modes is not None:

@@ -407,6 +407,7 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_AUG")) ctx->ride_aug = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   // A profiler that SERIALISES kernels (rocprofv3 --pmc / counter groups: ROCPROF_COUNTER_COLLECTION) breaks the one assumption of
   // the follower -- that its chain kernel is dispatched beside it: it would wait out its poll limit, ~1 s per panel, and the step
@@ -590,6 +591,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "trsv_resident") == 0) *value = ctx->trsv_resident;
   else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
+  else if (std::strcmp(key, "ride_aug") == 0) *value = ctx->ride_aug;
   else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
   else if (std::strcmp(key, "ride_outer_rows") == 0) *value = ctx->ride_outer_rows;
   else if (std::strcmp(key, "ride_outer_min_tiles") == 0) *value = ctx->ride_outer_min_tiles;
@@ -676,6 +678,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->ride_vchain_max_wgs = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {
     ctx->ride_occ3 = value != 0;
+  } else if (std::strcmp(key, "ride_aug") == 0) {
+    ctx->ride_aug = (int)value;
   } else if (std::strcmp(key, "ride_gate_pct") == 0) {
     ctx->ride_gate_pct = (int)value;
   } else if (std::strcmp(key, "ride_outer_rows") == 0) {

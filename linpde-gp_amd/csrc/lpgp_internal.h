@@ -98,6 +98,7 @@ struct lpgp_ctx {
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
   int ride_old_ungated = 1;            // ... the steps of old panels (block append) are not held back by the gate
   int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
+  int ride_aug = 0;                    // ... or, where the matrix has room for it, as ROWS of the matrix being factored (potrf.hip: augmented form; LPGP_RIDE_AUG)
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
   // ONE launch whose workgroups hand over through device flags (-1: never)
   int chain_resident_max_rows = 32;

@@ -224,7 +224,9 @@ static int ride_panel_now(lpgp_ctx* ctx, lpgp_mat* mat, int T, int p0, int p1, R
 // matrix).  `dep`: event behind the last write to columns [c0 + nb, cl) by an earlier launch on
 // another stream (null: none); the first panel chain does not wait for it, the first update does.
 // On return the panel stream is behind every update of the call.
-static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, hipStream_t sU, hipEvent_t dep, Ride* ride) {
+// TR >= T: the matrix has TR tile ROWS (rows beyond tile T belong to a block that is solved and updated but never factored: the
+// augmented form of potrf_predict_blocked); T stays the limit of the COLUMNS.
+static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, hipStream_t sU, hipEvent_t dep, Ride* ride, int TR) {
   const int64_t ld = mat->cap;
   double* a = mat->a;
   const int nbt = (int)(ctx->nb / TILE);
@@ -252,22 +254,22 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       dep_pending_p = false;
     }
     // panel factorisation on sP: the resident chain (one launch, chain.hip) where the chain is what bounds the pipeline ...
-    const bool resident = ctx->chain_resident_max_rows >= 0 && p1 - p0 == 4 && T - p1 <= ctx->chain_resident_max_rows && !ctx->distributed();
+    const bool resident = ctx->chain_resident_max_rows >= 0 && p1 - p0 == 4 && TR - p1 <= ctx->chain_resident_max_rows && !ctx->distributed();
     if (resident) {
       if (ride && ride->stream != sP && ctx->ride_vchain_pre) LPGP_HIP(hipEventRecord(ctx->ev_chain_pre, sP));      // (see ride_panel_now: the step that follows the chain's flags)
-      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, T, ctx->d_info_cur));
+      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, TR, ctx->d_info_cur));
     }
     // ... else tile by tile
     for (int jt = p0; jt < p1 && !resident; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
       double* linv = mat->linv + (int64_t)jt * tb * tb;
       LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info_cur, jt * TILE));
-      if (jt + 1 < T) {
+      if (jt + 1 < TR) {
         double* X = dj + tb;     // rows below, same tile column
-        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, T - jt - 1));
+        LPGP_TRY(panel_trsm(ctx, sP, mat, jt, X, TR - jt - 1));
         if (jt + 1 < p1)
           LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                               mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, T - jt - 1,
+                               mk(X, ld, X, ld, a + (int64_t)(jt + 1) * tb * (ld + 1), ld, TR - jt - 1,
                                   p1 - jt - 1, TILE, -1.0, 1.0, 2),
                                LPGP_K_SYRK_PANEL));
       }
@@ -282,7 +284,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     }
     if (!la) {
       LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, cl - p1, K, -1.0, 1.0, 1),
+                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, TR - p1, cl - p1, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
       p0 = p1;
       continue;
@@ -291,7 +293,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     const int p2 = (p1 + w1 < cl) ? p1 + w1 : cl;
     // Estimated duration of the remainder update (b) at 50 TFLOP/s against that of the next panel
     // chain: decides who bounds the pipeline from here on.
-    const double remc = (double)(cl - p2), remr = (double)(T - p2);          // (b): remr x remc lower trapezoid
+    const double remc = (double)(cl - p2), remr = (double)(TR - p2);         // (b): remr x remc lower trapezoid
     const double t_b_us = (remr * remc - 0.5 * remc * (remc - 1.0)) * (2.0 * TILE * TILE * (double)K / 50e6);
     const double t_chain_us = ctx->chain_us_tile * (double)(p2 - p1) + ctx->chain_us_fixed;
     const bool chain_bound = t_b_us < t_chain_us;
@@ -305,7 +307,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     // (a) next panel's columns on sP; they were last written by the previous remainder update
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
     LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, T - p1, p2 - p1, K, -1.0, 1.0, 3),
+                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, TR - p1, p2 - p1, K, -1.0, 1.0, 3),
                          LPGP_K_SYRK_AHEAD));
     if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
     // (b) remainder on an update stream.  Once its estimated duration even on the narrow stream
@@ -324,7 +326,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       }
       const double* P2 = a + (int64_t)p2 * tb + (int64_t)p0 * tb * ld;
       LPGP_HIP(hipStreamWaitEvent(sB, evp, 0));
-      GemmArgs gb = mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, T - p2, cl - p2, K, -1.0, 1.0, 1);
+      GemmArgs gb = mk(P2, ld, P2, ld, a + (int64_t)p2 * tb * (ld + 1), ld, TR - p2, cl - p2, K, -1.0, 1.0, 1);
       gb.occ3 = t_b_us > ctx->gemm3_margin * t_chain_us;       // (with gemm3_fact: three workgroups per CU only while the chain beside it has slack)
       LPGP_TRY(launch_gemm(ctx, sB, 0, 0, gb, LPGP_K_SYRK));
       LPGP_HIP(hipEventRecord(ctx->ev_upd[it & 1], sB));
@@ -341,9 +343,29 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
 }
 
 // Factor tile columns [t_done, T) of the padded matrix; columns [0, t_done) already hold L.
-static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride);
+static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride, int TR = 0);
 int potrf_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info) {
   return potrf_blocked_impl(ctx, mat, t_done64, T64, info, nullptr);
+}
+
+// dst[c + r * ldd] = src[r + c * lds] for r < rows, c < cols (both multiples of 32): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src, int64_t lds) {
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[ty + 8 * k][tx] = src[r0 + tx + (c0 + ty + 8 * k) * lds];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[c0 + tx + (r0 + ty + 8 * k) * ldd] = t[tx][ty + 8 * k];
+}
+static int transpose(hipStream_t st, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) {
+  for (int64_t c0 = 0; c0 < cols; c0 += 32 * 65535) {
+    const int64_t nc = std::min<int64_t>(cols - c0, 32 * 65535);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(rows / 32), (unsigned)(nc / 32)), dim3(256), 0, st, dst + c0, ldd, src + c0 * lds, lds);
+  }
+  LPGP_HIP(hipGetLastError());
+  return 0;
 }
 
 // The factorisation of tile columns [t_done, T) with the forward substitution of `v` (T * 128 rows x m_pad columns, leading
@@ -380,6 +402,17 @@ int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t 
     // nothing left to factor: the plain substitution
     return trsm_lower_blocked(ctx, mat, T, v, ldv, m_pad);
   }
+  if (ctx->ride_aug && (T + rd.mtl) * (int64_t)TILE <= mat->cap && !ctx->single_stream) {
+    // AUGMENTED form (round 6, option ride_aug): V^T = K_xX L^{-T} are ROWS of the matrix being factored -- the Cholesky of
+    // [G; K_xX] without its last diagonal block (BlockMatrix2x2.L_A_inv_B, linops/_block.py:203-207, read row-wise).  The
+    // substitution's updates then are tiles of the factorisation's own trailing-update launches (ONE grid, no second claimant
+    // of the chip) and its panel steps rows of the panel chain's tile solves.  K_Xx is transposed into the free rows below the
+    // matrix's blocks and back: 2 x 8 N M bytes through HBM.
+    double* vt = mat->a + T * (int64_t)TILE;
+    LPGP_TRY(transpose(ctx->s_main, vt, mat->cap, v, ldv, T * (int64_t)TILE, m_pad));
+    LPGP_TRY(potrf_blocked_impl(ctx, mat, t_done, T, nullptr, nullptr, (int)T + rd.mtl));
+    return transpose(ctx->s_main, v, ldv, vt, mat->cap, m_pad, T * (int64_t)TILE);
+  }
   if (T >= ctx->ride_max_tiles) {
     // very large factors: the two pipelines back to back (no host synchronisation in between).  At c4 (520 tile rows, 129 tile
     // columns of right-hand side) the factorisation's outer updates with K = 2 048 and the substitution's with K = 4 096 have
@@ -400,8 +433,9 @@ int potrf_predict_blocked(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done, int64_t 
   return 0;
 }
 
-static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride) {
+static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, int64_t T64, int32_t* info, Ride* ride, int TR) {
   const int T = (int)T64, t_done = (int)t_done64;
+  if (TR < T) TR = T;                                 // (TR > T: rows beyond the columns being factored, see factor_columns)
   const int64_t ld = mat->cap;
   double* a = mat->a;
   const int nbt = (int)(ctx->nb / TILE);
@@ -414,7 +448,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
 
   // ---- phase A (append): push the new rows through the already factored columns ----
   if (t_done > 0 && T > t_done) {
-    const int mnew = T - t_done;
+    const int mnew = TR - t_done;
     double* rows = a + (int64_t)t_done * tb;          // row offset of the new rows
     for (int p0 = 0; p0 < t_done; p0 += nbt) {
       const int p1 = (p0 + nbt < t_done) ? p0 + nbt : t_done;
@@ -441,7 +475,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
                                 rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
                              LPGP_K_GEMM));
       LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                           mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, mnew, K, -1.0, 1.0, 1),
+                           mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, T - t_done, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
     }
   }
@@ -471,7 +505,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
   for (int q0 = t_done; q0 < T; ++oit) {
     const bool outer = la && NBt > nbt && (T - q0) > ctx->nb_outer_min_tiles && (T - q0) > NBt;
     const int q1 = outer ? q0 + NBt : T;
-    LPGP_TRY(factor_columns(ctx, mat, T, q0, q1, sU, ev_a1, ride));
+    LPGP_TRY(factor_columns(ctx, mat, T, q0, q1, sU, ev_a1, ride, TR));
     if (q1 >= T) break;
     hipEvent_t ev_fact = ctx->ev_outer_fact[oit & 1];
     LPGP_HIP(hipEventRecord(ev_fact, sP));             // outer panel [q0, q1) is final (factor_columns joins its updates into sP)
@@ -483,14 +517,14 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
     if (ev_b) LPGP_HIP(hipStreamWaitEvent(sP, ev_b, 0));
     const double* P = a + (int64_t)q1 * tb + (int64_t)q0 * tb * ld;
     LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                         mk(P, ld, P, ld, a + (int64_t)q1 * tb * (ld + 1), ld, T - q1, qa - q1, K, -1.0, 1.0, 3),
+                         mk(P, ld, P, ld, a + (int64_t)q1 * tb * (ld + 1), ld, TR - q1, qa - q1, K, -1.0, 1.0, 3),
                          LPGP_K_SYRK_AHEAD));
     LPGP_HIP(hipStreamWaitEvent(sO, ev_fact, 0));
     ev_a1 = nullptr;
     if (qa < q2) {                                     // (a1): columns [qa, q2), rows [qa, T)
       const double* Pa = a + (int64_t)qa * tb + (int64_t)q0 * tb * ld;
       LPGP_TRY(launch_gemm(ctx, sO, 0, 0,
-                           mk(Pa, ld, Pa, ld, a + (int64_t)qa * tb * (ld + 1), ld, T - qa, q2 - qa, K, -1.0, 1.0, 1),
+                           mk(Pa, ld, Pa, ld, a + (int64_t)qa * tb * (ld + 1), ld, TR - qa, q2 - qa, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
       ev_a1 = ctx->ev_outer_a1[oit & 1];
       LPGP_HIP(hipEventRecord(ev_a1, sO));
@@ -499,7 +533,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
     if (q2 < T) {                                      // (b): columns [q2, T)
       const double* Pb = a + (int64_t)q2 * tb + (int64_t)q0 * tb * ld;
       LPGP_TRY(launch_gemm(ctx, sO, 0, 0,
-                           mk(Pb, ld, Pb, ld, a + (int64_t)q2 * tb * (ld + 1), ld, T - q2, T - q2, K, -1.0, 1.0, 1),
+                           mk(Pb, ld, Pb, ld, a + (int64_t)q2 * tb * (ld + 1), ld, TR - q2, T - q2, K, -1.0, 1.0, 1),
                            LPGP_K_SYRK));
       ev_b = ctx->ev_outer[oit & 1];
       LPGP_HIP(hipEventRecord(ev_b, sO));

@@ -4,7 +4,8 @@
 # Expected final number of observations of a chain of `condition_on_observations` calls.
 # The resident Gram/factor buffer is allocated once with this capacity instead of growing
 # (and being copied) with every appended block.  0 = grow on demand.
-gram_capacity_hint: int = 0
+import os as _os0
+gram_capacity_hint: int = int(_os0.environ.get("LPGP_GRAM_CAPACITY_HINT", 0))
 
 # Gram blocks whose two point sets are tensor grids (`domains.TensorProductGrid`, e.g. from
 # `Box.uniform_grid`) are assembled as sums of Kronecker products of 1-D kernel matrices

@@ -51,6 +51,13 @@ def test_bench_prints_one_contract_line():
     #  tests/test_gpu_fused.py::test_reference_sequence_mean_then_std)
     assert seq["mean_vs_predict_rel"] <= 1e-12 and seq["var_from_std_vs_predict_rel"] <= 1e-8
     assert line["e2e_with_h2d_ms"] > 0 and line["e2e"]["mean_vs_resident_rel"] <= 1e-12 and line["e2e"]["var_vs_resident_rel"] <= 1e-11
+    # round 6: the schedule of the timed region by name, and the two-pipeline step time -- the schedule EVERY N > 1 line runs -- as
+    # top-level fields a scaling reader can use
+    assert line["mode"] == "fused_factor_and_predict"
+    assert line["two_pipeline_ms_per_step"] > 0 and line["two_pipeline_value"] > 0
+    assert abs(line["two_pipeline_value"] * line["two_pipeline_ms_per_step"] / (line["value"] * line["ms_per_step"]) - 1.0) < 1e-9
+    # the reference's own sequence no longer pays 2 T dependent launches for its weights (trsv.hip): within 25 % of predict at c2
+    assert seq["default_mode_ms"] <= 1.25 * line["two_pipeline_ms_per_step"], (seq, line["two_pipeline_ms_per_step"])
 
 
 def test_plain_call_with_gpus_2_starts_its_own_ranks():
@@ -76,3 +83,5 @@ def test_plain_call_with_gpus_2_starts_its_own_ranks():
     # round 5: real parity at N > 1 -- the timed workload against the oracle on rank 0's host cores, in the same run
     assert line["parity"]["pass"] is True and "oracle" in line["parity"], line["parity"]
     assert line["config"]["calibration_seconds"] >= 0
+    # round 6: every N > 1 line names its schedule, and the field the N = 1 line is to be compared through is the same number here
+    assert line["mode"] == "two_pipelines" and abs(line["two_pipeline_ms_per_step"] - line["ms_per_step"]) < 1e-9
