@@ -36,6 +36,8 @@ typedef struct lpgp_ctx lpgp_ctx;   /* one per process / per GPU                
 typedef struct lpgp_pts lpgp_pts;   /* device-resident point set (n x d)                  */
 typedef struct lpgp_mat lpgp_mat;   /* device-resident SPD matrix -> Cholesky factor      */
 typedef struct lpgp_rhs lpgp_rhs;   /* device-resident n x m block of right-hand sides    */
+typedef struct lpgp_dvec lpgp_dvec; /* device-resident n x m block of plain vectors (matrix-free path: no Gram matrix behind it) */
+typedef struct lpgp_pcg lpgp_pcg;   /* state of preconditioned conjugate gradients on such blocks */
 
 /* One term  coef * prod_d  d^{n0[d]}/dx_d^{n0[d]}  d^{n1[d]}/dx'_d^{n1[d]}  k_d(x_d, x'_d)
  * of `TensorProduct_LinDiffOp_LinDiffOp.__init__`
@@ -350,6 +352,32 @@ int  lpgp_kernel_matrix(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
 int  lpgp_kernel_matvec(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups,
                         const lpgp_pts* X0, const lpgp_pts* X1,
                         const double* v_host, int64_t nrhs, double* out_host);
+
+/* ---- the same product with every operand RESIDENT (round 6) --------------------------------------------------------
+ * The reference's KeOps lazy tensors keep their operands on the device and probnum's `LinearOperator.solve` iterates on the
+ * product (diffops/_matern.py:112-135, experiments/cpu.py:214-229); until round 5 every iteration here went through host
+ * vectors.  An `lpgp_dvec` is an n x m block of vectors in HBM (one column per right-hand side); host arrays are C-order.   */
+int  lpgp_dvec_create(lpgp_ctx* ctx, int64_t n, int64_t m, lpgp_dvec** out);              /* zero-filled */
+int  lpgp_dvec_destroy(lpgp_dvec* d);
+int  lpgp_dvec_set(lpgp_ctx* ctx, lpgp_dvec* d, const double* host);
+int  lpgp_dvec_get(lpgp_ctx* ctx, const lpgp_dvec* d, double* host);
+/* out = a + s b (same shapes; out may be a or b)                                                                      */
+int  lpgp_dvec_axpby(lpgp_ctx* ctx, lpgp_dvec* out, const lpgp_dvec* a, const lpgp_dvec* b, double s);
+/* Y[off : off + n, :] += diag(d_host) V[off : off + n, :]: the noise diagonal of a Gram block (`_conditional.py:392-394`) */
+int  lpgp_dvec_scale_rows_add(lpgp_ctx* ctx, lpgp_dvec* Y, int64_t y_off, const lpgp_dvec* V, int64_t v_off, const double* d_host, int64_t n);
+/* Y[y_off : y_off + n0, :] (accumulate != 0: +=) [sum_g (kd[g])(X0, X1)] V[v_off : v_off + n1, :] -- launches only        */
+int  lpgp_kernel_matvec_dev(lpgp_ctx* ctx, const lpgp_kdesc* kd, int32_t ngroups, const lpgp_pts* X0, const lpgp_pts* X1,
+                            const lpgp_dvec* V, int64_t v_off, lpgp_dvec* Y, int64_t y_off, int32_t accumulate);
+/* Preconditioned conjugate gradients for all m columns at once, one iteration = launches only: column dots in a fixed order of
+ * summation, step lengths formed on the device, preconditioner M^{-1} = (I - L^T S^{-1} L) / delta (L: rank x n pivoted-Cholesky
+ * rows, Sinv = (delta I + L L^T)^{-1}, both handed over once; rank 0: M = delta I).  The caller forms Q = G P between the steps
+ * (lpgp_kernel_matvec_dev per block pair + noise terms); each call returns the m relative residuals (8 m bytes read back).  */
+int  lpgp_pcg_create(lpgp_ctx* ctx, int64_t n, int64_t m, int32_t rank, const double* L_host, const double* Sinv_host, double delta, lpgp_pcg** out);
+int  lpgp_pcg_destroy(lpgp_pcg* p);
+/* R = B - G X0 on entry; Z = M^{-1} R, P = Z                                                                           */
+int  lpgp_pcg_start(lpgp_ctx* ctx, lpgp_pcg* p, const lpgp_dvec* R, lpgp_dvec* Z, lpgp_dvec* P, const double* bnorm_host, double rtol, double* rel_host);
+/* Q = G P on entry; X += alpha P, R -= alpha Q, Z = M^{-1} R, P = Z + beta P (columns already below rtol are left alone) */
+int  lpgp_pcg_step(lpgp_ctx* ctx, lpgp_pcg* p, lpgp_dvec* X, lpgp_dvec* R, lpgp_dvec* Z, lpgp_dvec* P, const lpgp_dvec* Q, double rtol, double* rel_host);
 
 /* ---- measurement: HIP-event timing of the hot kernels on their own streams ---------- */
 enum lpgp_kernel_id { LPGP_K_ASSEMBLE = 0, LPGP_K_SYRK = 1 /* rank-nb trailing update */, LPGP_K_GEMM = 2,

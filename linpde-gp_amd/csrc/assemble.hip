@@ -198,7 +198,8 @@ struct MvArgs {
   const double* x0;
   const double* x1;
   int64_t n0, n1, n0_pad, n1_pad;
-  const double* v;               // device, [r][n1_pad]
+  const double* v;               // device, [r][v_stride]
+  int64_t v_stride;              // doubles between right-hand sides of v (>= n1)
   double* part;                  // device, [split][r][n0_pad]
   int32_t nr;                    // right-hand sides in this pass (<= MV_R)
   int32_t factors;               // per-point exponential factors (lpgp_ctx::asm_factors)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(FastDesc fd, MvArgs a)
     {
       const int64_t c = (int64_t)tc * AT + lane;
       for (int j = w; j < D; j += 4) sx1[j][lane] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.n1_pad + c] : 0.0;
+      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.v_stride + c] : 0.0;
     }
     __syncthreads();
 #pragma unroll 1
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
     {
       const int64_t c = (int64_t)tc * AT + lane;       // wave w stages coordinate / vector row w, w+4, ...
       for (int j = w; j < D; j += 4) sx1[j][lane] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
-      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.n1_pad + c] : 0.0;
+      for (int r = w; r < MV_R; r += 4) sv[r][lane] = (c < a.n1 && r < a.nr) ? a.v[(int64_t)r * a.v_stride + c] : 0.0;
       double xc[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) xc[j] = (c < a.n1) ? a.x1[j * a.n1_pad + c] : 0.0;
@@ -731,23 +732,27 @@ __global__ __launch_bounds__(256) void matvec_kernel(const DevDesc* __restrict__
   }
 }
 
+// out[r][out_stride] (accumulate: +=) the sum over the splits, in a fixed order
 __global__ void mv_reduce_kernel(const double* __restrict__ part, double* __restrict__ out, int64_t n0, int64_t n0_pad,
-                                 int splits, int nr) {
+                                 int splits, int nr, int64_t out_stride, int accumulate) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (i >= n0 || r >= nr) return;
   double s = 0.0;
   for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * MV_R + r) * n0_pad + i];
-  out[(int64_t)r * n0_pad + i] = s;
+  double* o = out + (int64_t)r * out_stride + i;
+  *o = accumulate ? *o + s : s;
 }
 
 // out[r][n0_pad] = sum_j K(x0_i, x1_j) v[r][j] for r < nr <= MV_R; `part` holds splits*MV_R*n0_pad doubles
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
-                  double* part, int splits, double* out) {
+                  double* part, int splits, double* out, int64_t v_stride, int64_t out_stride, int accumulate) {
+  if (v_stride <= 0) v_stride = n1_pad;
+  if (out_stride <= 0) out_stride = n0_pad;
   MvArgs a;
   a.x0 = x0; a.x1 = x1; a.n0 = n0; a.n1 = n1; a.n0_pad = n0_pad; a.n1_pad = n1_pad;
-  a.v = v; a.part = part; a.nr = nr;
+  a.v = v; a.v_stride = v_stride; a.part = part; a.nr = nr;
   a.factors = (ctx->asm_factors && host_desc.ngroups <= FACT_MAXG) ? 1 : 0;
   a.tiles_r = (int)((n0 + AT - 1) / AT);
   a.tiles_c = (int)((n1 + AT - 1) / AT);
@@ -763,7 +768,7 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
       prof_end(ctx, stream);
       LPGP_HIP(hipGetLastError());
       hipLaunchKernelGGL(mv_reduce_kernel, dim3((unsigned)((n0 + 255) / 256), (unsigned)nr), dim3(256), 0, stream,
-                         (const double*)part, out, n0, n0_pad, splits, nr);
+                         (const double*)part, out, n0, n0_pad, splits, nr, out_stride, accumulate);
       LPGP_HIP(hipGetLastError());
       return 0;
     }
@@ -784,7 +789,7 @@ int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, c
   LPGP_HIP(hipEventRecord(slot->done, stream));
   slot->used = true;
   hipLaunchKernelGGL(mv_reduce_kernel, dim3((unsigned)((n0 + 255) / 256), (unsigned)nr), dim3(256), 0, stream,
-                     (const double*)part, out, n0, n0_pad, splits, nr);
+                     (const double*)part, out, n0, n0_pad, splits, nr, out_stride, accumulate);
   LPGP_HIP(hipGetLastError());
   return 0;
 }

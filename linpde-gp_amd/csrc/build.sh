@@ -18,14 +18,14 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 pids=()
-for f in api assemble gemm solve solve4 solve4p potrf chain trsv dist testhooks; do
+for f in api assemble gemm solve solve4 solve4p potrf chain trsv pcg dist testhooks; do
   "$HIPCC" $FLAGS "$@" -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
 "$HIPCC" -O2 -std=c++17 -fPIC -I"$ROOT/include" -I"$HERE" -Wall -c "$HERE/lower.cpp" -o "$OUT/lower.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp.so" "$OUT/api.o" "$OUT/assemble.o" "$OUT/gemm.o" "$OUT/solve.o" "$OUT/solve4.o" "$OUT/solve4p.o" "$OUT/potrf.o" "$OUT/chain.o" "$OUT/trsv.o" "$OUT/dist.o" "$OUT/lower.o" \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/liblpgp.so" "$OUT/api.o" "$OUT/assemble.o" "$OUT/gemm.o" "$OUT/solve.o" "$OUT/solve4.o" "$OUT/solve4p.o" "$OUT/potrf.o" "$OUT/chain.o" "$OUT/trsv.o" "$OUT/pcg.o" "$OUT/dist.o" "$OUT/lower.o" \
   -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/liblpgp.so"
 # test hooks (include/lpgp_test.h): a library of their own, loaded by tests/ and scratch/ only

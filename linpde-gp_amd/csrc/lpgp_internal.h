@@ -430,9 +430,10 @@ int launch_assemble_kron(lpgp_ctx* ctx, hipStream_t stream, const lpgp_kdesc* kd
 size_t kron_work_doubles(int D, const int64_t* n0d, const int64_t* n1d);
 constexpr int MV_RHS = 4;         // right-hand sides per pass of the matrix-free product (== MV_R in assemble.hip)
 bool kron_fits(const lpgp_kdesc* kd, int ngroups);
+// v: [r][v_stride] (0: n1_pad), out: [r][out_stride] (0: n0_pad); accumulate: out += instead of =
 int launch_matvec(lpgp_ctx* ctx, hipStream_t stream, const DevDesc& host_desc, const double* x0, int64_t n0,
                   int64_t n0_pad, const double* x1, int64_t n1, int64_t n1_pad, const double* v, int nr,
-                  double* part, int splits, double* out);
+                  double* part, int splits, double* out, int64_t v_stride = 0, int64_t out_stride = 0, int accumulate = 0);
 int launch_add_diag(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* v, double scalar,
                     const Layout2D& lay = Layout2D());
 int launch_add_dense(hipStream_t stream, double* a, int64_t ld, int64_t off, int64_t n, const double* b,

@@ -563,6 +563,80 @@ def lowered_array(kdesc):
     return _lib.make_kdesc_array(kdesc)
 
 
+class DeviceVectors:
+    """An n x m block of vectors resident in HBM (`lpgp_dvec`): the operands of the matrix-free path."""
+
+    def __init__(self, ctx: Context, n: int, m: int, values: np.ndarray | None = None):
+        self.ctx, self.n, self.m = ctx, int(n), int(m)
+        h = C.c_void_p()
+        check(lib.lpgp_dvec_create(ctx._h, self.n, self.m, C.byref(h)), "lpgp_dvec_create")
+        self._h = h
+        if values is not None:
+            self.set(values)
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.lpgp_dvec_destroy(self._h)
+            self._h = None
+
+    def set(self, values: np.ndarray) -> None:
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.double).reshape(self.n, self.m))
+        check(lib.lpgp_dvec_set(self.ctx._h, self._h, as_pd(v)), "lpgp_dvec_set")
+
+    def get(self) -> np.ndarray:
+        out = np.empty((self.n, self.m))
+        check(lib.lpgp_dvec_get(self.ctx._h, self._h, as_pd(out)), "lpgp_dvec_get")
+        return out
+
+    def axpby(self, a: "DeviceVectors", b: "DeviceVectors", s: float) -> None:
+        """self = a + s * b"""
+        check(lib.lpgp_dvec_axpby(self.ctx._h, self._h, a._h, b._h, float(s)), "lpgp_dvec_axpby")
+
+    def scale_rows_add(self, off: int, V: "DeviceVectors", d: np.ndarray) -> None:
+        """self[off : off + len(d)] += diag(d) V[off : off + len(d)]"""
+        d = np.ascontiguousarray(d, dtype=np.double)
+        check(lib.lpgp_dvec_scale_rows_add(self.ctx._h, self._h, int(off), V._h, int(off), as_pd(d), d.size), "lpgp_dvec_scale_rows_add")
+
+
+def kernel_matvec_dev(ctx: Context, kdesc, X0: Points, X1: Points, V: DeviceVectors, v_off: int, Y: DeviceVectors, y_off: int,
+                      accumulate: bool) -> None:
+    """Y[y_off : y_off + n0] (+)= K(X0, X1) V[v_off : v_off + n1] with every operand resident (`lpgp_kernel_matvec_dev`)."""
+    arr = _kdesc_array(kdesc)
+    check(lib.lpgp_kernel_matvec_dev(ctx._h, arr, len(arr), X0._h, X1._h, V._h, int(v_off), Y._h, int(y_off), int(bool(accumulate))),
+          "lpgp_kernel_matvec_dev")
+
+
+class DevicePCG:
+    """Preconditioned conjugate gradients whose iteration is launches only (`lpgp_pcg_*`): `matvec(P, Q)` forms Q = G P on
+    `DeviceVectors`; everything else -- dots, step lengths, the low-rank preconditioner -- stays on the device."""
+
+    def __init__(self, ctx: Context, n: int, m: int, L: np.ndarray | None, Sinv: np.ndarray | None, delta: float):
+        self.ctx, self.n, self.m = ctx, int(n), int(m)
+        rank = 0 if L is None else int(L.shape[0])
+        Lc = None if rank == 0 else np.ascontiguousarray(L, dtype=np.double)
+        Sc = None if rank == 0 else np.ascontiguousarray(Sinv, dtype=np.double)
+        h = C.c_void_p()
+        check(lib.lpgp_pcg_create(ctx._h, self.n, self.m, rank, as_pd(Lc) if rank else None, as_pd(Sc) if rank else None, float(delta), C.byref(h)),
+              "lpgp_pcg_create")
+        self._h = h
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.lpgp_pcg_destroy(self._h)
+            self._h = None
+
+    def start(self, R, Z, P, bnorm: np.ndarray, rtol: float) -> np.ndarray:
+        rel = np.empty(self.m)
+        bn = np.ascontiguousarray(bnorm, dtype=np.double)
+        check(lib.lpgp_pcg_start(self.ctx._h, self._h, R._h, Z._h, P._h, as_pd(bn), float(rtol), as_pd(rel)), "lpgp_pcg_start")
+        return rel
+
+    def step(self, X, R, Z, P, Q, rtol: float) -> np.ndarray:
+        rel = np.empty(self.m)
+        check(lib.lpgp_pcg_step(self.ctx._h, self._h, X._h, R._h, Z._h, P._h, Q._h, float(rtol), as_pd(rel)), "lpgp_pcg_step")
+        return rel
+
+
 def gemm(ctx: Context, A: np.ndarray, B: np.ndarray, *, transa: bool = False, transb: bool = False, alpha: float = 1.0,
          beta: float = 0.0, C: np.ndarray | None = None) -> np.ndarray:
     """alpha op(A) op(B) + beta C  on the device's fp64 MFMA kernel (`lpgp_gemm_host`): the dense products the reference leaves

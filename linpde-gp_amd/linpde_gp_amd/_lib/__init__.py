@@ -122,6 +122,18 @@ def _load() -> C.CDLL:
     sig("lpgp_potrf_predict", C.c_int, vp, vp, vp, pd, pd, pd, pd)
     sig("lpgp_trsm_lower", C.c_int, vp, vp, vp)
     sig("lpgp_rhs_inner", C.c_int, vp, vp, vp, pd)
+    i32, i64, dbl = C.c_int32, C.c_int64, C.c_double
+    sig("lpgp_dvec_create", C.c_int, vp, i64, i64, C.POINTER(vp))
+    sig("lpgp_dvec_destroy", C.c_int, vp)
+    sig("lpgp_dvec_set", C.c_int, vp, vp, pd)
+    sig("lpgp_dvec_get", C.c_int, vp, vp, pd)
+    sig("lpgp_dvec_axpby", C.c_int, vp, vp, vp, vp, dbl)
+    sig("lpgp_dvec_scale_rows_add", C.c_int, vp, vp, i64, vp, i64, pd, i64)
+    sig("lpgp_kernel_matvec_dev", C.c_int, vp, pk, i32, vp, vp, vp, i64, vp, i64, i32)
+    sig("lpgp_pcg_create", C.c_int, vp, i64, i64, i32, pd, pd, dbl, C.POINTER(vp))
+    sig("lpgp_pcg_destroy", C.c_int, vp)
+    sig("lpgp_pcg_start", C.c_int, vp, vp, vp, vp, vp, pd, dbl, pd)
+    sig("lpgp_pcg_step", C.c_int, vp, vp, vp, vp, vp, vp, vp, dbl, pd)
     sig("lpgp_rhs_matmul", C.c_int, vp, vp, pd, C.c_int64, C.POINTER(vp))
     sig("lpgp_gemm_host", C.c_int, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_double, pd, pd, C.c_double, pd)
     sig("lpgp_rhs_to_host", C.c_int, vp, vp, vp, pd)
@@ -147,6 +159,8 @@ EXPORTED = [
     "lpgp_gram_assemble", "lpgp_mat_add_diag", "lpgp_mat_add_dense", "lpgp_mat_to_host", "lpgp_mat_factor_diag",
     "lpgp_potrf", "lpgp_potrf_enqueue", "lpgp_mat_condition", "lpgp_mat_check", "lpgp_mat_truncate", "lpgp_potrs", "lpgp_solve_weights", "lpgp_mat_set_residual", "lpgp_rhs_create", "lpgp_rhs_destroy",
     "lpgp_cross_assemble", "lpgp_cross_assemble_row", "lpgp_predict", "lpgp_potrf_predict", "lpgp_trsm_lower", "lpgp_rhs_inner", "lpgp_rhs_matmul", "lpgp_gemm_host",
+    "lpgp_dvec_create", "lpgp_dvec_destroy", "lpgp_dvec_set", "lpgp_dvec_get", "lpgp_dvec_axpby", "lpgp_dvec_scale_rows_add", "lpgp_kernel_matvec_dev",
+    "lpgp_pcg_create", "lpgp_pcg_destroy", "lpgp_pcg_start", "lpgp_pcg_step",
     "lpgp_rhs_to_host", "lpgp_kernel_diag", "lpgp_kernel_matrix", "lpgp_kernel_matvec", "lpgp_gram_assemble_grid", "lpgp_kron_fits", "lpgp_profile_enable", "lpgp_profile_reset",
     "lpgp_profile_get",
     ]

@@ -53,6 +53,8 @@ matrix_free_preconditioner_rank: int = 200      # pivoted-Cholesky rank (0: plai
 matrix_free_rtol: float = 1e-10                  # relative residual of every CG solve
 matrix_free_maxiter: int = 5000
 matrix_free_rhs_chunk: int = 64                  # prediction points per block of variance solves
+matrix_free_device_iteration: bool = True        # iterates / residuals / search directions resident in HBM, one iteration = launches only
+                                                 # (`lpgp_pcg_step`, round 6); False: the host loop of round 5 (NumPy vector algebra around `lpgp_kernel_matvec`)
 
 # Lazy mode: a block that was only assembled stays unfactored across FURTHER conditionings -- to be factored together with them,
 # the prediction riding inside -- only if it has at least this many rows; smaller ones are factored when the next conditioning

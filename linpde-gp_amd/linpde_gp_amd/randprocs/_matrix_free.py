@@ -9,8 +9,13 @@ experiment's 2-D model (`experiments/0001_cpu_stationary_2d.ipynb`).  Same surfa
 `condition_on_observations` (the previous weights warm-start the next solve).
 
 What runs where: every kernel entry -- Gram products, cross-covariance products, the rows the preconditioner is built from --
-is evaluated by the HIP kernels behind `lpgp_kernel_matvec` / `lpgp_kernel_matrix`; the O(N) vector updates of the iteration
-(axpy, dot) are NumPy on the host, between products of O(N^2) kernel evaluations each.  There is no dense N x N object anywhere.
+is evaluated by the HIP kernels behind `lpgp_kernel_matvec(_dev)` / `lpgp_kernel_matrix`.  Since round 6 the ITERATION is
+device-resident too (`pcg_device`): iterates, residuals and search directions live in HBM (`lpgp_dvec`), a product is launches
+only (`lpgp_kernel_matvec_dev` per block pair + the noise diagonals), and the vector algebra -- column dots, step lengths, the
+low-rank preconditioner -- is `lpgp_pcg_step`; the host reads back the relative residuals (8 bytes per column and iteration).
+The reference's KeOps operands stay on the device in the same way (`diffops/_matern.py:112-135`).  The host loop `pcg` is kept
+for Gram matrices with DENSE noise blocks and as the statement of the algorithm the device runs.  There is no dense N x N
+object anywhere.
 
 Preconditioner: rank-r pivoted Cholesky `G ~ L^T L` (r rows of G, greedy on the remaining diagonal) plus `delta I`, applied by
 the Woodbury identity -- the standard choice for kernel matrices with a noise floor; `delta` is the mean of the diagonal the
@@ -71,6 +76,26 @@ class GramProduct:
         return out.reshape(V.shape)
 
     __matmul__ = matvec
+
+    def device_ok(self) -> bool:
+        """Every noise term a diagonal: the product can run on resident operands."""
+        return all(nz is None or nz.ndim == 1 for nz in self._noise)
+
+    def matvec_dev(self, V, Q) -> None:
+        """Q = G V on `DeviceVectors` (launches only)."""
+        for i, bi in enumerate(self.blocks):
+            if self.sizes[i] == 0:
+                continue
+            first = True
+            for j, bj in enumerate(self.blocks):
+                if self.sizes[j] == 0:
+                    continue
+                _engine.kernel_matvec_dev(self.ctx, self.desc(i, j), bi.points, bj.points, V, self.offs[j], Q, self.offs[i], not first)
+                first = False
+                self.products += self.sizes[i] * self.sizes[j] * V.m
+            nz = self._noise[i]
+            if nz is not None:
+                Q.scale_rows_add(self.offs[i], V, nz)
 
     def diag(self):
         d = np.empty(self.n)
@@ -169,6 +194,39 @@ def pcg(matvec, B, precond=None, X0=None, rtol: float = 1e-10, maxiter: int = 20
     return (X[:, 0] if vec else X.reshape(B.shape)), info
 
 
+def pcg_device(G: "GramProduct", B, precond=None, X0=None, rtol: float = 1e-10, maxiter: int = 2000):
+    """The same iteration as `pcg` with every operand resident on the device (round 6): `G.matvec_dev` for the product,
+    `lpgp_pcg_step` for the rest.  Same return value."""
+    B = np.asarray(B, dtype=np.double)
+    vec = B.ndim == 1
+    B2 = np.ascontiguousarray(B.reshape(B.shape[0], -1))
+    n, m = B2.shape
+    ctx = G.ctx
+    DV = _engine.DeviceVectors
+    X = DV(ctx, n, m, None if X0 is None else np.asarray(X0, dtype=np.double).reshape(n, m))
+    R = DV(ctx, n, m, B2)
+    Z, P, Q = DV(ctx, n, m), DV(ctx, n, m), DV(ctx, n, m)
+    if X0 is not None:
+        G.matvec_dev(X, Q)
+        R.axpby(R, Q, -1.0)                       # R = B - G X0
+    bn = np.linalg.norm(B2, axis=0)
+    bn[bn == 0.0] = 1.0
+    if precond is not None and precond.rank:
+        Sinv = np.linalg.inv(precond._chol @ precond._chol.T)
+        it_ = _engine.DevicePCG(ctx, n, m, precond.L, 0.5 * (Sinv + Sinv.T), precond.delta)
+    else:
+        it_ = _engine.DevicePCG(ctx, n, m, None, None, 1.0 if precond is None else precond.delta)
+    rel = it_.start(R, Z, P, bn, rtol)
+    it = 0
+    while it < maxiter and np.any(rel > rtol):
+        G.matvec_dev(P, Q)
+        rel = it_.step(X, R, Z, P, Q, rtol)
+        it += 1
+    Xh = X.get()
+    info = {"iterations": it, "converged": bool(np.all(rel <= rtol)), "rel_residual": rel.copy(), "device_resident": True}
+    return (Xh[:, 0] if vec else Xh.reshape(B.shape)), info
+
+
 class _MatrixFreeGram:
     """`gram` of a matrix-free posterior: the part of probnum's `LinearOperator` protocol that makes sense without a factor."""
 
@@ -260,8 +318,12 @@ class MatrixFreeConditionalGaussianProcess:
         return self._precond
 
     def _solve(self, B, X0=None):
-        X, info = pcg(self._G.matvec, B, self._preconditioner(), X0=X0, rtol=float(config.matrix_free_rtol),
-                      maxiter=int(config.matrix_free_maxiter))
+        if config.matrix_free_device_iteration and self._G.device_ok() and np.asarray(B).reshape(self._G.n, -1).shape[1] <= 256:
+            X, info = pcg_device(self._G, B, self._preconditioner(), X0=X0, rtol=float(config.matrix_free_rtol),
+                                 maxiter=int(config.matrix_free_maxiter))
+        else:
+            X, info = pcg(self._G.matvec, B, self._preconditioner(), X0=X0, rtol=float(config.matrix_free_rtol),
+                          maxiter=int(config.matrix_free_maxiter))
         self.last_solve_info = info
         if not info["converged"]:
             raise np.linalg.LinAlgError(

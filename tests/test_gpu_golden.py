@@ -126,3 +126,57 @@ def test_matern_iso_blocks_vs_golden(golden_dir):
         _close(DD(g["dir_arg1"])(k, argnum=1).matrix(g["X0"], g["X1"]), g[tag + "k_dd"])
         _close(DD(g["dir_arg0"])(k, argnum=0).matrix(g["X0"], g["X1"]), g[tag + "dd_k"])
         _close(DD(g["dir0"])(DD(g["dir1"])(k, argnum=1), argnum=0).matrix(g["X0"], g["X1"]), g[tag + "dd_k_dd"])
+
+
+def _multiblock_device_posterior(lp, g, name):
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+
+    def noise(i, n):
+        nz = float(g[f"{name}_noise"][i])
+        return None if nz == 0 else lp.randvars.Normal(np.zeros(n), nz * np.eye(n))
+
+    if name == "poisson2d":
+        prior = lp.GaussianProcess(lp.functions.Zero((2,)), 4.0 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=1.0), cf.Matern((), nu=2.5, lengthscales=1.0)))
+        ops = [None] * 4 + [-1.0 * diffops.Laplacian((2,))]
+    elif name == "heat":
+        prior = lp.GaussianProcess(lp.functions.Zero((2,)), cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0)))
+        ops = [None] * 3 + [diffops.HeatOperator((2,), alpha=0.1), None]
+    else:
+        prior = lp.GaussianProcess(lp.functions.Zero((2,)), float(g["neumann_scale"]) * cf.Matern((2,), nu=2.5, lengthscales=g["neumann_lengthscales"]))
+        u = prior.condition_on_observations(g["neumann_Yv"], X=g["neumann_Xv"], b=lp.randvars.Normal(np.zeros(9), 1e-4 * np.eye(9)))
+        kap = float(g["neumann_kappa"])
+        for i in range(g["neumann_Xn"].shape[0]):
+            u = u.condition_on_observations(g["neumann_Yn"][i:i + 1], X=g["neumann_Xn"][i:i + 1], L=-kap * diffops.DirectionalDerivative(g["neumann_normals"][i]),
+                                            b=lp.randvars.Normal(np.zeros(1), 1e-4 * np.eye(1)))
+        return u
+    u = prior
+    for i, op in enumerate(ops):
+        X, Y = g[f"{name}_X{i}"], g[f"{name}_Y{i}"]
+        u = u.condition_on_observations(Y, X=X, L=op, b=noise(i, len(Y)))
+    return u
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["default", "fused"])
+@pytest.mark.parametrize("name", ["poisson2d", "heat", "neumann"])
+def test_multiblock_posteriors_vs_golden(golden_dir, name, lazy):
+    """Round 6: the multi-block conditioning algebra of c3 (four boundary blocks with a nugget + a PDE block:
+    five conditionings, block appends), c5 (initial condition, two boundary conditions, heat collocation, noisy interior values)
+    and the Neumann blocks of the CPU-die experiment (isotropic Matern, one functional per boundary point) through the C ABI
+    against posteriors solved in 50-digit mpmath from SymPy-differentiated kernels (`tests/golden/posterior_multiblock.npz`,
+    `make_golden_multiblock.py`) -- independent of the oracle, which `tests/test_oracle_golden.py` holds to the same vectors.
+    Mean and variance at the plain 1e-8 (north_star), in the default mode and in the fused factor-and-predict pipeline."""
+    import linpde_gp_amd as lp
+    g = np.load(os.path.join(golden_dir, "posterior_multiblock.npz"))
+    saved = lp.config.lazy_factorization
+    lp.config.lazy_factorization = lazy
+    try:
+        u = _multiblock_device_posterior(lp, g, name)
+        mean, var = u.predict(g[f"{name}_Xt"])
+        w = np.array(u.representer_weights)
+    finally:
+        lp.config.lazy_factorization = saved
+    cond = float(g[f"{name}_cond"])
+    np.testing.assert_allclose(mean, g[f"{name}_mean"], rtol=0, atol=1e-8 * np.max(np.abs(g[f"{name}_mean"])))
+    np.testing.assert_allclose(var, g[f"{name}_var"], rtol=0, atol=1e-8 * np.max(np.abs(g[f"{name}_var"])))
+    np.testing.assert_allclose(w, g[f"{name}_weights"], rtol=0, atol=max(1e-8, 20 * cond * 2.0**-53) * np.max(np.abs(g[f"{name}_weights"])))

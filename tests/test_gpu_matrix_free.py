@@ -98,3 +98,43 @@ def test_matrix_free_matches_the_dense_path_at_32k(lp):
     assert np.max(np.abs(vf - vd)) <= 1e-7 * np.max(np.abs(vd))
     r = free.gram @ wf - (o.Y)
     assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(o.Y)
+
+
+def test_device_resident_iteration_equals_the_host_loop(lp):
+    """Round 6: iterates, residuals and search directions resident in HBM, one iteration = launches only (`lpgp_pcg_step`,
+    `lpgp_kernel_matvec_dev`) -- against the host loop of round 5 on the same problem: same iteration count (+-1: the dots are
+    summed in another order), same weights / mean / variance; two observation blocks (a differential one, offsets into the
+    resident vectors), a warm-started re-conditioning, and a multi-column solve (`gram.solve`)."""
+    from linpde_gp_amd.linfuncops import diffops
+    from linpde_gp_amd.randprocs import _matrix_free as mfree
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(12)
+    n0, n1 = 1500, 700
+    X0, X1 = rng.uniform(-1, 1, (n0, 2)), rng.uniform(-1, 1, (n1, 2))
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), 1.2**2 * cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=0.5), cf.Matern((), nu=2.5, lengthscales=0.6)))
+    Y0 = np.sin(2 * X0[:, 0]) * np.cos(X0[:, 1]) + 0.05 * rng.standard_normal(n0)
+    Y1 = rng.standard_normal(n1)
+    Xt = rng.uniform(-1, 1, (40, 2))
+    saved = (lp.config.matrix_free, lp.config.matrix_free_device_iteration, lp.config.matrix_free_rtol)
+    lp.config.matrix_free, lp.config.matrix_free_rtol = True, 1e-11
+    out = {}
+    try:
+        for dev in (False, True):
+            lp.config.matrix_free_device_iteration = dev
+            u = prior.condition_on_observations(Y0, X0, b=lp.randvars.Normal(np.zeros(n0), np.full(n0, 1e-2)))      # (a DIAGONAL noise: dense noise blocks keep the host loop)
+            w0 = np.array(u.representer_weights)
+            it0 = u.last_solve_info["iterations"]
+            assert bool(u.last_solve_info.get("device_resident", False)) is dev
+            u2 = u.condition_on_observations(Y1, X1, L=-1.0 * diffops.Laplacian((2,)), b=lp.randvars.Normal(np.zeros(n1), np.full(n1, 0.5)))
+            w = np.array(u2.representer_weights)
+            it1 = u2.last_solve_info["iterations"]
+            mean, var = u2.predict(Xt)
+            S = u2.gram.solve(np.stack([np.concatenate([Y0, Y1]), np.ones(n0 + n1)], axis=1))
+            out[dev] = (w0, it0, w, it1, mean, var, S)
+    finally:
+        lp.config.matrix_free, lp.config.matrix_free_device_iteration, lp.config.matrix_free_rtol = saved
+    (w0h, it0h, wh, it1h, mh, vh, Sh), (w0d, it0d, wd, it1d, md, vd, Sd) = out[False], out[True]
+    assert abs(it0d - it0h) <= 1 and abs(it1d - it1h) <= 1, (it0h, it0d, it1h, it1d)
+    for a, b_ in ((w0d, w0h), (wd, wh), (md, mh), (Sd, Sh)):
+        assert np.max(np.abs(a - b_)) <= 1e-8 * np.max(np.abs(b_))
+    assert np.max(np.abs(vd - vh)) <= 1e-7 * np.max(np.abs(vh))

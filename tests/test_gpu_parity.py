@@ -13,6 +13,9 @@ from oracle import covfuncs as ocf
 from oracle import gp as ogp
 
 pytestmark = pytest.mark.gpu
+# Gram / kernel entries against the oracle, relative to the largest entry of the block (SURVEY section 8d asks for <= 1e-13 absolute on
+# O(1) entries; the bar here is the one tests/test_gpu_random.py has carried since round 4, `ENTRY_RTOL`)
+ENTRY_ATOL = float(__import__("os").environ.get("LPGP_TEST_ENTRY_ATOL", "4e-15"))
 
 
 @pytest.fixture(scope="module")
@@ -88,7 +91,7 @@ def test_reference_tensor_product_cases(lp, name, nu0, nu1, L0, L1):
     got = kk.matrix(X, X)
     ref = ocf.LkL([(1.0, [("matern", nu0, 1.0), ("matern", nu1, 1.0)])], coeffs(L0), coeffs(L1), X, X)
     # the reference's own bar is atol 1e-14 + rtol 1e-7 against JAX autodiff (test_diffops.py:42)
-    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=ENTRY_ATOL * np.abs(ref).max())
 
 
 # ---- (1) kernel blocks -------------------------------------------------------------------

@@ -15,6 +15,9 @@ import scipy.stats
 from oracle import covfuncs as ocf
 
 pytestmark = pytest.mark.gpu
+# Gram / kernel entries against the oracle, relative to the largest entry of the block (SURVEY section 8d asks for <= 1e-13 absolute on
+# O(1) entries; the bar here is the one tests/test_gpu_random.py has carried since round 4, `ENTRY_RTOL`)
+ENTRY_ATOL = float(__import__("os").environ.get("LPGP_TEST_ENTRY_ATOL", "4e-15"))
 
 SHAPES = ((), (1,), (3,))
 
@@ -94,7 +97,7 @@ def _check(k, okern, shape, L0, L1):
     ref = ocf.LkL(okern, _coeffs(*(L0 or (None, None)), d), _coeffs(*(L1 or (None, None)), d), Xf, Xf)
     got = kk(Xs[:, None], Xs[None, :])
     assert got.shape == (128, 128)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=ENTRY_ATOL * np.abs(ref).max())
     np.testing.assert_allclose(kk.linop(Xs, Xs) @ np.eye(128), ref, rtol=0, atol=1e-11 * np.abs(ref).max())
 
 
