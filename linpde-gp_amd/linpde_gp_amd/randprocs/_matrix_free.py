@@ -419,7 +419,7 @@ class _MatrixFreeCovariance:
         K0 = gp._cross_dense(P0)
         K1 = K0 if x1 is None else gp._cross_dense(P1)
         S, _ = gp._solve(K1)
-        return kxx - K0.T @ S
+        return _engine.gemm(gp._ctx, K0, S, transa=True, alpha=-1.0, beta=1.0, C=kxx)      # kxx - K0^T S on the device
 
     def __call__(self, x0, x1=None):
         if x1 is None:
