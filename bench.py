@@ -549,6 +549,7 @@ def main():
     # `ms_per_step`.
     mode_name = "two_pipelines" if (distributed or not bench_lazy) else "fused_factor_and_predict"
     two_pipeline_ms = dt / args.steps * 1e3 if mode_name == "two_pipelines" else None
+    tp_syrk = None
     if two_pipeline_ms is None:
         saved_lazy = lp.config.lazy_factorization
         try:
@@ -561,6 +562,11 @@ def main():
             ctx.sync()
             two_pipeline_ms = (time.perf_counter() - t0_tp) / k_tp * 1e3
             del last_tp
+            # the roofline kernel in THAT schedule (it does not share the chip with the substitution's updates there): one extra step under HIP events
+            ctx.profile_reset(); ctx.profile_enable([ROOFLINE_SLOT])
+            step(); ctx.sync()
+            tp_syrk = ctx.profile_get()[ROOFLINE_SLOT]
+            ctx.profile_enable(False); ctx.profile_reset()
         finally:
             lp.config.lazy_factorization = saved_lazy
     modes, ref_seq, e2e = None, None, None
@@ -871,6 +877,11 @@ def main():
     out["mode"] = mode_name
     out["two_pipeline_ms_per_step"] = two_pipeline_ms
     out["two_pipeline_value"] = (world if replicas else 1) * flops / (two_pipeline_ms * 1e-3) / 1e9
+    if tp_syrk is not None and tp_syrk["ms"] > 0:
+        ach_tp = tp_syrk["flops"] / (tp_syrk["ms"] * 1e-3) / 1e12
+        out["roofline"]["two_pipeline_mode"] = {
+            "achieved": ach_tp, "frac": ach_tp / FP64_MFMA_PEAK_TFLOPS, "launches_per_step": tp_syrk["launches"],
+            "note": "the same kernel in the two-pipeline schedule (package default; every N > 1 line): beside the panel chain only, not beside the riding substitution's updates"}
     out["config"]["lazy_factorization"] = bool(lp.config.lazy_factorization) and not distributed
     out["config"]["fused_factor_and_predict"] = bool(lp.config.lazy_factorization) and not distributed
     if modes is not None:

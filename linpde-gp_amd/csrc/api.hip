@@ -403,11 +403,14 @@ int lpgp_init(int device, lpgp_ctx** out) {
   }
   for (int i = 0; i < 4; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
   LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_pre, hipEventDisableTiming));
+  LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_rows, hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT2")) ctx->chain_resident2_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_AUG")) ctx->ride_aug = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_RIDE_B_ON_RIDE")) ctx->ride_b_on_ride = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   // A profiler that SERIALISES kernels (rocprofv3 --pmc / counter groups: ROCPROF_COUNTER_COLLECTION) breaks the one assumption of
   // the follower -- that its chain kernel is dispatched beside it: it would wait out its poll limit, ~1 s per panel, and the step
@@ -491,6 +494,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
   (void)hipEventDestroy(ctx->ev_chain_pre);
+  if (ctx->ev_chain_rows) (void)hipEventDestroy(ctx->ev_chain_rows);
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
@@ -589,6 +593,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "ride_stream") == 0) *value = ctx->ride_stream;
   else if (std::strcmp(key, "chain_resident_max_rows") == 0) *value = ctx->chain_resident_max_rows;
   else if (std::strcmp(key, "trsv_resident") == 0) *value = ctx->trsv_resident;
+  else if (std::strcmp(key, "chain_resident2_max_rows") == 0) *value = ctx->chain_resident2_max_rows;
   else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_aug") == 0) *value = ctx->ride_aug;
@@ -674,6 +679,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->chain_resident_max_rows = (int)value;
   } else if (std::strcmp(key, "trsv_resident") == 0) {
     ctx->trsv_resident = value != 0;
+  } else if (std::strcmp(key, "chain_resident2_max_rows") == 0) {
+    ctx->chain_resident2_max_rows = (int)value;
   } else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) {
     ctx->ride_vchain_max_wgs = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {

@@ -98,9 +98,12 @@ __device__ __forceinline__ int* ch_U(const ChainArgs& g, int k) { return g.slot 
 // base / lane_step / cstep: element (workgroup-local row i, panel column c) of X at base[i * lane_step + c * cstep] -- rows of the
 // matrix: (g.a + first row, 1, g.ld); columns of a right-hand side V (X = V^T, the forward substitution's panel step): (V + first
 // column * ldv, ldv, 1)
+// RG = 2: eight waves, 32 rows per workgroup (one per CU beside the factor workgroup's 152 KB); RG = 1: four waves, 16 rows, 68 KB of
+// LDS -- two workgroups per CU (panel_chain_rows_kernel: the rows below a WIDE panel, round 6)
+template <int RG>
 __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr, double* base, const int64_t lane_step, const int64_t cstep,
                                                 double* smem) {
-  constexpr int NT = 4, RG = 2;
+  constexpr int NT = 4;
   constexpr PsvSched<NT, 0> SCH = psv_make_sched<NT, 0>(4 / RG);
   static_assert(psv_sched_ok<NT, RG, 0>(), "resident chain: broken stage schedule");
   constexpr int XA = RG * 32 * 64;
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(512, 1) void panel_chain_kernel(ChainArgs g) {
   }
   if (b <= 12) {
     const int tr = 1 + (b - 1) / 4, w = (b - 1) & 3;
-    chain_rows_role(g, tr, g.a + (int64_t)tr * TILE + 32 * w, 1, g.ld, sm);
+    chain_rows_role<2>(g, tr, g.a + (int64_t)tr * TILE + 32 * w, 1, g.ld, sm);
   } else {
-    chain_rows_role(g, 4, g.a + (int64_t)4 * TILE + 32 * (int64_t)(b - 13), 1, g.ld, sm);
+    chain_rows_role<2>(g, 4, g.a + (int64_t)4 * TILE + 32 * (int64_t)(b - 13), 1, g.ld, sm);
   }
 }
 
@@ -311,11 +314,21 @@ __global__ __launch_bounds__(512, 1) void panel_chain_kernel(ChainArgs g) {
 // Launched AFTER its chain kernel in host order, on the substitution's stream; reads the flags only.
 __global__ __launch_bounds__(512, 1) void panel_chain_v_kernel(ChainArgs g, double* V, int64_t ldv) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  chain_rows_role(g, 4, V + (int64_t)blockIdx.x * 32 * ldv, ldv, 1, sm);
+  chain_rows_role<2>(g, 4, V + (int64_t)blockIdx.x * 32 * ldv, ldv, 1, sm);
+}
+
+// The rows BELOW the diagonal block of a panel whose factor and in-block workgroups run in panel_chain_kernel on ANOTHER stream
+// (round 6: the two-kernel form of the resident chain for panels with more rows below than one workgroup per CU can hold at
+// 152 KB each): 16 rows per workgroup, 68 KB of LDS, two per CU; reads the chain's flags, publishes nothing.
+__global__ __launch_bounds__(256, 2) void panel_chain_rows_kernel(ChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  chain_rows_role<1>(g, 4, g.a + (int64_t)4 * TILE + 16 * (int64_t)blockIdx.x, 1, g.ld, sm);
 }
 
 // The chain of panel [p0, p0 + 4) of the padded matrix, all rows down to tile T, on `stream`.
-int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info) {
+// rows_here = false: the factor workgroup and the twelve in-block row workgroups only; the rows below follow through the flags
+// in a launch of their own (launch_panel_chain_rows).
+int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here) {
   const int64_t ld = mat->cap;
   if (!ctx->d_chain_flags) {
     LPGP_HIP(hipMalloc(&ctx->d_chain_flags, (size_t)CH_SLOTS * CH_SLOT_INTS * sizeof(int)));
@@ -332,13 +345,37 @@ int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0,
   g.slot_clear = ctx->d_chain_flags + ((n + CH_SLOTS / 2) % CH_SLOTS) * CH_SLOT_INTS;
   g.info = d_info;
   g.info_base = p0 * TILE;
-  g.n_below = (T - p0 - 4) * (TILE / 32);
+  g.n_below = rows_here ? (T - p0 - 4) * (TILE / 32) : 0;
   const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
   static_assert((size_t)TILE_LDS_DOUBLES >= (size_t)(2 * 32 * 64 + TSV_RING), "resident chain: the tile image must cover the row role's LDS");
   LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_chain_kernel), shmem));
   // algorithmic flops of the panel's chain: four tile Choleskys + the triangular solve of the rows below against the block
   prof_begin(ctx, stream, LPGP_K_PANEL, 4.0 * TILE * TILE * TILE / 3.0 + (double)(T - p0 - 1) * TILE * 512.0 * 512.0 / 2.0, 0.0);
   hipLaunchKernelGGL(panel_chain_kernel, dim3((unsigned)(13 + g.n_below)), dim3(512), shmem, stream, g);
+  prof_end(ctx, stream);
+  LPGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// rows below the diagonal block of panel p0 (down to tile T), following the chain launched LAST (launch_panel_chain(..., rows_here = false))
+int launch_panel_chain_rows(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info) {
+  LPGP_CHECK(ctx->chain_last_slot && ctx->chain_last_p0 == p0, "resident chain: no chain launch of panel %d to follow", p0);
+  const int64_t ld = mat->cap;
+  const int below = T - p0 - 4;
+  if (below <= 0) return 0;
+  ChainArgs g;
+  g.a = mat->a + (int64_t)p0 * TILE * (ld + 1);
+  g.ld = ld;
+  g.linv = mat->linv + (int64_t)p0 * TILE * TILE;
+  g.slot = ctx->chain_last_slot;
+  g.slot_clear = nullptr;
+  g.info = d_info;
+  g.info_base = p0 * TILE;
+  g.n_below = 0;
+  const size_t shmem = (size_t)(32 * 64 + TSV_RING) * sizeof(double);          // one row group's fragment image + the stage ring: 69 632 B
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_chain_rows_kernel), shmem));
+  prof_begin(ctx, stream, LPGP_K_PANEL, (double)below * TILE * 512.0 * 512.0, 0.0);
+  hipLaunchKernelGGL(panel_chain_rows_kernel, dim3((unsigned)(below * (TILE / 16))), dim3(256), shmem, stream, g);
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;

@@ -98,10 +98,16 @@ struct lpgp_ctx {
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
   int ride_old_ungated = 1;            // ... the steps of old panels (block append) are not held back by the gate
   int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
+  int ride_b_on_ride = 0;              // ... the factorisation's remainder updates queue on the substitution's stream once its gate is open (LPGP_RIDE_B_ON_RIDE)
   int ride_aug = 0;                    // ... or, where the matrix has room for it, as ROWS of the matrix being factored (potrf.hip: augmented form; LPGP_RIDE_AUG)
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
   // ONE launch whose workgroups hand over through device flags (-1: never)
   int chain_resident_max_rows = 32;
+  int chain_resident2_max_rows = 0;    // ... and panels with MORE rows below (up to this many tile rows) as TWO launches that talk through the same flags: factor + in-block
+                                       // workgroups on the panel stream, the rows below -- 16 rows and 68 KB of LDS per workgroup, two per CU -- on an idle masked stream.
+                                       // 0: never -- the default: measured SLOWER (round 6: c2 7.8 -> 8.9 ms, c3 50.2 -> 53): at 68 KB a row workgroup shares its CU with an
+                                       // update workgroup and runs at half speed; the 152 KB of the one-launch form are what keeps a CU to itself (MEASUREMENTS.md)
+  hipEvent_t ev_chain_rows = nullptr;
   int trsv_resident = 1;               // single right-hand side: one resident launch per direction (trsv.hip); 0: one launch per tile (rounds 1-5)
   int* d_chain_flags = nullptr;        // ring of flag slots (zeroed; a launch zeroes the slot half a ring ahead)
   int64_t chain_launches = 0;
@@ -385,7 +391,8 @@ int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx,
                       int nt_cols, int mt, int prof_kernel);
 
 // chain.hip: the whole chain of panel [p0, p0 + 4) (rows down to tile T) in one launch
-int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info);
+int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here = true);
+int launch_panel_chain_rows(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info);
 int launch_panel_chain_v(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, double* V, int64_t ldv, int64_t cols, int* d_info);
 // potrf.hip -------------------------------------------------------------------------------
 int debug_tile_xcc(int32_t* out8, int reset);

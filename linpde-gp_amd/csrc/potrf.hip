@@ -259,8 +259,24 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       if (ride && ride->stream != sP && ctx->ride_vchain_pre) LPGP_HIP(hipEventRecord(ctx->ev_chain_pre, sP));      // (see ride_panel_now: the step that follows the chain's flags)
       LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, TR, ctx->d_info_cur));
     }
+    // ... a WIDER panel as two launches (round 6): the factor workgroup and the in-block rows (13 workgroups of 152 KB: thirteen CUs)
+    // here, the rows below -- 16 per workgroup, 68 KB, two per CU -- on the outer-update stream, which is idle at these sizes and
+    // CU-masked: its workgroups wait ON the chip for the factor workgroup's flags and must not sit on the CUs that workgroup needs
+    // (the mask leaves it `reserve` of them); the launch is ordered behind everything in front of the chain kernel (an event), so
+    // that it is not dispatched before the chain kernel can be.  The substitution's follower is not used with this form.
+    hipStream_t sR = ctx->s_outer;
+    const bool resident2 = !resident && ctx->chain_resident2_max_rows > 0 && ctx->chain_resident_max_rows >= 0 && p1 - p0 == 4 && TR - p1 > 0 &&
+                           TR - p1 <= ctx->chain_resident2_max_rows && !ctx->distributed() && !ctx->single_stream && sR && sR != sP && ctx->ev_chain_rows;
+    if (resident2) {
+      LPGP_HIP(hipEventRecord(ctx->ev_chain_pre, sP));
+      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, TR, ctx->d_info_cur, false));
+      LPGP_HIP(hipStreamWaitEvent(sR, ctx->ev_chain_pre, 0));
+      LPGP_TRY(launch_panel_chain_rows(ctx, sR, mat, p0, TR, ctx->d_info_cur));
+      LPGP_HIP(hipEventRecord(ctx->ev_chain_rows, sR));
+      LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_chain_rows, 0));
+    }
     // ... else tile by tile
-    for (int jt = p0; jt < p1 && !resident; ++jt) {
+    for (int jt = p0; jt < p1 && !resident && !resident2; ++jt) {
       double* dj = a + (int64_t)jt * tb * (ld + 1);
       double* linv = mat->linv + (int64_t)jt * tb * tb;
       LPGP_TRY(launch_potrf_tile(ctx, sP, dj, ld, linv, ctx->d_info_cur, jt * TILE));
@@ -319,6 +335,10 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       //  remainder updates move to the narrow stream from then on)
       const bool ride_has_upd = ride && ride->open && ride->stream2 == sU;
       hipStream_t sB = (ctx->s_upd_narrow && (t_b_us * narrow_frac < t_chain_us || ride_has_upd)) ? ctx->s_upd_narrow : sU;
+      // (round 6, option ride_b_on_ride: once the gate is open the remainder update queues on the SUBSTITUTION's stream, behind the
+      //  step of the panel it belongs to: one update grid at a time -- the factorisation's and the substitution's launches alternate
+      //  instead of sharing the chip -- with the panel chain beside it)
+      if (ctx->ride_b_on_ride && ride && ride->open && ride->stream != sP && ride->held.empty()) sB = ride->stream;
       if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
       if (dep_pending_u) {
         LPGP_HIP(hipStreamWaitEvent(sB, dep, 0));

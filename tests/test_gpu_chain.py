@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from linpde_gp_amd import _engine
     c = _engine.default_context()
-    saved = c.get_option("chain_resident_max_rows")
+    saved = c.get_option("chain_resident_max_rows"), c.get_option("chain_resident2_max_rows")
     yield c
-    c.set_option("chain_resident_max_rows", saved)
+    c.set_option("chain_resident_max_rows", saved[0])
+    c.set_option("chain_resident2_max_rows", saved[1])
 
 
 def _posterior(lp, n, seed, noise=1e-3, ls=0.35):
@@ -114,3 +115,43 @@ def test_a_timed_out_hand_over_kills_the_chain_for_good(ctx):
         assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
     finally:
         lp.config.lazy_factorization = False
+
+
+@pytest.mark.parametrize("n", [640, 1500, 4608, 8320])       # 1 ... 61 tile rows below the first panel (c2's shape: 65 tile rows)
+def test_two_kernel_resident_chain_equals_the_tile_by_tile_chain(ctx, n):
+    """Round 6: panels with MORE rows below than the one-launch chain holds (one 152-KB workgroup per CU) run as TWO launches that
+    talk through the same device flags -- factor + in-block workgroups on the panel stream, the rows below as 16-row workgroups of
+    68 KB, two per CU, on an idle masked stream (`panel_chain_rows_kernel`).  Every panel forced through that form (one-launch
+    limit 0 rows, two-launch limit 64) against the tile-by-tile chain: factors to 1e-12, posterior against the oracle, in the
+    default mode and with the substitution riding inside (lazy)."""
+    import linpde_gp_amd as lp
+    prior, okern, X, Y, b = _posterior(lp, n, seed=n + 1)
+    Xt = np.random.default_rng(1).uniform(-1, 1, (33, 2))
+    out = {}
+    for mode, (r1, r2) in (("two", (0, 64)), ("tiles", (-1, 0))):
+        ctx.set_option("chain_resident_max_rows", r1)
+        ctx.set_option("chain_resident2_max_rows", r2)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        u = prior.condition_on_observations(Y, X, b=b)
+        pred = u.predict(Xt)
+        prof = ctx.profile_get(); ctx.profile_enable(False)
+        out[mode] = (u.gram.cholesky(), pred, prof["potrf_tile"]["launches"])
+        del u
+    assert out["tiles"][2] > 0
+    if n <= 65 * 128 - 512 - 128:
+        assert out["two"][2] <= 4, out["two"][2]            # (every four-tile panel went through the chain kernels; a ragged last panel may not)
+    Lr, Lt = out["two"][0], out["tiles"][0]
+    assert np.max(np.abs(Lr - Lt)) <= 1e-12 * np.max(np.abs(Lt))
+    post = ogp.condition(okern, [ogp.ObsBlock(X, ocf.identity(2), Y, 0.0, 1e-3)])
+    m, v = out["two"][1]
+    assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
+    assert np.max(np.abs(v - post.var(Xt))) <= 1e-8 * np.max(np.abs(post.var(Xt)))
+    # the fused pipeline over the same panels
+    ctx.set_option("chain_resident_max_rows", 0)
+    ctx.set_option("chain_resident2_max_rows", 64)
+    lp.config.lazy_factorization = True
+    try:
+        m2, v2 = prior.condition_on_observations(Y, X, b=b).predict(Xt)
+    finally:
+        lp.config.lazy_factorization = False
+    assert np.max(np.abs(m2 - m)) <= 1e-11 * np.max(np.abs(m)) and np.max(np.abs(v2 - v)) <= 1e-10 * np.max(np.abs(v))
