@@ -404,6 +404,8 @@ int lpgp_init(int device, lpgp_ctx** out) {
   for (int i = 0; i < 4; ++i) LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_ride[i], hipEventDisableTiming));
   LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_pre, hipEventDisableTiming));
   LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_chain_rows, hipEventDisableTiming));
+  LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_append[0], hipEventDisableTiming));
+  LPGP_HIP(hipEventCreateWithFlags(&ctx->ev_append[1], hipEventDisableTiming));
   if (const char* e = std::getenv("LPGP_RIDE_STREAM")) ctx->ride_stream = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
@@ -411,6 +413,8 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_AUG")) ctx->ride_aug = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_B_ON_RIDE")) ctx->ride_b_on_ride = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_APPEND_SPLIT")) ctx->append_split = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_APPEND_SPLIT_MIN_TILES")) ctx->append_split_min_tiles = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);
   // A profiler that SERIALISES kernels (rocprofv3 --pmc / counter groups: ROCPROF_COUNTER_COLLECTION) breaks the one assumption of
   // the follower -- that its chain kernel is dispatched beside it: it would wait out its poll limit, ~1 s per panel, and the step
@@ -495,6 +499,7 @@ int lpgp_finalize(lpgp_ctx* ctx) {
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_ride[i]);
   (void)hipEventDestroy(ctx->ev_chain_pre);
   if (ctx->ev_chain_rows) (void)hipEventDestroy(ctx->ev_chain_rows);
+  for (auto& e : ctx->ev_append) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_panel[i]);
     (void)hipEventDestroy(ctx->ev_upd[i]);
@@ -597,6 +602,7 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_aug") == 0) *value = ctx->ride_aug;
+  else if (std::strcmp(key, "append_split") == 0) *value = ctx->append_split;
   else if (std::strcmp(key, "ride_gate_pct") == 0) *value = ctx->ride_gate_pct;
   else if (std::strcmp(key, "ride_outer_rows") == 0) *value = ctx->ride_outer_rows;
   else if (std::strcmp(key, "ride_outer_min_tiles") == 0) *value = ctx->ride_outer_min_tiles;
@@ -687,6 +693,8 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->ride_occ3 = value != 0;
   } else if (std::strcmp(key, "ride_aug") == 0) {
     ctx->ride_aug = (int)value;
+  } else if (std::strcmp(key, "append_split") == 0) {
+    ctx->append_split = value != 0;
   } else if (std::strcmp(key, "ride_gate_pct") == 0) {
     ctx->ride_gate_pct = (int)value;
   } else if (std::strcmp(key, "ride_outer_rows") == 0) {

@@ -98,6 +98,9 @@ struct lpgp_ctx {
   int ride_stream = 1 + 8 * 7;         // ... runs on (first + 8 * second stream; potrf.hip): 0 s_outer, 1 s_upd_all, 2 s_upd_narrow, 3 the panel stream, 4 s_upd, 7 none
   int ride_old_ungated = 1;            // ... the steps of old panels (block append) are not held back by the gate
   int ride_occ3 = 1;                   // ... its updates may use the three-workgroups-per-CU kernel
+  int append_split = 0;                // (OFF: measured flat, c3 50.3-50.8 either way, profiles/r06_append_split_ab.txt) block append: the last old panel's update of the new block split into the first new panel's columns (panel stream) and the
+  int append_split_min_tiles = 16;     // remainder (update stream, under the first new chain), for new blocks of at least this many tile rows (LPGP_APPEND_SPLIT)
+  hipEvent_t ev_append[2] = {nullptr, nullptr};
   int ride_b_on_ride = 0;              // ... the factorisation's remainder updates queue on the substitution's stream once its gate is open (LPGP_RIDE_B_ON_RIDE)
   int ride_aug = 0;                    // ... or, where the matrix has room for it, as ROWS of the matrix being factored (potrf.hip: augmented form; LPGP_RIDE_AUG)
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in

@@ -467,6 +467,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
   if (info) LPGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sP));
 
   // ---- phase A (append): push the new rows through the already factored columns ----
+  hipEvent_t append_dep = nullptr;
   if (t_done > 0 && T > t_done) {
     const int mnew = TR - t_done;
     double* rows = a + (int64_t)t_done * tb;          // row offset of the new rows
@@ -494,9 +495,30 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
                              mk(Xp, ld, a + (int64_t)p1 * tb + (int64_t)p0 * tb * ld, ld,
                                 rows + (int64_t)p1 * tb * ld, ld, mnew, t_done - p1, K, -1.0, 1.0, 0),
                              LPGP_K_GEMM));
-      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                           mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, T - t_done, K, -1.0, 1.0, 1),
-                           LPGP_K_SYRK));
+      // Round 6: the update of the new block by the LAST old panel with the look-ahead split every other trailing update has -- the first
+      // new panel's columns on the panel stream, its chain right behind them, the remainder on the update stream underneath that
+      // chain (until then ONE launch on the panel stream: at c3 the first chain of the PDE block, 0.5 ms on an otherwise idle
+      // chip, waited for all 2.4 ms of the 16 384^2 x 512 update).  The remainder's event is the `dep` of factor_columns.
+      const bool split = ctx->lookahead != 0 && ctx->append_split && p1 == t_done && (T - t_done) > nbt && mnew >= ctx->append_split_min_tiles &&
+                         sU != sP && ctx->ev_append[0] && ctx->ev_append[1];
+      if (!split) {
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, T - t_done, K, -1.0, 1.0, 1),
+                             LPGP_K_SYRK));
+      } else {
+        const int c1 = t_done + nbt;
+        LPGP_HIP(hipEventRecord(ctx->ev_append[0], sP));                   // the new rows are solved against the old panel
+        LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                             mk(Xp, ld, Xp, ld, rows + (int64_t)t_done * tb * ld, ld, mnew, nbt, K, -1.0, 1.0, 3),
+                             LPGP_K_SYRK_AHEAD));
+        LPGP_HIP(hipStreamWaitEvent(sU, ctx->ev_append[0], 0));
+        const double* Xq = Xp + (int64_t)nbt * tb;                           // rows from the second new panel on
+        LPGP_TRY(launch_gemm(ctx, sU, 0, 0,
+                             mk(Xq, ld, Xq, ld, a + (int64_t)c1 * tb * (ld + 1), ld, TR - c1, T - c1, K, -1.0, 1.0, 1),
+                             LPGP_K_SYRK));
+        LPGP_HIP(hipEventRecord(ctx->ev_append[1], sU));
+        append_dep = ctx->ev_append[1];
+      }
     }
   }
 
@@ -520,7 +542,7 @@ static int potrf_blocked_impl(lpgp_ctx* ctx, lpgp_mat* mat, int64_t t_done64, in
   const int NBt = (int)(ctx->nb_outer / TILE);
   const bool la = ctx->lookahead != 0;
   hipStream_t sO = ctx->s_outer ? ctx->s_outer : sU;
-  hipEvent_t ev_a1 = nullptr, ev_b = nullptr;
+  hipEvent_t ev_a1 = append_dep, ev_b = nullptr;
   int oit = 0;
   for (int q0 = t_done; q0 < T; ++oit) {
     const bool outer = la && NBt > nbt && (T - q0) > ctx->nb_outer_min_tiles && (T - q0) > NBt;

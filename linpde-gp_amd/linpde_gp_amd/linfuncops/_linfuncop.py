@@ -55,6 +55,9 @@ class LinearFunctionOperator:
             return covfuncs.apply_linfuncop(self, f, argnum=argnum)
         if isinstance(f, gps.ConditionalGaussianProcess):
             return gps.apply_linfuncop_to_conditional_gp(self, f)
+        from ..randprocs._matrix_free import MatrixFreeConditionalGaussianProcess
+        if isinstance(f, MatrixFreeConditionalGaussianProcess):
+            return f._with_test_operator(self)
         if isinstance(f, gps.GaussianProcess):
             return gps.GaussianProcess(
                 mean=self(f.mean),

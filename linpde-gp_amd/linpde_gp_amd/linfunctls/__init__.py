@@ -75,6 +75,14 @@ class LinearFunctional:
 
         if isinstance(f, gps.ConditionalGaussianProcess):
             return gps.apply_linfunctl_to_conditional_gp(self, f)
+        from ..randprocs._matrix_free import MatrixFreeConditionalGaussianProcess
+        if isinstance(f, MatrixFreeConditionalGaussianProcess):
+            # `L(posterior)` for a functional: the joint law of L[f] at the functional's points, through the matrix-free read-out
+            from ..randvars import Normal
+            view = f._with_test_operator(self)
+            X = self.points()
+            x = X if f.input_ndim else X[:, 0]
+            return Normal(view.mean(x), view.cov.matrix(x))
         if isinstance(f, gps.GaussianProcess):
             return gps.apply_linfunctl_to_gp(self, f)
         if isinstance(f, covfuncs.CovarianceFunction):

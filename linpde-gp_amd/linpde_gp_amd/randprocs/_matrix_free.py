@@ -288,6 +288,8 @@ class MatrixFreeConditionalGaussianProcess:
         return cls(prior, old + (block,), warm_start=warm)
 
     def condition_on_observations(self, Y, X=None, *, L=None, b=None):
+        if any(v != 1.0 or any(mi) for mi, v in self._test_coeffs.items()):
+            raise NotImplementedError("conditioning a transformed posterior is not supported")
         return MatrixFreeConditionalGaussianProcess.from_observations(self._prior, Y, X, L=L, b=b, previous=self)
 
     # -- reference surface ------------------------------------------------------------------
@@ -350,9 +352,27 @@ class MatrixFreeConditionalGaussianProcess:
 
     def _prior_mean_at(self, X):
         m = self._prior.mean
+        d = len(next(iter(self._test_coeffs)))
         if isinstance(m, functions.Constant):
-            return np.full(X.shape[0], float(m.value))
-        return np.asarray(m(X if self.input_ndim else X[:, 0]), dtype=np.double).reshape(-1)
+            return np.full(X.shape[0], self._test_coeffs.get((0,) * d, 0.0) * float(m.value))
+        if set(self._test_coeffs) == {(0,) * d} and self._test_coeffs[(0,) * d] == 1.0:
+            return np.asarray(m(X if self.input_ndim else X[:, 0]), dtype=np.double).reshape(-1)
+        # a read-out `L(posterior)` of a non-constant mean: closed-form derivatives or NotImplementedError, as on the dense path
+        return np.asarray(functions.apply_coefficients(self._test_coeffs, m)(X if self.input_ndim else X[:, 0]), dtype=np.double).reshape(-1)
+
+    def _with_test_operator(self, L) -> "MatrixFreeConditionalGaussianProcess":
+        """`L(posterior)` (`_conditional.py:432-450`): the same observations, weights and preconditioner, read out through `L`
+        (`LinearFunctionOperator.__call__` is isinstance-based and knew the dense posterior only)."""
+        out = MatrixFreeConditionalGaussianProcess.__new__(MatrixFreeConditionalGaussianProcess)
+        out.__dict__.update(self.__dict__)
+        out._test_coeffs = covfuncs._compose(L.coefficients_dict(), self._test_coeffs)
+        return out
+
+    def __call__(self, x) -> randvars.Normal:
+        X, batch = self._flat(x)
+        if len(batch) != 1:
+            raise ValueError("`__call__` needs inputs of shape (N,) + input_shape")
+        return randvars.Normal(self.mean(x), self.cov.matrix(x))
 
     def _cross_desc(self, ob):
         return self._G._lowered(self._prior.cov, self._test_coeffs, ob.coeffs)

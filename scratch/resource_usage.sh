@@ -7,7 +7,7 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 CS="$ROOT/linpde-gp_amd/csrc"
 TMP=$(mktemp -d)
 pids=()
-for f in api assemble gemm solve solve4 solve4p potrf chain dist; do
+for f in api assemble gemm solve solve4 solve4p potrf chain trsv pcg dist; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$CS" -Wall -Wno-unused-function \
     -Rpass-analysis=kernel-resource-usage -c "$CS/$f.hip" -o "$TMP/$f.o" 2> "$TMP/$f.txt" &
   pids+=($!)

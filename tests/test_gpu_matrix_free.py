@@ -138,3 +138,37 @@ def test_device_resident_iteration_equals_the_host_loop(lp):
     for a, b_ in ((w0d, w0h), (wd, wh), (md, mh), (Sd, Sh)):
         assert np.max(np.abs(a - b_)) <= 1e-8 * np.max(np.abs(b_))
     assert np.max(np.abs(vd - vh)) <= 1e-7 * np.max(np.abs(vh))
+
+
+def test_operators_apply_to_a_matrix_free_posterior(lp):
+    """`LinearFunctionOperator.__call__(u)` / `LinearFunctional.__call__(u)` dispatch on the posterior's type and knew the
+    dense posterior only; a matrix-free posterior is read out through the same operator maps (`_conditional.py:432-467`).  The
+    Laplacian of the posterior and a Dirac functional, against the dense path of the same problem."""
+    from linpde_gp_amd.linfuncops import diffops
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(4)
+    n = 400
+    X = rng.uniform(-1, 1, (n, 2))
+    Y = np.sin(2 * X[:, 0]) * np.cos(X[:, 1])
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), cf.TensorProduct(cf.Matern((), nu=3.5, lengthscales=0.6), cf.Matern((), nu=3.5, lengthscales=0.7)))
+    b = lp.randvars.Normal(np.zeros(n), np.full(n, 1e-3))
+    Xt = rng.uniform(-0.9, 0.9, (12, 2))
+    dense = prior.condition_on_observations(Y, X, b=b)
+    Ld = (-1.0 * diffops.Laplacian((2,)))(dense)
+    md, vd = Ld.predict(Xt)
+    saved = (lp.config.matrix_free, lp.config.matrix_free_rtol)
+    lp.config.matrix_free, lp.config.matrix_free_rtol = True, 1e-12
+    try:
+        free = prior.condition_on_observations(Y, X, b=b)
+        Lf = (-1.0 * diffops.Laplacian((2,)))(free)
+        mf_, vf = Lf.predict(Xt)
+        rv = Lf(Xt)
+        with pytest.raises(NotImplementedError):
+            Lf.condition_on_observations(Y[:3], X[:3])
+    finally:
+        lp.config.matrix_free, lp.config.matrix_free_rtol = saved
+    assert type(Lf).__name__ == "MatrixFreeConditionalGaussianProcess"
+    assert np.max(np.abs(mf_ - md)) <= 1e-7 * np.max(np.abs(md))
+    assert np.max(np.abs(vf - vd)) <= 1e-7 * np.max(np.abs(vd))
+    np.testing.assert_allclose(np.diag(rv.cov), vf, rtol=0, atol=1e-7 * np.max(np.abs(vd)))
+    np.testing.assert_allclose(rv.cov, Ld.cov.matrix(Xt), rtol=0, atol=1e-6 * np.max(np.abs(vd)))
