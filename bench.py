@@ -550,7 +550,9 @@ def main():
     mode_name = "two_pipelines" if (distributed or not bench_lazy) else "fused_factor_and_predict"
     two_pipeline_ms = dt / args.steps * 1e3 if mode_name == "two_pipelines" else None
     tp_syrk = None
-    if two_pipeline_ms is None:
+    # (LPGP_BENCH_NO_MODES -- set by the profile collections only, scratch/collect_profiles.sh: the profiled process must contain ONE
+    #  schedule, or the per-kernel averages of rocprofv3 --stats mix the two)
+    if two_pipeline_ms is None and not os.environ.get("LPGP_BENCH_NO_MODES"):
         saved_lazy = lp.config.lazy_factorization
         try:
             lp.config.lazy_factorization = False
@@ -876,7 +878,7 @@ def main():
     }
     out["mode"] = mode_name
     out["two_pipeline_ms_per_step"] = two_pipeline_ms
-    out["two_pipeline_value"] = (world if replicas else 1) * flops / (two_pipeline_ms * 1e-3) / 1e9
+    out["two_pipeline_value"] = None if two_pipeline_ms is None else (world if replicas else 1) * flops / (two_pipeline_ms * 1e-3) / 1e9
     if tp_syrk is not None and tp_syrk["ms"] > 0:
         ach_tp = tp_syrk["flops"] / (tp_syrk["ms"] * 1e-3) / 1e12
         out["roofline"]["two_pipeline_mode"] = {

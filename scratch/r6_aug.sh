@@ -7,7 +7,7 @@ export LPGP_BENCH_NO_MODES=1
 for rep in 1 2; do
   for aug in 0 1; do
     echo "== c3 aug=$aug rep=$rep"
-    LPGP_GRAM_CAPACITY_HINT=21248 LPGP_RIDE_AUG=$aug timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu ${EXTRA:-} 2>&1 | tail -1 | python -c "
+    LPGP_RIDE_AUG=$aug timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu ${EXTRA:-} 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('ms_per_step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'step_frac', d['roofline'].get('step_frac_of_peak'), 'parity', d.get('parity'))
