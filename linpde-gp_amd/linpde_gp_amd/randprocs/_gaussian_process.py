@@ -489,6 +489,17 @@ class ConditionalGaussianProcess(GaussianProcess):
         Yf, Lf, bf, Xpts, coeffs, pred_mean = self._preprocess_observations(
             prior=self._prior, Y=Y, X=X, L=L, b=b)
         block = _ObservationBlock(Yf, Lf, bf, Xpts, coeffs, Lf.device_points(self._state.ctx), pred_mean)
+        from .. import config
+        if config.matrix_free_above and not self._state.ctx.distributed and \
+                sum(ob.points.n for ob in self._blocks) + block.points.n > int(config.matrix_free_above):
+            # (the threshold used to be consulted at the FIRST conditioning only -- a dense posterior re-conditioned past it
+            #  stayed dense and could run out of memory.)  The chain continues matrix-free on the same observation blocks; the weights
+            #  of this posterior, if they exist, warm-start the solve.
+            from ._matrix_free import MatrixFreeConditionalGaussianProcess
+            warm = None
+            if self._representer_weights is not None:
+                warm = np.concatenate([np.asarray(self._representer_weights, dtype=np.double), np.zeros(block.points.n)])
+            return MatrixFreeConditionalGaussianProcess(self._prior, self._blocks + (block,), warm_start=warm)
         return ConditionalGaussianProcess._extend(self._prior, self._state, self._blocks, block)
 
     @classmethod

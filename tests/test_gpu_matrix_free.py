@@ -172,3 +172,31 @@ def test_operators_apply_to_a_matrix_free_posterior(lp):
     assert np.max(np.abs(vf - vd)) <= 1e-7 * np.max(np.abs(vd))
     np.testing.assert_allclose(np.diag(rv.cov), vf, rtol=0, atol=1e-7 * np.max(np.abs(vd)))
     np.testing.assert_allclose(rv.cov, Ld.cov.matrix(Xt), rtol=0, atol=1e-6 * np.max(np.abs(vd)))
+
+
+def test_a_dense_chain_continues_matrix_free_past_the_threshold(lp):
+    """`matrix_free_above` is consulted at EVERY conditioning: a dense posterior conditioned past it continues without a
+    Gram matrix, on the same observation blocks, and agrees with the all-dense chain."""
+    from linpde_gp_amd.randprocs._matrix_free import MatrixFreeConditionalGaussianProcess
+    cf = lp.randprocs.covfuncs
+    rng = np.random.default_rng(9)
+    X0, X1 = rng.uniform(-1, 1, (300, 2)), rng.uniform(-1, 1, (250, 2))
+    Y0, Y1 = np.sin(3 * X0[:, 0]) + X0[:, 1], np.sin(3 * X1[:, 0]) + X1[:, 1]
+    prior = lp.GaussianProcess(lp.functions.Zero((2,)), cf.TensorProduct(cf.Matern((), nu=2.5, lengthscales=0.5), cf.Matern((), nu=2.5, lengthscales=0.5)))
+    b0, b1 = lp.randvars.Normal(np.zeros(300), np.full(300, 1e-2)), lp.randvars.Normal(np.zeros(250), np.full(250, 1e-2))
+    Xt = rng.uniform(-1, 1, (20, 2))
+    dense = prior.condition_on_observations(Y0, X0, b=b0).condition_on_observations(Y1, X1, b=b1)
+    md, vd = dense.predict(Xt)
+    saved = (lp.config.matrix_free_above, lp.config.matrix_free_rtol)
+    lp.config.matrix_free_above, lp.config.matrix_free_rtol = 400, 1e-12
+    try:
+        u0 = prior.condition_on_observations(Y0, X0, b=b0)
+        assert type(u0).__name__ == "ConditionalGaussianProcess"
+        _ = u0.representer_weights
+        u1 = u0.condition_on_observations(Y1, X1, b=b1)
+        assert isinstance(u1, MatrixFreeConditionalGaussianProcess)
+        mf_, vf = u1.predict(Xt)
+    finally:
+        lp.config.matrix_free_above, lp.config.matrix_free_rtol = saved
+    assert np.max(np.abs(mf_ - md)) <= 1e-8 * np.max(np.abs(md))
+    assert np.max(np.abs(vf - vd)) <= 1e-7 * np.max(np.abs(vd))
