@@ -413,7 +413,6 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_AUG")) ctx->ride_aug = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_B_ON_RIDE")) ctx->ride_b_on_ride = std::atoi(e);
-  if (const char* e = std::getenv("LPGP_UNMASK_RATIO")) ctx->unmask_ratio = std::atof(e);
   if (const char* e = std::getenv("LPGP_APPEND_SPLIT")) ctx->append_split = std::atoi(e);
   if (const char* e = std::getenv("LPGP_APPEND_SPLIT_MIN_TILES")) ctx->append_split_min_tiles = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OLD_UNGATED")) ctx->ride_old_ungated = std::atoi(e);

@@ -101,7 +101,6 @@ struct lpgp_ctx {
   int append_split = 0;                // (OFF: measured flat, c3 50.3-50.8 either way, profiles/r06_append_split_ab.txt) block append: the last old panel's update of the new block split into the first new panel's columns (panel stream) and the
   int append_split_min_tiles = 16;     // remainder (update stream, under the first new chain), for new blocks of at least this many tile rows (LPGP_APPEND_SPLIT)
   hipEvent_t ev_append[2] = {nullptr, nullptr};
-  double unmask_ratio = 0.0;           // remainder updates estimated this many times longer than the chain run on the UNMASKED stream (0: never; LPGP_UNMASK_RATIO)
   int ride_b_on_ride = 0;              // ... the factorisation's remainder updates queue on the substitution's stream once its gate is open (LPGP_RIDE_B_ON_RIDE)
   int ride_aug = 0;                    // ... or, where the matrix has room for it, as ROWS of the matrix being factored (potrf.hip: augmented form; LPGP_RIDE_AUG)
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in

@@ -339,10 +339,6 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
       //  step of the panel it belongs to: one update grid at a time -- the factorisation's and the substitution's launches alternate
       //  instead of sharing the chip -- with the panel chain beside it)
       if (ctx->ride_b_on_ride && ride && ride->open && ride->stream != sP && ride->held.empty()) sB = ride->stream;
-      // (round 6, option unmask_ratio: while the remainder update is estimated this many times longer than the chain beside it, it runs
-      //  UNMASKED -- 65 instead of 58 TFLOP/s alone -- and the chain's kernels wait for retiring workgroups' slots instead of finding
-      //  reserved CUs; 0: never)
-      if (ctx->unmask_ratio > 0.0 && t_b_us > ctx->unmask_ratio * t_chain_us && ctx->s_upd_all && ctx->s_upd_all != sP && !(ride && ride->open)) sB = ctx->s_upd_all;
       if (last_upd) LPGP_HIP(hipStreamWaitEvent(sB, last_upd, 0));     // behind the previous remainder update
       if (dep_pending_u) {
         LPGP_HIP(hipStreamWaitEvent(sB, dep, 0));
