@@ -410,6 +410,8 @@ int lpgp_init(int device, lpgp_ctx** out) {
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT")) ctx->chain_resident_max_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_TRSV_RESIDENT")) ctx->trsv_resident = std::atoi(e);
   if (const char* e = std::getenv("LPGP_CHAIN_RESIDENT2")) ctx->chain_resident2_max_rows = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_CHAIN_AHEAD")) ctx->chain_ahead = std::atoi(e);
+  if (const char* e = std::getenv("LPGP_CHAIN_AHEAD_MIN_ROWS")) ctx->chain_ahead_min_rows = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_OCC3")) ctx->ride_occ3 = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_AUG")) ctx->ride_aug = std::atoi(e);
   if (const char* e = std::getenv("LPGP_RIDE_B_ON_RIDE")) ctx->ride_b_on_ride = std::atoi(e);
@@ -599,6 +601,8 @@ int lpgp_get_option(lpgp_ctx* ctx, const char* key, int64_t* value) {
   else if (std::strcmp(key, "chain_resident_max_rows") == 0) *value = ctx->chain_resident_max_rows;
   else if (std::strcmp(key, "trsv_resident") == 0) *value = ctx->trsv_resident;
   else if (std::strcmp(key, "chain_resident2_max_rows") == 0) *value = ctx->chain_resident2_max_rows;
+  else if (std::strcmp(key, "chain_ahead") == 0) *value = ctx->chain_ahead;
+  else if (std::strcmp(key, "chain_ahead_min_rows") == 0) *value = ctx->chain_ahead_min_rows;
   else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) *value = ctx->ride_vchain_max_wgs;
   else if (std::strcmp(key, "ride_occ3") == 0) *value = ctx->ride_occ3;
   else if (std::strcmp(key, "ride_aug") == 0) *value = ctx->ride_aug;
@@ -687,6 +691,10 @@ int lpgp_set_option(lpgp_ctx* ctx, const char* key, int64_t value) {
     ctx->trsv_resident = value != 0;
   } else if (std::strcmp(key, "chain_resident2_max_rows") == 0) {
     ctx->chain_resident2_max_rows = (int)value;
+  } else if (std::strcmp(key, "chain_ahead") == 0) {
+    ctx->chain_ahead = value != 0;
+  } else if (std::strcmp(key, "chain_ahead_min_rows") == 0) {
+    ctx->chain_ahead_min_rows = (int)value;
   } else if (std::strcmp(key, "ride_vchain_max_wgs") == 0) {
     ctx->ride_vchain_max_wgs = (int)value;
   } else if (std::strcmp(key, "ride_occ3") == 0) {

@@ -42,7 +42,7 @@
 
 namespace lpgp {
 
-constexpr int CH_SLOT_INTS = 32;          // F[0..3] | S(k, j) at 4 + 3 (k - 1) + j, k = 1..3, j < k | U_k at 12 + k | abort at 16
+constexpr int CH_SLOT_INTS = 32;          // F[0..3] | S(k, j) at 4 + 3 (k - 1) + j, k = 1..3, j < k | U_k at 12 + k, k = 1..3 | abort at 16 | U_0 at 17
 constexpr int CH_SLOTS = 64;
 constexpr int CH_SPIN_LIMIT = 4000000;    // polls of ~0.25 us each: one second
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ void ch_publish(int* word, bool add) {
 }
 
 __device__ __forceinline__ int* ch_S(const ChainArgs& g, int k, int j) { return g.slot + 4 + 3 * (k - 1) + j; }
-__device__ __forceinline__ int* ch_U(const ChainArgs& g, int k) { return g.slot + 12 + k; }
+__device__ __forceinline__ int* ch_U(const ChainArgs& g, int k) { return k == 0 ? g.slot + 17 : g.slot + 12 + k; }      // (U_0: only with the fused look-ahead)
 
 // ---- rows: the fused panel chain of solve_panel.h (NT = 4, 32 rows per workgroup, row form) with hand-overs ----
 // tr: tile of the diagonal block the rows lie in (1..3), or 4 for rows below it; row_rel: first row relative to the block's first
@@ -100,12 +100,16 @@ __device__ __forceinline__ int* ch_U(const ChainArgs& g, int k) { return g.slot 
 // column * ldv, ldv, 1)
 // RG = 2: eight waves, 32 rows per workgroup (one per CU beside the factor workgroup's 152 KB); RG = 1: four waves, 16 rows, 68 KB of
 // LDS -- two workgroups per CU (panel_chain_rows_kernel: the rows below a WIDE panel, round 6)
-template <int RG>
+// NP = 4 (round 6): the LOOK-AHEAD update by the previous panel -- A_i -= X_prev,j L_prev,ij^T for this workgroup's rows, the launch
+// factor_columns otherwise puts between two chains -- rides in front of the chain (sixteen more products; the form of
+// panel_solve_kernel<NT, RG, true, 4>).  It needs nothing of THIS panel, so it runs while the factor workgroup waits for the four
+// workgroups of tile 0's rows (tr = 0: a role that exists only with NP > 0), which publish U_0.
+template <int RG, int NP = 0>
 __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr, double* base, const int64_t lane_step, const int64_t cstep,
                                                 double* smem) {
   constexpr int NT = 4;
-  constexpr PsvSched<NT, 0> SCH = psv_make_sched<NT, 0>(4 / RG);
-  static_assert(psv_sched_ok<NT, RG, 0>(), "resident chain: broken stage schedule");
+  constexpr PsvSched<NT, NP> SCH = psv_make_sched<NT, NP>(4 / RG);
+  static_assert(psv_sched_ok<NT, RG, NP>(), "resident chain: broken stage schedule");
   constexpr int XA = RG * 32 * 64;
   double* xa = smem;
   double* ring = smem + XA;
@@ -122,15 +126,20 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
 
   auto issue = [&](auto S_) {
     constexpr int s = decltype(S_)::value;
-    constexpr PsvProd pd = psv_prod(NT, s / 8, 0);
-    constexpr int kt = s % 8, stride = psv_stride<NT, 0>(s);
+    constexpr PsvProd pd = psv_prod(NT, s / 8, NP);
+    constexpr int kt = s % 8, stride = psv_stride<NT, NP>(s);
     constexpr bool tri = pd.kind < 3;
     constexpr int len = tri ? 128 - 16 * kt : 128, col0 = tri ? 16 * kt : 0;
-    const double* lbase = (pd.kind == 0 || pd.kind == 2) ? linv : Lblk;
     int64_t ldl_ = ldl;
+    // (kind 4: the factor's block LEFT of the diagonal block -- this panel's rows, the previous panel's columns)
+    const double* lbase = (pd.kind == 0 || pd.kind == 2) ? linv : (pd.kind == 4 ? Lblk - (int64_t)NP * TILE * ldl : Lblk);
     asm volatile("" : "+s"(lbase), "+s"(ldl_));
-    const double* M = (pd.kind == 0 || pd.kind == 2) ? lbase + (int64_t)pd.j * TILE * TILE
-                                                      : lbase + (int64_t)pd.i * TILE + (int64_t)pd.j * TILE * ldl_;
+    // (the look-ahead products run i-MAJOR here -- product p < NP * NT is tile row i = p / NP of the panel against the previous
+    //  panel's column tile j = p % NP -- so that a workgroup that owns rows of tile tr is done with them after (tr + 1) * NP
+    //  products; all kind-4 stages have one size, the stage schedule does not care)
+    constexpr int pi = pd.kind == 4 ? (s / 8) / (NP > 0 ? NP : 1) : pd.i, pj = pd.kind == 4 ? (s / 8) % (NP > 0 ? NP : 1) : pd.j;
+    const double* M = (pd.kind == 0 || pd.kind == 2) ? lbase + (int64_t)pj * TILE * TILE
+                                                      : lbase + (int64_t)pi * TILE + (int64_t)pj * TILE * ldl_;
     const int64_t ldm = (pd.kind == 0 || pd.kind == 2) ? (int64_t)TILE : ldl_;
     double* sb = ring + SCH.off[s];
     if (2 * lane < len) {
@@ -164,12 +173,21 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[t][q] = pbase[(t * TILE + q * 16) * cstep];
-  wait_column(0);                                           // (the loads above are waited for inside)
+  // (NP > 0) the first operand image is the previous panel's first solved tile of these rows, negated
+  double vp[8];
+  if constexpr (NP > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vp[q] = pbase[(-(NP * TILE) + q * 16) * cstep];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSV_BARRIER();
+  } else {
+    wait_column(0);                                         // (the loads above are waited for inside)
+  }
   asm volatile("" ::: "memory");
   issue(std::integral_constant<int, 0>{});
   double* const xown = xa + (size_t)(rg * 32 + cc) * 64 + lane;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) xown[q * 256] = a[0][q];
+  for (int q = 0; q < 8; ++q) xown[q * 256] = NP > 0 ? -vp[q] : a[0][q];
   asm volatile("" ::: "memory");
   static_for<1, SCH.iss_hi[0]>(issue);
   const unsigned mlane = lds_base + 8u * (unsigned)(rg * 2048 + lane);
@@ -178,11 +196,11 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
 
   auto run_product = [&](auto P_, double(&dst)[8], const bool active) {
     constexpr int prod = decltype(P_)::value;
-    constexpr bool tri = psv_prod(NT, prod, 0).kind < 3;
+    constexpr bool tri = psv_prod(NT, prod, NP).kind < 3;
     static_for<0, 8>([&](auto KT_) {
       constexpr int kt = decltype(KT_)::value;
       constexpr int s = prod * 8 + kt;
-      constexpr int stride = psv_stride<NT, 0>(s);
+      constexpr int stride = psv_stride<NT, NP>(s);
       constexpr int q0 = tri ? kt : 0;
       vm_wait_n<SCH.wait[s]>();
       TSV_BARRIER();
@@ -218,10 +236,53 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
     });
   };
 
+  // ---- (NP > 0) the fused look-ahead update: the previous panel applied to this workgroup's rows of the panel's columns ----
+  // i-major: tile column i of the panel gets its NP products in a row; rows of the diagonal block's tile tr stop after column tr
+  // (columns beyond lie above the diagonal) and go straight to their chain -- the stages of the skipped products that are already
+  // in flight land in the ring unread, the hand-over below drains and re-issues as at every hand-over.
+  static_for<0, NT>([&](auto I_) {
+    constexpr int i = decltype(I_)::value;
+    if (below || i <= tr) {
+      static_for<0, NP>([&](auto JP_) {
+        constexpr int jp = decltype(JP_)::value;
+        if constexpr (i > 0 || jp > 0) {
+          TSV_BARRIER();                                       // the previous product has read the fragment image
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xown[q * 256] = -vp[q];
+        }
+        {                                                      // the next operand (the same rows' next solved tile of the previous panel), in flight under this product
+          constexpr int jn = (jp + 1) % NP;
+          int64_t cs = cstep;
+          asm volatile("" : "+s"(cs));                         // (re-formed per product: hoisted, the 32 addresses of the four operand tiles cost 64 registers)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) vp[q] = pbase[(-(NP * TILE) + jn * TILE + q * 16) * cs];
+        }
+        run_product(std::integral_constant<int, i * NP + jp>{}, a[i], true);      // A_i -= Xprev_jp Lprev_{i,jp}^T
+      });
+    }
+  });
+  if constexpr (NP > 0) {
+    if (tr == 0) {
+      // rows of the panel's FIRST tile: their strip of the diagonal tile is complete, the factor workgroup may start
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pbase[q * 16 * cstep] = a[0][q];
+      ch_publish(ch_U(g, 0), true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (stages in flight land in this workgroup's LDS: not beyond its end)
+      return;
+    }
+  }
   static_for<0, NT>([&](auto J_) {
     constexpr int j = decltype(J_)::value;
-    constexpr int p0 = psv_first_prod(NT, j, 0);
+    constexpr int p0 = psv_first_prod(NT, j, NP);
     const bool solve = j < tr;                               // rows of tile tr are solved against the columns left of it
+    if constexpr (j == 0 && NP > 0) {
+      // column 0 becomes available (nothing of this panel was needed so far): wait, acquire, re-issue the stages in flight
+      wait_column(0);
+      static_for<8 * p0, SCH.iss_hi[8 * p0]>(issue);
+      TSV_BARRIER();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xown[q * 256] = a[0][q];
+    }
     if constexpr (j > 0) {
       if (solve) {
         // column j becomes available: drain, wait, acquire, re-issue the stages that were prefetched before it was final
@@ -284,25 +345,31 @@ __device__ __forceinline__ void chain_rows_role(const ChainArgs& g, const int tr
   }
 }
 
+// AHEAD = 4: the look-ahead update by the PREVIOUS panel (four tiles wide) rides in front of every row workgroup's chain, four more
+// workgroups own the rows of the panel's first tile (blocks 1..4), and the factor workgroup waits for them (U_0) before tile 0.
+template <int AHEAD>
 __global__ __launch_bounds__(512, 1) void panel_chain_kernel(ChainArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int b = blockIdx.x;
+  constexpr int NB0 = AHEAD ? 4 : 0;                          // workgroups of tile 0's rows
   if (b == 0) {
     // ---- factor role ----
     if (threadIdx.x < CH_SLOT_INTS) g.slot_clear[threadIdx.x] = 0;
     for (int j = 0; j < 4; ++j) {
-      if (j > 0) ch_wait(g, [&] { return ch_load(ch_U(g, j)) >= 4; });
+      if (j > 0 || AHEAD) ch_wait(g, [&] { return ch_load(ch_U(g, j)) >= 4; });
       potrf_tile_body(g.a + (int64_t)j * TILE * (g.ld + 1), g.ld, g.linv + (int64_t)j * TILE * TILE, g.info, g.info_base + j * TILE, sm);
       ch_publish(g.slot + j, false);
       TSV_BARRIER();                                          // (the tile's LDS image is reused by the next load)
     }
     return;
   }
-  if (b <= 12) {
-    const int tr = 1 + (b - 1) / 4, w = (b - 1) & 3;
-    chain_rows_role<2>(g, tr, g.a + (int64_t)tr * TILE + 32 * w, 1, g.ld, sm);
+  if (b <= NB0) {
+    chain_rows_role<2, AHEAD>(g, 0, g.a + 32 * (b - 1), 1, g.ld, sm);
+  } else if (b <= NB0 + 12) {
+    const int tr = 1 + (b - NB0 - 1) / 4, w = (b - NB0 - 1) & 3;
+    chain_rows_role<2, AHEAD>(g, tr, g.a + (int64_t)tr * TILE + 32 * w, 1, g.ld, sm);
   } else {
-    chain_rows_role<2>(g, 4, g.a + (int64_t)4 * TILE + 32 * (int64_t)(b - 13), 1, g.ld, sm);
+    chain_rows_role<2, AHEAD>(g, 4, g.a + (int64_t)4 * TILE + 32 * (int64_t)(b - NB0 - 13), 1, g.ld, sm);
   }
 }
 
@@ -328,7 +395,9 @@ __global__ __launch_bounds__(256, 2) void panel_chain_rows_kernel(ChainArgs g) {
 // The chain of panel [p0, p0 + 4) of the padded matrix, all rows down to tile T, on `stream`.
 // rows_here = false: the factor workgroup and the twelve in-block row workgroups only; the rows below follow through the flags
 // in a launch of their own (launch_panel_chain_rows).
-int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here) {
+// ahead = true: the look-ahead update by the previous panel (columns [p0 - 4, p0), all rows from p0 on) is part of the launch.
+int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here, bool ahead) {
+  LPGP_CHECK(!ahead || (p0 >= 4 && rows_here), "resident chain: the fused look-ahead needs a previous panel of four tiles and the rows in the same launch");
   const int64_t ld = mat->cap;
   if (!ctx->d_chain_flags) {
     LPGP_HIP(hipMalloc(&ctx->d_chain_flags, (size_t)CH_SLOTS * CH_SLOT_INTS * sizeof(int)));
@@ -348,10 +417,13 @@ int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0,
   g.n_below = rows_here ? (T - p0 - 4) * (TILE / 32) : 0;
   const size_t shmem = (size_t)TILE_LDS_DOUBLES * sizeof(double);
   static_assert((size_t)TILE_LDS_DOUBLES >= (size_t)(2 * 32 * 64 + TSV_RING), "resident chain: the tile image must cover the row role's LDS");
-  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(&panel_chain_kernel), shmem));
+  void (*kfn)(ChainArgs) = ahead ? panel_chain_kernel<4> : panel_chain_kernel<0>;
+  LPGP_TRY_RC(ensure_lds_attr(ctx, reinterpret_cast<const void*>(kfn), shmem));
   // algorithmic flops of the panel's chain: four tile Choleskys + the triangular solve of the rows below against the block
-  prof_begin(ctx, stream, LPGP_K_PANEL, 4.0 * TILE * TILE * TILE / 3.0 + (double)(T - p0 - 1) * TILE * 512.0 * 512.0 / 2.0, 0.0);
-  hipLaunchKernelGGL(panel_chain_kernel, dim3((unsigned)(13 + g.n_below)), dim3(512), shmem, stream, g);
+  // (+ the look-ahead update of the panel's columns by the previous panel, K = 512, where it rides along)
+  prof_begin(ctx, stream, LPGP_K_PANEL, 4.0 * TILE * TILE * TILE / 3.0 + (double)(T - p0 - 1) * TILE * 512.0 * 512.0 / 2.0 +
+                                            (ahead ? 2.0 * 512.0 * ((double)(T - p0) * TILE * 512.0 - 0.5 * 512.0 * 511.0) : 0.0), 0.0);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((ahead ? 17 : 13) + g.n_below)), dim3(512), shmem, stream, g);
   prof_end(ctx, stream);
   LPGP_HIP(hipGetLastError());
   return 0;

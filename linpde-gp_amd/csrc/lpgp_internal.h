@@ -106,6 +106,9 @@ struct lpgp_ctx {
   // resident panel chain (chain.hip): panels of four tiles with at most this many tile rows below them run their whole chain in
   // ONE launch whose workgroups hand over through device flags (-1: never)
   int chain_resident_max_rows = 32;
+  int chain_ahead = 1;                 // resident chain: the look-ahead update by the previous panel rides in front of the NEXT panel's chain (one launch per panel
+                                       // where two chains follow each other; LPGP_CHAIN_AHEAD=0: a launch of its own, round 5)
+  int chain_ahead_min_rows = 12;       // ... where at least this many tile rows lie below that panel (LPGP_CHAIN_AHEAD_MIN_ROWS)
   int chain_resident2_max_rows = 0;    // ... and panels with MORE rows below (up to this many tile rows) as TWO launches that talk through the same flags: factor + in-block
                                        // workgroups on the panel stream, the rows below -- 16 rows and 68 KB of LDS per workgroup, two per CU -- on an idle masked stream.
                                        // 0: never -- the default: measured SLOWER (round 6: c2 7.8 -> 8.9 ms, c3 50.2 -> 53): at 68 KB a row workgroup shares its CU with an
@@ -394,7 +397,7 @@ int launch_trsm_panel(lpgp_ctx* ctx, hipStream_t stream, double* X, int64_t ldx,
                       int nt_cols, int mt, int prof_kernel);
 
 // chain.hip: the whole chain of panel [p0, p0 + 4) (rows down to tile T) in one launch
-int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here = true);
+int launch_panel_chain(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info, bool rows_here = true, bool ahead = false);
 int launch_panel_chain_rows(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, int T, int* d_info);
 int launch_panel_chain_v(lpgp_ctx* ctx, hipStream_t stream, lpgp_mat* mat, int p0, double* V, int64_t ldv, int64_t cols, int* d_info);
 // potrf.hip -------------------------------------------------------------------------------

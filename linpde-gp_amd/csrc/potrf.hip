@@ -245,6 +245,7 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
   int have_upd_event = 0;          // ev_upd[...] recorded for the previous remainder update
   hipEvent_t last_upd = nullptr;
   int it = 0;
+  bool ahead_next = false;
   for (int p0 = c0; p0 < cl; ++it) {
     const int w0 = width_at(p0);
     const int p1 = (p0 + w0 < cl) ? p0 + w0 : cl;
@@ -255,9 +256,12 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     }
     // panel factorisation on sP: the resident chain (one launch, chain.hip) where the chain is what bounds the pipeline ...
     const bool resident = ctx->chain_resident_max_rows >= 0 && p1 - p0 == 4 && TR - p1 <= ctx->chain_resident_max_rows && !ctx->distributed();
+    const bool ahead = ahead_next;          // the previous iteration left this panel's look-ahead update to its chain kernel
+    ahead_next = false;
+    LPGP_CHECK(!ahead || resident, "factor_columns: a look-ahead update was left to a chain kernel that is not launched");
     if (resident) {
       if (ride && ride->stream != sP && ctx->ride_vchain_pre) LPGP_HIP(hipEventRecord(ctx->ev_chain_pre, sP));      // (see ride_panel_now: the step that follows the chain's flags)
-      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, TR, ctx->d_info_cur));
+      LPGP_TRY(launch_panel_chain(ctx, sP, mat, p0, TR, ctx->d_info_cur, true, ahead));
     }
     // ... a WIDER panel as two launches (round 6): the factor workgroup and the in-block rows (13 workgroups of 152 KB: thirteen CUs)
     // here, the rows below -- 16 per workgroup, 68 KB, two per CU -- on the outer-update stream, which is idle at these sizes and
@@ -319,13 +323,25 @@ static int factor_columns(lpgp_ctx* ctx, lpgp_mat* mat, int T, int c0, int cl, h
     // ~70 us alone.  While the UPDATE bounds it, (b) is released with the panel and (a) runs
     // underneath it (alone it would leave part of the chip idle).
     hipEvent_t evp = ctx->ev_panel[it & 1];
-    if (!chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    // Round 6: where the NEXT panel's chain is the resident kernel (and both panels are four tiles wide), the look-ahead update (a)
+    // is not a launch: that kernel's row workgroups apply it to their own rows in front of their chain (chain.hip, AHEAD = 4) --
+    // one launch per panel where it used to be chain, (a), chain, and no (a) that waits for slots beside the substitution's
+    // long updates (two of the nine in a c3 step took 0.98 and 0.48 ms: profiles/r05_fused_final_trace_compact.txt.gz).  Only
+    // where at least `chain_ahead_min_rows` tile rows lie below the next panel: the fused form costs the chain ~35 us (the
+    // factor workgroup waits for four products of tile 0's rows), a launch of (a) on a few tiles less than that.
+    const bool fuse_next = ctx->chain_ahead && p1 - p0 == 4 && p2 - p1 == 4 && ctx->chain_resident_max_rows >= 0 &&
+                           TR - p2 <= ctx->chain_resident_max_rows && TR - p2 >= ctx->chain_ahead_min_rows && !ctx->distributed();
+    if (!chain_bound || fuse_next) LPGP_HIP(hipEventRecord(evp, sP));
     // (a) next panel's columns on sP; they were last written by the previous remainder update
     if (have_upd_event) LPGP_HIP(hipStreamWaitEvent(sP, ctx->ev_upd[(it + 1) & 1], 0));
-    LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
-                         mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, TR - p1, p2 - p1, K, -1.0, 1.0, 3),
-                         LPGP_K_SYRK_AHEAD));
-    if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    if (fuse_next) {
+      ahead_next = true;
+    } else {
+      LPGP_TRY(launch_gemm(ctx, sP, 0, 0,
+                           mk(P, ld, P, ld, a + (int64_t)p1 * tb * (ld + 1), ld, TR - p1, p2 - p1, K, -1.0, 1.0, 3),
+                           LPGP_K_SYRK_AHEAD));
+      if (chain_bound) LPGP_HIP(hipEventRecord(evp, sP));
+    }
     // (b) remainder on an update stream.  Once its estimated duration even on the narrow stream
     // (which leaves a quarter of the CUs to the panel chain) is below that of the chain, it moves
     // there.

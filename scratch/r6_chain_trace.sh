@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 D=gpurun_out/r6_chain_trace; rm -rf $D; mkdir -p $D
 export LPGP_BENCH_NO_MODES=1 LPGP_BENCH_PROF_STEPS=1
-LPGP_CHAIN_RESIDENT2=${R2:-56} rocprofv3 --kernel-trace --output-format csv -d $D -- python3 bench.py --workload poisson1d --steps 3 --warmup 2 --no-cpu > $D/log.txt 2>&1
+LPGP_CHAIN_RESIDENT2=${R2:-0} LPGP_CHAIN_AHEAD=${AH:-1} rocprofv3 --kernel-trace --output-format csv -d $D -- python3 bench.py --workload ${WL:-poisson1d} --steps 3 --warmup 2 --no-cpu > $D/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob
 f = max(glob.glob("gpurun_out/r6_chain_trace/**/*kernel_trace.csv", recursive=True))

@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 def ctx():
     from linpde_gp_amd import _engine
     c = _engine.default_context()
-    saved = c.get_option("chain_resident_max_rows"), c.get_option("chain_resident2_max_rows")
+    saved = c.get_option("chain_resident_max_rows"), c.get_option("chain_resident2_max_rows"), c.get_option("chain_ahead"), c.get_option("chain_ahead_min_rows")
     yield c
     c.set_option("chain_resident_max_rows", saved[0])
     c.set_option("chain_resident2_max_rows", saved[1])
+    c.set_option("chain_ahead", saved[2])
+    c.set_option("chain_ahead_min_rows", saved[3])
 
 
 def _posterior(lp, n, seed, noise=1e-3, ls=0.35):
@@ -149,6 +151,42 @@ def test_two_kernel_resident_chain_equals_the_tile_by_tile_chain(ctx, n):
     # the fused pipeline over the same panels
     ctx.set_option("chain_resident_max_rows", 0)
     ctx.set_option("chain_resident2_max_rows", 64)
+    lp.config.lazy_factorization = True
+    try:
+        m2, v2 = prior.condition_on_observations(Y, X, b=b).predict(Xt)
+    finally:
+        lp.config.lazy_factorization = False
+    assert np.max(np.abs(m2 - m)) <= 1e-11 * np.max(np.abs(m)) and np.max(np.abs(v2 - v)) <= 1e-10 * np.max(np.abs(v))
+
+
+@pytest.mark.parametrize("n", [1500, 4608, 8320])
+def test_look_ahead_update_fused_into_the_next_chain(ctx, n):
+    """Round 6: where two resident panels follow each other the look-ahead update between them is not a launch -- the NEXT chain
+    kernel's row workgroups apply it to their own rows first (`panel_chain_kernel<4>`: sixteen more products per row workgroup,
+    four workgroups for the rows of the panel's first tile, the factor workgroup waits for them).  Forced on every eligible panel
+    (no minimum of rows) against the separate launch: same factor to 1e-12, fewer look-ahead launches, posterior against the oracle;
+    default mode and the fused factor-and-predict pipeline."""
+    import linpde_gp_amd as lp
+    prior, okern, X, Y, b = _posterior(lp, n, seed=n + 7)
+    Xt = np.random.default_rng(2).uniform(-1, 1, (21, 2))
+    ctx.set_option("chain_resident_max_rows", 64)
+    ctx.set_option("chain_ahead_min_rows", 0)
+    out = {}
+    for ahead in (1, 0):
+        ctx.set_option("chain_ahead", ahead)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        u = prior.condition_on_observations(Y, X, b=b)
+        pred = u.predict(Xt)
+        prof = ctx.profile_get(); ctx.profile_enable(False)
+        out[ahead] = (u.gram.cholesky(), pred, prof["syrk_lookahead"]["launches"] + prof["gemm_small"]["launches"], np.array(u.representer_weights))
+        del u
+    assert out[1][2] < out[0][2], (out[1][2], out[0][2])                 # look-ahead launches disappeared
+    assert np.max(np.abs(out[1][0] - out[0][0])) <= 1e-12 * np.max(np.abs(out[0][0]))
+    post = ogp.condition(okern, [ogp.ObsBlock(X, ocf.identity(2), Y, 0.0, 1e-3)])
+    m, v = out[1][1]
+    assert np.max(np.abs(m - post.mean(Xt))) <= 1e-8 * np.max(np.abs(post.mean(Xt)))
+    assert np.max(np.abs(v - post.var(Xt))) <= 1e-8 * np.max(np.abs(post.var(Xt)))
+    ctx.set_option("chain_ahead", 1)
     lp.config.lazy_factorization = True
     try:
         m2, v2 = prior.condition_on_observations(Y, X, b=b).predict(Xt)
