@@ -259,7 +259,10 @@ int  lpgp_mat_truncate(lpgp_ctx* ctx, lpgp_mat* mat, int32_t nblocks);
 /* x = G^{-1} b for nrhs right-hand sides, b_host (n x nrhs, column-major, in/out)      */
 int  lpgp_potrs(lpgp_ctx* ctx, lpgp_mat* mat, double* b_host, int64_t nrhs);
 /* representer weights w = G^{-1} r; keeps w resident for lpgp_predict; w_host may be
- * NULL (_conditional.py:96-110)                                                         */
+ * NULL (_conditional.py:96-110).  Single GPU: ONE resident launch per direction whose workgroups hand the solution over
+ * block by block (csrc/trsv.hip; option "trsv_resident" / LPGP_TRSV_RESIDENT, 0: one launch per 128-row tile as in rounds
+ * 1-5); r_host and w_host pass through pinned staging, the call returns with w_host written.  A hand-over that does not
+ * arrive within its bound (a dispatch order the kernel does not expect) is reported as an error, not a hang.            */
 int  lpgp_solve_weights(lpgp_ctx* ctx, lpgp_mat* mat, const double* r_host, double* w_host);
 /* hands the residual r = Y - L[m] - b.mean (_conditional.py:44) to the factored matrix
  * WITHOUT solving for the weights: lpgp_predict with both mean and variance requested then

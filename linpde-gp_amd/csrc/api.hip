@@ -1934,7 +1934,10 @@ int lpgp_rhs_matmul(lpgp_ctx* ctx, const lpgp_rhs* A, const double* B_host, int6
     for (int64_t j = 0; j < m; ++j) hb[(size_t)(kk + j * ka)] = B_host[kk * m + j];
   void* pb = nullptr;
   const size_t bb = hb.size() * sizeof(double);
-  if (pool_alloc(ctx, &pb, bb, nullptr) != 0) return -1;
+  if (pool_alloc(ctx, &pb, bb, nullptr) != 0) {
+    (void)lpgp_rhs_destroy(out);
+    return -1;
+  }
   int rc = 0;
   if (hipMemcpyAsync(pb, hb.data(), bb, hipMemcpyHostToDevice, ctx->s_main) != hipSuccess) rc = -1;
   if (rc == 0) {

@@ -175,7 +175,12 @@ int lpgp_dvec_create(lpgp_ctx* ctx, int64_t n, int64_t m, lpgp_dvec** out) {
   void* p = nullptr;
   if (pool_alloc(ctx, &p, d->bytes, nullptr) != 0) { delete d; return -1; }
   d->v = (double*)p;
-  LPGP_HIP(hipMemsetAsync(d->v, 0, d->bytes, ctx->s_main));
+  if (hipMemsetAsync(d->v, 0, d->bytes, ctx->s_main) != hipSuccess) {
+    (void)hipGetLastError();
+    pool_free(ctx, p, d->bytes);
+    delete d;
+    LPGP_CHECK(false, "lpgp_dvec_create: clearing %zu bytes failed", (size_t)((n + 63) / 64 * 64) * (size_t)m * sizeof(double));
+  }
   *out = d;
   return 0;
 }
@@ -343,6 +348,9 @@ int lpgp_pcg_start(lpgp_ctx* ctx, lpgp_pcg* p, const lpgp_dvec* R, lpgp_dvec* Z,
 int lpgp_pcg_step(lpgp_ctx* ctx, lpgp_pcg* p, lpgp_dvec* X, lpgp_dvec* R, lpgp_dvec* Z, lpgp_dvec* P, const lpgp_dvec* Q, double rtol, double* rel_host) {
   LPGP_CHECK(ctx && p && X && R && Z && P && Q && rel_host, "lpgp_pcg_step: null argument");
   LPGP_DEVICE(ctx);
+  for (const lpgp_dvec* d : {(const lpgp_dvec*)X, (const lpgp_dvec*)R, (const lpgp_dvec*)Z, (const lpgp_dvec*)P, Q})
+    LPGP_CHECK(d->n == p->n && d->m == p->m, "lpgp_pcg_step: a vector block of %lld x %lld where the iteration was created for %lld x %lld", (long long)d->n,
+               (long long)d->m, (long long)p->n, (long long)p->m);
   hipStream_t st = ctx->s_main;
   const dim3 gv((unsigned)((p->n + 255) / 256), (unsigned)p->m);
   hipLaunchKernelGGL(pcg_dot_kernel, dim3(PCG_G, (unsigned)p->m), dim3(256), 0, st, (const double*)P->v, (const double*)Q->v, p->n, P->ld, p->part());
