@@ -18,10 +18,12 @@ INDEPENDENTLY of both: kernel entries by SymPy differentiation of the base kerne
                   (noise 1e-4)  (c5's algebra at N = 29)
     neumann_*     prior 1.5^2 isotropic Matern-5/2 (l = 0.9, 0.7) in 2-D; blocks: 9 noisy values (1e-4), then 5 Neumann
                   observations -0.8 <n, grad u> at boundary points (noise 1e-4)
+    expquad2d_*   prior 1.7 ExpQuad(l=0.6) x ExpQuad(l=0.8), L = -Laplace: c3's block structure on the OTHER kernel family of the
+                  path (`diffops/_expquad.py:12-433`): 4 edges x 4 values (noise 1e-6), then 4 x 4 collocation points, f = 2 (noise 1e-6)
   For every problem: the point sets, right-hand sides, noise levels, cond_2 of the fp64 Gram matrix, representer weights,
   posterior mean and variance at the test points.
 
-Run:  python tests/golden/make_golden_multiblock.py      (a few minutes: ~1e5 SymPy-lambdified kernel entries at 50 digits)
+Run:  python tests/golden/make_golden_multiblock.py [problem ...]     (a few minutes: ~1e5 SymPy-lambdified kernel entries at 50 digits)
 """
 import os
 import sys
@@ -89,6 +91,32 @@ def poisson2d():
         out[f"poisson2d_X{i}"] = X
         out[f"poisson2d_Y{i}"] = ys[i]
     print(f"poisson2d: N = {sum(len(y) for y in ys)}, cond_2(G) = {cond:.2e}")
+    return out
+
+
+def expquad2d():
+    fac = [("expquad", 0.6), ("expquad", 0.8)]
+    scale = 1.7
+    ident, lap = {(0, 0): 1}, {(2, 0): -1, (0, 2): -1}
+    s = np.linspace(-1.0 + 1e-6, 1.0 - 1e-6, 4)
+    edges = [np.column_stack([np.full(4, -1.0), s]), np.column_stack([np.full(4, 1.0), s]),
+             np.column_stack([s, np.full(4, -1.0)]), np.column_stack([s, np.full(4, 1.0)])]
+    g = np.linspace(-0.7, 0.7, 4)
+    Xp = np.array([[a, b] for a in g for b in g])
+    Xs = edges + [Xp]
+    Ls = [ident] * 4 + [lap]
+    ys = [np.zeros(4)] * 4 + [np.full(16, 2.0)]
+    noises = ["1e-6"] * 5
+    Xt = np.array([[0.0, 0.0], [0.31, -0.42], [-0.55, 0.6], [0.8, 0.15], [-0.2, -0.85], [0.47, 0.53]])
+    w, mean, var, cond = solve_posterior(
+        lambda i, j: block(fac, scale, Ls[i], Ls[j], Xs[i], Xs[j]), noises, ys,
+        lambda i: block(fac, scale, ident, Ls[i], Xt, Xs[i]), lambda t: mpmath.mpf(scale), Xt)
+    out = {"expquad2d_Xt": Xt, "expquad2d_weights": w, "expquad2d_mean": mean, "expquad2d_var": var, "expquad2d_cond": cond,
+           "expquad2d_noise": np.array([float(v) for v in noises])}
+    for i, X in enumerate(Xs):
+        out[f"expquad2d_X{i}"] = X
+        out[f"expquad2d_Y{i}"] = ys[i]
+    print(f"expquad2d: N = {sum(len(y) for y in ys)}, cond_2(G) = {cond:.2e}")
     return out
 
 
@@ -187,11 +215,14 @@ def neumann():
 
 
 def main():
-    out = {}
-    out.update(poisson2d())
-    out.update(heat())
-    out.update(neumann())
-    np.savez(os.path.join(HERE, "posterior_multiblock.npz"), **out)
+    path = os.path.join(HERE, "posterior_multiblock.npz")
+    makers = {"poisson2d": poisson2d, "heat": heat, "neumann": neumann, "expquad2d": expquad2d}
+    only = sys.argv[1:]                      # `... expquad2d`: recompute that problem only, keep the others' committed vectors
+    out = dict(np.load(path)) if only and os.path.exists(path) else {}
+    for name, fn in makers.items():
+        if not only or name in only:
+            out.update(fn())
+    np.savez(path, **out)
     print("wrote posterior_multiblock.npz")
 
 

@@ -142,6 +142,9 @@ def _multiblock_device_posterior(lp, g, name):
     elif name == "heat":
         prior = lp.GaussianProcess(lp.functions.Zero((2,)), cf.TensorProduct(cf.Matern((), nu=1.5, lengthscales=2.5), cf.Matern((), nu=2.5, lengthscales=2.0)))
         ops = [None] * 3 + [diffops.HeatOperator((2,), alpha=0.1), None]
+    elif name == "expquad2d":
+        prior = lp.GaussianProcess(lp.functions.Zero((2,)), 1.7 * cf.TensorProduct(cf.ExpQuad((), lengthscales=0.6), cf.ExpQuad((), lengthscales=0.8)))
+        ops = [None] * 4 + [-1.0 * diffops.Laplacian((2,))]
     else:
         prior = lp.GaussianProcess(lp.functions.Zero((2,)), float(g["neumann_scale"]) * cf.Matern((2,), nu=2.5, lengthscales=g["neumann_lengthscales"]))
         u = prior.condition_on_observations(g["neumann_Yv"], X=g["neumann_Xv"], b=lp.randvars.Normal(np.zeros(9), 1e-4 * np.eye(9)))
@@ -158,11 +161,12 @@ def _multiblock_device_posterior(lp, g, name):
 
 
 @pytest.mark.parametrize("lazy", [False, True], ids=["default", "fused"])
-@pytest.mark.parametrize("name", ["poisson2d", "heat", "neumann"])
+@pytest.mark.parametrize("name", ["poisson2d", "heat", "neumann", "expquad2d"])
 def test_multiblock_posteriors_vs_golden(golden_dir, name, lazy):
     """Round 6: the multi-block conditioning algebra of c3 (four boundary blocks with a nugget + a PDE block:
     five conditionings, block appends), c5 (initial condition, two boundary conditions, heat collocation, noisy interior values)
-    and the Neumann blocks of the CPU-die experiment (isotropic Matern, one functional per boundary point) through the C ABI
+    and the Neumann blocks of the CPU-die experiment (isotropic Matern, one functional per boundary point), c3's blocks on an
+    ExpQuad product prior (the path's other kernel family), through the C ABI
     against posteriors solved in 50-digit mpmath from SymPy-differentiated kernels (`tests/golden/posterior_multiblock.npz`,
     `make_golden_multiblock.py`) -- independent of the oracle, which `tests/test_oracle_golden.py` holds to the same vectors.
     Mean and variance at the plain 1e-8 (north_star), in the default mode and in the fused factor-and-predict pipeline."""
